@@ -1,0 +1,170 @@
+/*
+ * magcache_hip.h -- C ABI of libmagcache_hip.so, the MI355X (gfx950) engine behind the MagCache
+ * denoising hot path.
+ *
+ * The reference (Zehong-Ma/MagCache) has no plugin API: its boundary is a monkey-patch surface,
+ *   Model.__class__.forward = magcache_forward  + class attributes cnt / num_steps / K / ...
+ *   (MagCache4Wan2.1/magcache_generate.py:896-928), called twice per step by the sampler loop
+ *   (eval/magcache/experiments/Wan2.1_EVAL/wan_magcache.py:296-299).
+ * Everything below `magcache_forward` -- embeds, the N DiT blocks, skip / residual capture, head --
+ * is what this library replaces.  The Python shim `magcache_amd.magcache_forward` keeps the
+ * reference's signature and attribute surface and binds these entry points with ctypes (see
+ * INTEGRATION.md); no torch type crosses this boundary, only device pointers, sizes and a stream.
+ *
+ * Conventions: every pointer named *_dev is device memory owned by the caller; the engine owns its
+ * weight copies and the RoPE table; scratch and the residual cache live in ONE caller-provided
+ * workspace (mc_workspace_bytes / mc_set_workspace), so nothing is allocated during a forward and
+ * a forward is graph-capture-safe.  All calls are asynchronous on the given hipStream_t.  One
+ * engine per device, not thread-safe.  Functions return mc_status; mc_last_error() gives the text.
+ */
+#ifndef MAGCACHE_HIP_H
+#define MAGCACHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mc_engine mc_engine;
+typedef void* mc_stream; /* hipStream_t */
+
+typedef enum {
+  MC_OK = 0,
+  MC_EINVAL = 1, /* shape / dtype / seq_len violation: mirrors the reference asserts
+                    (magcache_generate.py:226-227, :242, :253) */
+  MC_ENOMEM = 2,
+  MC_EHIP = 3,   /* a HIP runtime call failed */
+  MC_ESTATE = 4  /* call order violation (missing weights / workspace / cached residual) */
+} mc_status;
+
+typedef enum { MC_F32 = 0, MC_BF16 = 1 } mc_dtype;
+
+/* forward modes: what magcache_forward does between the embeds and the head */
+typedef enum {
+  MC_MODE_FULL = 0,  /* run all blocks, residual_cache[branch] = x_out - x_in   (:297-301) */
+  MC_MODE_SKIP = 1,  /* x = x_in + residual_cache[branch]                        (:294-295) */
+  MC_MODE_CALIB = 2  /* as FULL, plus norm_ratio / norm_std / cos_dis vs the
+                        previous residual of the same branch                     (:165-175) */
+} mc_mode;
+
+/* Wan DiT geometry (upstream wan/modules/model.py WanModel.__init__ arguments) + latent grid. */
+typedef struct {
+  int dim, ffn_dim, num_heads, num_layers;
+  int in_dim, out_dim, freq_dim, text_dim, text_len;
+  int latent_f, latent_h, latent_w; /* latent [in_dim, F, H, W]; patch size is (1,2,2) */
+  float eps;
+  int sp_rank, sp_size; /* sequence-parallel shard of the token axis; 0,1 for one GPU */
+  int n_branches;       /* residual-cache slots: 2 for CFG models (cond/uncond), 1 otherwise */
+  int calibration;      /* reserve the extra residual slot calibration mode needs */
+} mc_config;
+
+const char* mc_last_error(void);
+const char* mc_version(void);
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+mc_status mc_create(const mc_config* cfg, mc_engine** out);
+void mc_destroy(mc_engine* e);
+size_t mc_workspace_bytes(const mc_engine* e);
+mc_status mc_set_workspace(mc_engine* e, void* ws_dev, size_t bytes);
+/* named sub-buffer of the workspace (offset from ws_dev): "x", "x0", "kv_gather", "kv_local",
+ * "head_tokens", "residual0", "residual1", "calib_sums", "calib_stats", ... */
+mc_status mc_buffer_info(const mc_engine* e, const char* name, size_t* offset, size_t* bytes);
+
+/* Weights by upstream state_dict name ("patch_embedding.weight", "blocks.3.self_attn.q.weight",
+ * "head.modulation", ...).  The engine keeps its own copy (bf16 for the block Linears, fp32 for
+ * norms / biases / modulation / time embedding / head), so src_dev may be freed afterwards. */
+mc_status mc_set_weight(mc_engine* e, const char* name, const void* src_dev, mc_dtype dtype, const int64_t* shape,
+                        int ndim, mc_stream stream);
+int mc_weights_missing(const mc_engine* e, char* buf, size_t buflen); /* count; names into buf */
+
+/* ---- one DiT evaluation = the body of magcache_forward (:229-305) ------------------------------
+ * latent_dev : fp32 [in_dim, F, H, W]
+ * t_dev      : fp32 scalar on device, or NULL to use t_host (no device sync either way)
+ * context_dev: [ctx_len, text_dim] fp32 or bf16, ctx_len <= text_len (zero padded inside, :257-262)
+ * branch     : residual-cache slot, the reference's cnt % 2
+ * out_dev    : fp32 [out_dim, F, H, W]                                                (:312)
+ * Only for sp_size == 1; a sharded engine is driven through the phase calls below. */
+mc_status mc_forward(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
+                     const void* context_dev, mc_dtype ctx_dtype, int ctx_len, int branch, mc_mode mode,
+                     float* out_dev, mc_stream stream);
+
+/* ---- the same forward in phases (sequence parallel: the caller runs the K/V all-gather between
+ * pre_attn and post_attn of every layer with its own communicator, e.g. torch.distributed/RCCL) */
+mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
+                   const void* context_dev, mc_dtype ctx_dtype, int ctx_len, mc_stream stream);
+mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream);  /* LN+mod, QKV, qk-norm, RoPE */
+mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream);
+mc_status mc_head(mc_engine* e, int branch, mc_mode mode, mc_stream stream); /* -> "head_tokens" */
+/* tokens_dev: fp32 [n_tok, 4*out_dim] for tokens tok0..tok0+n_tok-1 -> out_dev [out_dim,F,H,W] */
+mc_status mc_unpatchify(mc_engine* e, const float* tokens_dev, int tok0, int n_tok, float* out_dev,
+                        mc_stream stream);
+
+/* calibration: stats_dev[3] = {norm_ratio, norm_std, cos_dis} of the last MC_MODE_CALIB forward
+ * of `branch`, found at "calib_stats" + 3*branch floats; mc_calib_finalize recomputes that triple
+ * from "calib_sums" (4 doubles: sum rho, sum rho^2, sum 1-cos, count) after a cross-rank sum. */
+mc_status mc_calib_ready(const mc_engine* e, int branch, int* has_stats);
+mc_status mc_calib_finalize(mc_engine* e, int branch, mc_stream stream);
+mc_status mc_state_reset(mc_engine* e); /* forget cached residuals (new video) */
+
+/* ---- host-side MagCache decision rule (reference :277-292, :306-311 and its per-model twins) --
+ * Pure host arithmetic, never touches the device.  variant: see MC_RULE_*. */
+typedef struct mc_rule mc_rule;
+enum {
+  MC_RULE_WAN21 = 0,     /* [2]-slot state, cnt >= int(n*R), '<'                                   */
+  MC_RULE_HUNYUAN = 1,   /* scalar state, cnt >= int(R*n), '<='   (magcache_sample_video.py:88-102) */
+  MC_RULE_FLUX = 2,      /* scalar, cnt >= int(R*n+0.5), '<=', step 11-of-28 never skipped
+                            (magcache_flux.py:326-338)                                              */
+  MC_RULE_WAN22_T2V = 3, /* [2]-slot, split_step gating (MagCache4Wan2.2/magcache_generate.py:294-303) */
+  MC_RULE_WAN22_I2V = 4,
+  MC_RULE_WAN22_TI2V = 5
+};
+mc_rule* mc_rule_create(int variant, int num_steps, double thresh, int K, double retention_ratio,
+                        const double* mag_ratios, int n_ratios, int split_step);
+void mc_rule_destroy(mc_rule* r);
+/* One forward call: returns 1 if this call is skipped, 0 if the blocks run; *branch = state slot.
+ * Advances cnt and resets at cnt >= num_steps exactly like the reference. */
+int mc_rule_step(mc_rule* r, int* branch);
+int mc_rule_cnt(const mc_rule* r);
+void mc_rule_state(const mc_rule* r, double acc_err[2], int acc_steps[2], double acc_ratio[2]);
+/* nearest_interp (reference :27-34); dst has target_length entries */
+void mc_nearest_interp(const double* src, int src_len, double* dst, int target_length);
+
+/* ---- single ops, exported for parity tests and micro-benchmarks --------------------------------
+ * gemm: C[M,N] = A[M,K] . W[N,K]^T  bf16 in, fp32 accumulate; epi: 0 bf16(+bias) 1 gelu_tanh->bf16
+ *       2 X += gate*bf16(acc+bias)  3 as 2 and R = X - X0  4 embed (X fp32, X0 bf16)  5 fp32 store */
+mc_status mc_op_gemm_bf16(const void* A_dev, long lda, const void* W_dev, long ldw, const float* bias_dev, int M,
+                          int N, int K, int epi, void* Cb_dev, long ldc, float* X_dev, long ldx,
+                          const float* gate_dev, const void* X0_dev, long ldx0, float* R_dev, long ldr,
+                          void* X0out_dev, long ldx0out, int m_valid, mc_stream stream);
+/* attention: head_dim 128; Q rows Lq_pad (multiple of 256); KV = n_shards shards of shard_rows rows
+ * (multiple of 64), the first shard_valid of each valid */
+mc_status mc_op_attention(const void* Q_dev, long ldq, const void* K_dev, long ldk, long k_shard_stride,
+                          const void* V_dev, long ldv, long v_shard_stride, void* O_dev, long ldo, int Lq_pad,
+                          int n_heads, int shard_rows, int shard_valid, int n_shards, float scale,
+                          mc_stream stream);
+mc_status mc_op_ln_modulate(const float* x_dev, long ldx, const void* x0_dev, long ldx0, const float* sc_dev,
+                            const float* sh_dev, int mode, float eps, void* out_bf16_dev, long ldo,
+                            float* out_f32_dev, long ldof, int M, int D, mc_stream stream);
+mc_status mc_op_rmsnorm_rope(void* x_bf16_dev, long ldx, const float* w_dev, float eps, const float* cs_dev,
+                             int cs_row0, int M, int D, mc_stream stream);
+mc_status mc_op_skip_add(const void* x0_bf16_dev, long ldx0, const float* r_dev, long ldr, float* out_dev, long ldo,
+                         int M, int D, mc_stream stream);
+mc_status mc_op_residual_sub(const float* x_dev, long ldx, const void* x0_bf16_dev, long ldx0, float* r_dev,
+                             long ldr, int M, int D, mc_stream stream);
+/* partial_dev: 4*n_blocks doubles scratch; sums_dev: 4 doubles; stats_dev: 3 floats */
+mc_status mc_op_calib_stats(const float* r_dev, long ldr, const float* rp_dev, long ldrp, int M, int D,
+                            double* partial_dev, int n_blocks, double* sums_dev, float* stats_dev,
+                            mc_stream stream);
+mc_status mc_op_cfg_euler(const float* cond_dev, const float* uncond_dev, float guide, float dt, float* x_dev,
+                          float* eps_out_dev, size_t n, mc_stream stream);
+mc_status mc_op_cast_bf16(const float* src_dev, void* dst_bf16_dev, size_t n, mc_stream stream);
+/* rope table the engine builds for a latent grid: fp32 [n_tok][64][2] (cos, sin), upstream
+ * wan/modules/model.py rope_params + rope_apply split (d-4*(d//6), 2*(d//6), 2*(d//6)), d = 128 */
+mc_status mc_op_rope_table(int F, int Hp, int Wp, int tok0, int n_tok, float* cs_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGCACHE_HIP_H */

@@ -1,0 +1,49 @@
+"""Build libmagcache_hip.so (HIP kernels + C-ABI engine) for gfx950 with hipcc, in-tree.
+
+`python -m magcache_amd.build` or `magcache_amd.build.build()`.  The .so lands next to this file so
+that it travels with the repo snapshot to the GPU box; nothing is JIT-compiled at import time.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmagcache_hip.so")
+SOURCES = ["gemm_bf16.hip", "attention.hip", "elementwise.hip", "magcache_ops.hip", "engine.cpp", "rule.cpp"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "ops.h")]
+    headers.append(os.path.join(HERE, "..", "include", "magcache_hip.h"))
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(objdir, src + ".o")
+        objs.append(op)
+        if force or _stale(op, [sp] + headers):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

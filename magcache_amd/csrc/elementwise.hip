@@ -1,0 +1,397 @@
+// Token-wise (HBM-bound) kernels of the Wan DiT forward on gfx950: AdaLN-modulated LayerNorm,
+// RMSNorm(q/k)+3-D RoPE, patch im2col / unpatchify, the fp32 time-embedding GEMVs, the fp32 head
+// Linear and the CFG + flow-Euler sampler update.  Op order follows the reference wrapper
+// MagCache4Wan2.1/magcache_generate.py:236-266 (embeds) and :304-305 (head, unpatchify); the
+// block-internal ops are upstream wan/modules/model.py (WanAttentionBlock / WanSelfAttention /
+// Head), restated in oracle/wan_dit_ref.py.
+//
+// All of these are one-wave-per-row (or grid-stride) kernels with 16-byte per-lane accesses:
+// they are bound by HBM, not by MFMA, and there is nothing to tile.
+#include "common.h"
+#include "ops.h"
+
+namespace mc {
+
+namespace {
+
+// ------------------------------------------------------------------ LayerNorm (+ modulate / affine)
+// one wave per row; lane holds NV float4 (row element e = i*256 + lane*4 + j)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, long ldx,
+                                                          const bf16_t* __restrict__ x0, long ldx0,
+                                                          const float* __restrict__ sc,
+                                                          const float* __restrict__ sh, int mode, float eps,
+                                                          bf16_t* __restrict__ out, long ldo,
+                                                          float* __restrict__ out_f32, long ldof, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  f32x4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+  if (x0) {  // fused MagCache skip: row = ori_x (bf16) + cached residual (fp32)
+    const bf16_t* x0r = x0 + (size_t)row * ldx0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      u32x2 b = *(const u32x2*)(x0r + i * 256 + lane * 4);
+      v[i][0] += __uint_as_float(b[0] << 16);
+      v[i][1] += __uint_as_float(b[0] & 0xffff0000u);
+      v[i][2] += __uint_as_float(b[1] << 16);
+      v[i][3] += __uint_as_float(b[1] & 0xffff0000u);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = v[i][j] - mean;
+      q += d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = i * 256 + lane * 4;
+    f32x4 a = *(const f32x4*)(sc + e);
+    f32x4 b = *(const f32x4*)(sh + e);
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float n = (v[i][j] - mean) * rstd;
+      y[j] = (mode == 0) ? n * (1.0f + a[j]) + b[j] : n * a[j] + b[j];
+    }
+    if (out_f32) {
+      *(f32x4*)(out_f32 + (size_t)row * ldof + e) = y;
+    } else {
+      u32x2 w = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+      *(u32x2*)(out + (size_t)row * ldo + e) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RMSNorm (+ RoPE), in place, bf16
+// one wave per row; lane element e = i*512 + lane*8 + j.  Two passes over the (L1-resident) row.
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ x, long ldx,
+                                                           const float* __restrict__ w, float eps,
+                                                           const float* __restrict__ cs, int cs_row0, int M,
+                                                           int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  bf16_t* xr = x + (size_t)row * ldx;
+  float ss = 0.f;
+  for (int e = lane * 8; e < D; e += 512) {
+    u32x4 b = *(const u32x4*)(xr + e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = __uint_as_float(b[j] << 16), hi = __uint_as_float(b[j] & 0xffff0000u);
+      ss += lo * lo + hi * hi;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  const float* csr = cs ? cs + (size_t)(cs_row0 + row) * 128 : nullptr;
+  for (int e = lane * 8; e < D; e += 512) {
+    u32x4 b = *(const u32x4*)(xr + e);
+    f32x4 w0 = *(const f32x4*)(w + e), w1 = *(const f32x4*)(w + e + 4);
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = __uint_as_float(b[j] << 16), hi = __uint_as_float(b[j] & 0xffff0000u);
+      // upstream WanRMSNorm: _norm(x.float()).type_as(x) * weight  -> bf16 rounding before the weight
+      y[2 * j] = bf16_round(lo * rstd);
+      y[2 * j + 1] = bf16_round(hi * rstd);
+    }
+    y[0] *= w0[0]; y[1] *= w0[1]; y[2] *= w0[2]; y[3] *= w0[3];
+    y[4] *= w1[0]; y[5] *= w1[1]; y[6] *= w1[2]; y[7] *= w1[3];
+    if (csr) {
+      const int pi = (e & 127) >> 1;  // first pair index inside the head
+      f32x4 c0 = *(const f32x4*)(csr + 2 * pi), c1 = *(const f32x4*)(csr + 2 * pi + 4);
+      const float cc[4] = {c0[0], c0[2], c1[0], c1[2]};
+      const float sn[4] = {c0[1], c0[3], c1[1], c1[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float re = y[2 * j], im = y[2 * j + 1];
+        y[2 * j] = re * cc[j] - im * sn[j];
+        y[2 * j + 1] = re * sn[j] + im * cc[j];
+      }
+    }
+    u32x4 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+               pack_bf16x2(y[6], y[7])};
+    *(u32x4*)(xr + e) = o;
+  }
+}
+
+// ------------------------------------------------------------------ patch im2col / unpatchify, patch (1,2,2)
+__global__ void patchify_kernel(const float* __restrict__ lat, int C, int F, int H, int W, int tok0, int n_tok,
+                                int n_rows, bf16_t* __restrict__ out, long ldo) {
+  const int Hp = H / 2, Wp = W / 2;
+  const long total = (long)n_rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C), c = (int)(i % C);
+    u32x2 o = {0u, 0u};
+    if (r < n_tok) {
+      const int tok = tok0 + r;
+      const int f = tok / (Hp * Wp), rem = tok % (Hp * Wp), hp = rem / Wp, wp = rem % Wp;
+      const float* b = lat + (((size_t)c * F + f) * H + 2 * hp) * W + 2 * wp;
+      o[0] = pack_bf16x2(b[0], b[1]);
+      o[1] = pack_bf16x2(b[W], b[W + 1]);
+    }
+    *(u32x2*)(out + (size_t)r * ldo + c * 4) = o;
+  }
+}
+
+__global__ void unpatchify_kernel(const float* __restrict__ tokv, long ldt, int C, int F, int H, int W, int tok0,
+                                  int n_tok, float* __restrict__ out) {
+  const int Hp = H / 2, Wp = W / 2;
+  const long total = (long)n_tok * 4 * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (4 * C)), k = (int)(i % (4 * C));
+    const int c = k % C, pq = k / C, dh = pq >> 1, dw = pq & 1;  // token vector = (ph, pw, c), c fastest
+    const int tok = tok0 + r;
+    const int f = tok / (Hp * Wp), rem = tok % (Hp * Wp), hp = rem / Wp, wp = rem % Wp;
+    out[(((size_t)c * F + f) * H + 2 * hp + dh) * W + 2 * wp + dw] = tokv[(size_t)r * ldt + k];
+  }
+}
+
+// ------------------------------------------------------------------ fp32 GEMV (time embedding MLPs)
+__global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ Wt, const float* __restrict__ x,
+                                                       const float* __restrict__ b, float* __restrict__ y, int N,
+                                                       int K, int act_in, int act_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* wr = Wt + (size_t)n * K;
+  float acc = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    f32x4 wv = *(const f32x4*)(wr + k);
+    f32x4 xv = *(const f32x4*)(x + k);
+    if (act_in == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = silu(xv[j]);
+    }
+    acc += (wv[0] * xv[0] + wv[1] * xv[1]) + (wv[2] * xv[2] + wv[3] * xv[3]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float r = acc + (b ? b[n] : 0.f);
+    if (act_out == 1) r = silu(r);
+    y[n] = r;
+  }
+}
+
+__global__ void sinusoid_kernel(const float* __restrict__ t_dev, double t_host, int dim, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int halfd = dim / 2;
+  if (i >= halfd) return;
+  const double t = t_dev ? (double)t_dev[0] : t_host;
+  const double fr = pow(10000.0, -(double)i / (double)halfd);
+  const double a = t * fr;
+  out[i] = (float)cos(a);
+  out[halfd + i] = (float)sin(a);
+}
+
+__global__ void add_bcast_kernel(const float* __restrict__ a, int na, const float* __restrict__ b,
+                                 float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i % na] + b[i];
+}
+
+__global__ void cast_pad_bf16_kernel(const float* __restrict__ src, long lds_, int rows_valid, int rows, int cols,
+                                     bf16_t* __restrict__ dst, long ldd) {
+  const long total = (long)rows * (cols / 4);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (cols / 4)), c = (int)(i % (cols / 4)) * 4;
+    u32x2 o = {0u, 0u};
+    if (r < rows_valid) {
+      f32x4 v = *(const f32x4*)(src + (size_t)r * lds_ + c);
+      o[0] = pack_bf16x2(v[0], v[1]);
+      o[1] = pack_bf16x2(v[2], v[3]);
+    }
+    *(u32x2*)(dst + (size_t)r * ldd + c) = o;
+  }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  const size_t n4 = n / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v = *(const f32x4*)(src + i * 4);
+    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2*)(dst + i * 4) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = f32_to_bf16(src[n4 * 4 + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ head Linear, fp32, small N (<= 64)
+// block = 256 threads -> 64 rows x 64 cols, K chunked by 32 through LDS; thread = 4x4 outputs.
+__global__ __launch_bounds__(256) void head_linear_kernel(const float* __restrict__ xn, long ldx,
+                                                          const float* __restrict__ Wt,
+                                                          const float* __restrict__ b, float* __restrict__ out,
+                                                          long ldo, int M, int N, int K) {
+  __shared__ float xs[32][65];
+  __shared__ float ws[32][65];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * 64;
+  const int tr = tid >> 4, tc = tid & 15;  // thread -> rows tr*4.., cols tc*4..
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    // load 64x32 of x and of W (transposed into [k][row]) : 2048 elements each, 8 per thread
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;       // 0..511 -> (row = idx/8, k4 = idx%8)
+      const int r = idx >> 3, kq = (idx & 7) * 4;
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+      if (m0 + r < M) xv = *(const f32x4*)(xn + (size_t)(m0 + r) * ldx + k0 + kq);
+      if (r < N) wv = *(const f32x4*)(Wt + (size_t)r * K + k0 + kq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xs[kq + j][r] = xv[j];
+        ws[kq + j][r] = wv[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      float xa[4], wb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xa[i] = xs[k][tr * 4 + i]; wb[i] = ws[k][tc * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(xa[i], wb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + tr * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = tc * 4 + j;
+      if (n < N) out[(size_t)m * ldo + n] = acc[i][j] + (b ? b[n] : 0.f);
+    }
+  }
+}
+
+__global__ void cfg_euler_kernel(const float* __restrict__ cond, const float* __restrict__ uncond, float g,
+                                 float dt, float* __restrict__ x, float* __restrict__ eps_out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float u = uncond[i], c = cond[i];
+    const float e = u + g * (c - u);
+    if (eps_out) eps_out[i] = e;
+    x[i] = x[i] + dt * e;
+  }
+}
+
+inline int grid_for(long total, int block, int cap = 2048) {
+  long g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long ldx0, const float* sc,
+                              const float* sh, int mode, float eps, bf16_t* out, long ldo, float* out_f32,
+                              long ldof, int M, int D, hipStream_t stream) {
+  if (M <= 0 || D <= 0 || (D % 256) != 0) return hipErrorInvalidValue;
+  const dim3 grid((M + 3) / 4), block(256);
+#define MC_LN_CASE(NV)                                                                                      \
+  case NV:                                                                                                  \
+    hipLaunchKernelGGL((ln_modulate_kernel<NV>), grid, block, 0, stream, x, ldx, x0, ldx0, sc, sh, mode, eps, out, \
+                       ldo, out_f32, ldof, M, D);                                                           \
+    break;
+  switch (D / 256) {
+    MC_LN_CASE(1)
+    MC_LN_CASE(2)
+    MC_LN_CASE(4)
+    MC_LN_CASE(6)
+    MC_LN_CASE(8)
+    MC_LN_CASE(12)
+    MC_LN_CASE(16)
+    MC_LN_CASE(20)
+    default: return hipErrorInvalidValue;
+  }
+#undef MC_LN_CASE
+  return hipGetLastError();
+}
+
+hipError_t launch_rmsnorm_rope(bf16_t* x, long ldx, const float* w, float eps, const float* cs, int cs_row0,
+                               int M, int D, hipStream_t stream) {
+  if (M <= 0 || D <= 0 || (D % 128) != 0 || (ldx % 8) != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, ldx, w, eps, cs, cs_row0, M,
+                     D);
+  return hipGetLastError();
+}
+
+hipError_t launch_patchify(const float* lat, int C, int F, int H, int W, int tok0, int n_tok, int n_rows,
+                           bf16_t* out, long ldo, hipStream_t stream) {
+  if ((H & 1) || (W & 1) || n_rows < n_tok) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)n_rows * C, 256)), dim3(256), 0, stream, lat, C, F, H, W,
+                     tok0, n_tok, n_rows, out, ldo);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpatchify(const float* tok, long ldt, int C, int F, int H, int W, int tok0, int n_tok,
+                             float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for((long)n_tok * 4 * C, 256)), dim3(256), 0, stream, tok, ldt, C,
+                     F, H, W, tok0, n_tok, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemv_f32(const float* W, const float* x, const float* b, float* y, int N, int K, int act_in,
+                           int act_out, hipStream_t stream) {
+  if ((K % 4) != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gemv_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, x, b, y, N, K, act_in, act_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sinusoid(const float* t_dev, double t_host, int dim, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(sinusoid_kernel, dim3((dim / 2 + 127) / 128), dim3(128), 0, stream, t_dev, t_host, dim, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_add_bcast(const float* a, int na, const float* b, float* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(add_bcast_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, na, b, out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_cast_pad_bf16(const float* src, long lds_, int rows_valid, int rows, int cols, bf16_t* dst,
+                                long ldd, hipStream_t stream) {
+  if ((cols % 4) != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3(grid_for((long)rows * (cols / 4), 256)), dim3(256), 0, stream, src,
+                     lds_, rows_valid, rows, cols, dst, ldd);
+  return hipGetLastError();
+}
+
+hipError_t launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for((long)(n / 4 + 1), 256)), dim3(256), 0, stream, src, dst, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_head_linear(const float* xn, long ldx, const float* W, const float* b, float* out, long ldo,
+                              int M, int N, int K, hipStream_t stream) {
+  if (N > 64 || (K % 32) != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(head_linear_kernel, dim3((M + 63) / 64), dim3(256), 0, stream, xn, ldx, W, b, out, ldo, M, N,
+                     K);
+  return hipGetLastError();
+}
+
+hipError_t launch_cfg_euler(const float* cond, const float* uncond, float g, float dt, float* x, float* eps_out,
+                            size_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, stream, cond, uncond, g, dt, x,
+                     eps_out, n);
+  return hipGetLastError();
+}
+
+}  // namespace mc

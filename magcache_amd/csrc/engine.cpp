@@ -1,0 +1,753 @@
+// Host-side engine behind include/magcache_hip.h: weight store, workspace plan and the launch
+// sequence of one DiT evaluation (the body of the reference's magcache_forward,
+// MagCache4Wan2.1/magcache_generate.py:229-305) on a caller-supplied HIP stream.
+//
+// Nothing here allocates or synchronises during a forward: weights are converted once at
+// mc_set_weight, all scratch + the residual cache are carved from one caller-owned workspace, the
+// MagCache decision is made by the caller on the host (reference :277-292 never touches the GPU).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/magcache_hip.h"
+#include "ops.h"
+
+using mc::bf16_t;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+mc_status fail(mc_status s, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return s;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(MC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Slot {  // one named parameter
+  void* dst = nullptr;
+  mc_dtype dst_dtype = MC_F32;
+  size_t numel = 0;
+  size_t row_off = 0;  // for fused destinations (q/k/v -> wqkv): element offset
+  bool loaded = false;
+};
+
+struct Layer {
+  bf16_t *wqkv, *wo, *wcq, *wckv, *wco, *w1, *w2;
+  float *bqkv, *bo, *bcq, *bckv, *bco, *b1, *b2;
+  float *nq, *nk, *cnq, *cnk, *n3w, *n3b, *mod;
+};
+
+struct Buf {
+  size_t off = 0, bytes = 0;
+};
+
+}  // namespace
+
+struct mc_engine {
+  mc_config cfg;
+  int d, ffn, H, NL, L, Lr, Lp, P, rank, tok0, Kp;  // Kp = in_dim*4 padded to 64
+  int ctx_rows;                                     // text_len padded to 64
+  std::vector<Layer> layers;
+  // non-block weights
+  bf16_t *w_patch, *w_text0, *w_text1;
+  float *b_patch, *b_text0, *b_text1;
+  float *w_time0, *b_time0, *w_time1, *b_time1, *w_tproj, *b_tproj;
+  float *w_head, *b_head, *head_mod;
+  float* cs_table = nullptr;  // rope (cos,sin) [Lp][64][2]
+  std::map<std::string, Slot> slots;
+  std::vector<void*> owned;
+  // workspace
+  char* ws = nullptr;
+  size_t ws_bytes = 0, ws_need = 0;
+  std::map<std::string, Buf> bufs;
+  int res_slot[2] = {0, 1};  // residual buffer index held by branch b
+  int res_scratch = 2;
+  bool have_res[2] = {false, false};
+  bool have_stats[2] = {false, false};
+  bool embedded = false;
+
+  template <class T>
+  T* buf(const char* name) const {
+    auto it = bufs.find(name);
+    return reinterpret_cast<T*>(ws + it->second.off);
+  }
+  float* residual(int idx) const {
+    static const char* names[3] = {"residual0", "residual1", "residual2"};
+    return buf<float>(names[idx]);
+  }
+};
+
+namespace {
+
+template <class T>
+mc_status dev_alloc(mc_engine* e, T** p, size_t n) {
+  void* q = nullptr;
+  hipError_t err = hipMalloc(&q, n * sizeof(T) + 256);
+  if (err != hipSuccess) return fail(MC_ENOMEM, "hipMalloc(%zu) failed: %s", n * sizeof(T), hipGetErrorString(err));
+  e->owned.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return MC_OK;
+}
+
+void add_slot(mc_engine* e, const std::string& name, void* dst, mc_dtype dt, size_t numel, size_t row_off = 0) {
+  Slot s;
+  s.dst = dst;
+  s.dst_dtype = dt;
+  s.numel = numel;
+  s.row_off = row_off;
+  e->slots[name] = s;
+}
+
+void add_buf(mc_engine* e, size_t& cur, const char* name, size_t bytes) {
+  Buf b;
+  b.off = cur;
+  b.bytes = bytes;
+  e->bufs[name] = b;
+  cur = align_up(cur + bytes, 256);
+}
+
+// upstream rope_params / rope_apply frequency split for head_dim 128 (22 + 21 + 21 complex pairs)
+void rope_table_host(int F, int Hp, int Wp, int tok0, int n_tok, float* cs) {
+  const int d = 128, c = d / 2;
+  const int n_hw = c / 3, n_t = c - 2 * n_hw;             // 21, 22
+  const double dim_t = (double)(d - 4 * (d / 6)), dim_hw = (double)(2 * (d / 6));  // 44, 42
+  for (int r = 0; r < n_tok; ++r) {
+    const int tok = tok0 + r;
+    float* row = cs + (size_t)r * 2 * c;
+    if (tok >= F * Hp * Wp) {  // padded token: identity rotation (upstream leaves the tail untouched)
+      for (int i = 0; i < c; ++i) { row[2 * i] = 1.f; row[2 * i + 1] = 0.f; }
+      continue;
+    }
+    const int f = tok / (Hp * Wp), rem = tok % (Hp * Wp), h = rem / Wp, w = rem % Wp;
+    for (int i = 0; i < c; ++i) {
+      double pos, fr;
+      if (i < n_t) { pos = f; fr = 1.0 / std::pow(10000.0, (2.0 * i) / dim_t); }
+      else if (i < n_t + n_hw) { pos = h; fr = 1.0 / std::pow(10000.0, (2.0 * (i - n_t)) / dim_hw); }
+      else { pos = w; fr = 1.0 / std::pow(10000.0, (2.0 * (i - n_t - n_hw)) / dim_hw); }
+      const double a = pos * fr;
+      row[2 * i] = (float)std::cos(a);
+      row[2 * i + 1] = (float)std::sin(a);
+    }
+  }
+}
+
+mc_status check_ready(const mc_engine* e) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (!e->ws) return fail(MC_ESTATE, "workspace not set (mc_set_workspace)");
+  for (auto& kv : e->slots)
+    if (!kv.second.loaded) return fail(MC_ESTATE, "weight '%s' was never set", kv.first.c_str());
+  return MC_OK;
+}
+
+mc::GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, const float* bias, int M, int N, int K) {
+  mc::GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.M = M; p.N = N; p.K = K;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mc_last_error(void) { return g_err; }
+const char* mc_version(void) { return "magcache_hip 0.1 (gfx950)"; }
+
+mc_status mc_create(const mc_config* cfg, mc_engine** out) {
+  if (!cfg || !out) return fail(MC_EINVAL, "null argument");
+  const mc_config& c = *cfg;
+  if (c.dim <= 0 || c.num_heads <= 0 || c.dim != c.num_heads * 128)
+    return fail(MC_EINVAL, "dim (%d) must be num_heads (%d) * 128", c.dim, c.num_heads);
+  if ((c.dim % 256) || (c.ffn_dim % 64) || (c.text_dim % 64) || (c.freq_dim % 4) || c.num_layers <= 0)
+    return fail(MC_EINVAL, "unsupported geometry dim=%d ffn=%d text_dim=%d", c.dim, c.ffn_dim, c.text_dim);
+  if ((c.latent_h & 1) || (c.latent_w & 1) || c.latent_f <= 0)
+    return fail(MC_EINVAL, "latent grid %dx%dx%d not divisible by patch (1,2,2)", c.latent_f, c.latent_h, c.latent_w);
+  if (c.sp_size < 1 || c.sp_rank < 0 || c.sp_rank >= c.sp_size) return fail(MC_EINVAL, "bad sp rank/size");
+  if (c.n_branches != 1 && c.n_branches != 2) return fail(MC_EINVAL, "n_branches must be 1 or 2");
+  if (c.out_dim * 4 > 64) return fail(MC_EINVAL, "out_dim*4 > 64 unsupported by the head kernel");
+
+  mc_engine* e = new mc_engine();
+  e->cfg = c;
+  e->d = c.dim; e->ffn = c.ffn_dim; e->H = c.num_heads; e->NL = c.num_layers;
+  e->L = c.latent_f * (c.latent_h / 2) * (c.latent_w / 2);
+  e->P = c.sp_size; e->rank = c.sp_rank;
+  if (e->L % e->P) {
+    delete e;
+    return fail(MC_EINVAL, "seq_len %d not divisible by sp_size %d", e->L, c.sp_size);
+  }
+  e->Lr = e->L / e->P;
+  e->Lp = (int)align_up(e->Lr, 256);
+  e->tok0 = e->rank * e->Lr;
+  e->Kp = (int)align_up((size_t)c.in_dim * 4, 64);
+  e->ctx_rows = (int)align_up(c.text_len, 64);
+  const size_t d = e->d, ffn = e->ffn;
+
+  mc_status st = MC_OK;
+#define ALLOC(ptr, n) do { st = dev_alloc(e, &(ptr), (n)); if (st != MC_OK) { mc_destroy(e); return st; } } while (0)
+  e->layers.resize(e->NL);
+  for (int i = 0; i < e->NL; ++i) {
+    Layer& l = e->layers[i];
+    ALLOC(l.wqkv, 3 * d * d); ALLOC(l.bqkv, 3 * d); ALLOC(l.nq, d); ALLOC(l.nk, d);
+    ALLOC(l.wo, d * d); ALLOC(l.bo, d);
+    ALLOC(l.n3w, d); ALLOC(l.n3b, d);
+    ALLOC(l.wcq, d * d); ALLOC(l.bcq, d); ALLOC(l.cnq, d);
+    ALLOC(l.wckv, 2 * d * d); ALLOC(l.bckv, 2 * d); ALLOC(l.cnk, d);
+    ALLOC(l.wco, d * d); ALLOC(l.bco, d);
+    ALLOC(l.w1, ffn * d); ALLOC(l.b1, ffn); ALLOC(l.w2, d * ffn); ALLOC(l.b2, d);
+    ALLOC(l.mod, 6 * d);
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    add_slot(e, p + "self_attn.q.weight", l.wqkv, MC_BF16, d * d, 0);
+    add_slot(e, p + "self_attn.k.weight", l.wqkv, MC_BF16, d * d, d * d);
+    add_slot(e, p + "self_attn.v.weight", l.wqkv, MC_BF16, d * d, 2 * d * d);
+    add_slot(e, p + "self_attn.q.bias", l.bqkv, MC_F32, d, 0);
+    add_slot(e, p + "self_attn.k.bias", l.bqkv, MC_F32, d, d);
+    add_slot(e, p + "self_attn.v.bias", l.bqkv, MC_F32, d, 2 * d);
+    add_slot(e, p + "self_attn.norm_q.weight", l.nq, MC_F32, d);
+    add_slot(e, p + "self_attn.norm_k.weight", l.nk, MC_F32, d);
+    add_slot(e, p + "self_attn.o.weight", l.wo, MC_BF16, d * d);
+    add_slot(e, p + "self_attn.o.bias", l.bo, MC_F32, d);
+    add_slot(e, p + "norm3.weight", l.n3w, MC_F32, d);
+    add_slot(e, p + "norm3.bias", l.n3b, MC_F32, d);
+    add_slot(e, p + "cross_attn.q.weight", l.wcq, MC_BF16, d * d);
+    add_slot(e, p + "cross_attn.q.bias", l.bcq, MC_F32, d);
+    add_slot(e, p + "cross_attn.norm_q.weight", l.cnq, MC_F32, d);
+    add_slot(e, p + "cross_attn.k.weight", l.wckv, MC_BF16, d * d, 0);
+    add_slot(e, p + "cross_attn.v.weight", l.wckv, MC_BF16, d * d, d * d);
+    add_slot(e, p + "cross_attn.k.bias", l.bckv, MC_F32, d, 0);
+    add_slot(e, p + "cross_attn.v.bias", l.bckv, MC_F32, d, d);
+    add_slot(e, p + "cross_attn.norm_k.weight", l.cnk, MC_F32, d);
+    add_slot(e, p + "cross_attn.o.weight", l.wco, MC_BF16, d * d);
+    add_slot(e, p + "cross_attn.o.bias", l.bco, MC_F32, d);
+    add_slot(e, p + "ffn.0.weight", l.w1, MC_BF16, ffn * d);
+    add_slot(e, p + "ffn.0.bias", l.b1, MC_F32, ffn);
+    add_slot(e, p + "ffn.2.weight", l.w2, MC_BF16, d * ffn);
+    add_slot(e, p + "ffn.2.bias", l.b2, MC_F32, d);
+    add_slot(e, p + "modulation", l.mod, MC_F32, 6 * d);
+  }
+  const size_t kin = (size_t)c.in_dim * 4;
+  ALLOC(e->w_patch, d * e->Kp); ALLOC(e->b_patch, d);
+  HIP_TRY(hipMemset(e->w_patch, 0, d * e->Kp * sizeof(bf16_t)));
+  ALLOC(e->w_text0, d * c.text_dim); ALLOC(e->b_text0, d); ALLOC(e->w_text1, d * d); ALLOC(e->b_text1, d);
+  ALLOC(e->w_time0, d * c.freq_dim); ALLOC(e->b_time0, d); ALLOC(e->w_time1, d * d); ALLOC(e->b_time1, d);
+  ALLOC(e->w_tproj, 6 * d * d); ALLOC(e->b_tproj, 6 * d);
+  ALLOC(e->w_head, (size_t)c.out_dim * 4 * d); ALLOC(e->b_head, (size_t)c.out_dim * 4); ALLOC(e->head_mod, 2 * d);
+  // patch weight [d, in_dim, 1, 2, 2] is stored [d, Kp] (Kp = in_dim*4 padded to a GEMM K step)
+  add_slot(e, "patch_embedding.weight", e->w_patch, MC_BF16, d * kin);
+  add_slot(e, "patch_embedding.bias", e->b_patch, MC_F32, d);
+  add_slot(e, "text_embedding.0.weight", e->w_text0, MC_BF16, d * c.text_dim);
+  add_slot(e, "text_embedding.0.bias", e->b_text0, MC_F32, d);
+  add_slot(e, "text_embedding.2.weight", e->w_text1, MC_BF16, d * d);
+  add_slot(e, "text_embedding.2.bias", e->b_text1, MC_F32, d);
+  add_slot(e, "time_embedding.0.weight", e->w_time0, MC_F32, d * c.freq_dim);
+  add_slot(e, "time_embedding.0.bias", e->b_time0, MC_F32, d);
+  add_slot(e, "time_embedding.2.weight", e->w_time1, MC_F32, d * d);
+  add_slot(e, "time_embedding.2.bias", e->b_time1, MC_F32, d);
+  add_slot(e, "time_projection.1.weight", e->w_tproj, MC_F32, 6 * d * d);
+  add_slot(e, "time_projection.1.bias", e->b_tproj, MC_F32, 6 * d);
+  add_slot(e, "head.head.weight", e->w_head, MC_F32, (size_t)c.out_dim * 4 * d);
+  add_slot(e, "head.head.bias", e->b_head, MC_F32, (size_t)c.out_dim * 4);
+  add_slot(e, "head.modulation", e->head_mod, MC_F32, 2 * d);
+
+  // RoPE table for this rank's rows
+  ALLOC(e->cs_table, (size_t)e->Lp * 128);
+  {
+    std::vector<float> cs((size_t)e->Lp * 128);
+    // rows >= Lr are padding: identity; rows < Lr are global tokens tok0 + r
+    rope_table_host(c.latent_f, c.latent_h / 2, c.latent_w / 2, e->tok0, e->Lr, cs.data());
+    for (size_t r = e->Lr; r < (size_t)e->Lp; ++r)
+      for (int i = 0; i < 64; ++i) { cs[r * 128 + 2 * i] = 1.f; cs[r * 128 + 2 * i + 1] = 0.f; }
+    HIP_TRY(hipMemcpy(e->cs_table, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+#undef ALLOC
+
+  // ---- workspace plan
+  size_t cur = 0;
+  const size_t Lp = e->Lp;
+  add_buf(e, cur, "x", Lp * d * 4);
+  add_buf(e, cur, "x0", Lp * d * 2);
+  add_buf(e, cur, "xn", Lp * d * 2);
+  add_buf(e, cur, "qkv", Lp * 3 * d * 2);  // P>1: only the first Lp*d (q) is used
+  add_buf(e, cur, "ao", Lp * d * 2);
+  add_buf(e, cur, "h", std::max(Lp * ffn * 2, Lp * d * 4));  // FFN hidden (bf16) / head LN out (fp32)
+  add_buf(e, cur, "tokens", Lp * e->Kp * 2);
+  add_buf(e, cur, "ctx_in", (size_t)e->ctx_rows * c.text_dim * 2);
+  add_buf(e, cur, "ctx_h", (size_t)e->ctx_rows * d * 2);
+  add_buf(e, cur, "ctx", (size_t)e->ctx_rows * d * 2);
+  add_buf(e, cur, "ckv", (size_t)e->ctx_rows * 2 * d * 2);
+  add_buf(e, cur, "temb", (size_t)(c.freq_dim + 2 * d + 6 * d) * 4);  // sinus | h1 | e | e0
+  add_buf(e, cur, "emod", (size_t)e->NL * 6 * d * 4);
+  add_buf(e, cur, "ehead", 2 * d * 4);
+  add_buf(e, cur, "head_tokens", Lp * 64 * 4);
+  add_buf(e, cur, "kv_gather", e->P > 1 ? (size_t)e->P * Lp * 2 * d * 2 : 256);
+  add_buf(e, cur, "residual0", Lp * d * 4);
+  add_buf(e, cur, "residual1", c.n_branches > 1 ? Lp * d * 4 : 256);
+  add_buf(e, cur, "residual2", c.calibration ? Lp * d * 4 : 256);
+  add_buf(e, cur, "calib_partial", 1024 * 4 * 8);
+  add_buf(e, cur, "calib_sums", 4 * 8);
+  add_buf(e, cur, "calib_stats", 2 * 3 * 4);
+  e->ws_need = cur;
+  // "kv_local": this rank's slice of the gather buffer
+  if (e->P > 1) {
+    Buf b = e->bufs["kv_gather"];
+    b.off += (size_t)e->rank * Lp * 2 * d * 2;
+    b.bytes = Lp * 2 * d * 2;
+    e->bufs["kv_local"] = b;
+  }
+  *out = e;
+  return MC_OK;
+}
+
+void mc_destroy(mc_engine* e) {
+  if (!e) return;
+  for (void* p : e->owned) (void)hipFree(p);
+  delete e;
+}
+
+size_t mc_workspace_bytes(const mc_engine* e) { return e ? e->ws_need : 0; }
+
+mc_status mc_set_workspace(mc_engine* e, void* ws_dev, size_t bytes) {
+  if (!e || !ws_dev) return fail(MC_EINVAL, "null argument");
+  if (bytes < e->ws_need) return fail(MC_EINVAL, "workspace too small: %zu < %zu", bytes, e->ws_need);
+  if (((uintptr_t)ws_dev) & 255) return fail(MC_EINVAL, "workspace must be 256-byte aligned");
+  e->ws = (char*)ws_dev;
+  e->ws_bytes = bytes;
+  e->have_res[0] = e->have_res[1] = false;
+  return MC_OK;
+}
+
+mc_status mc_buffer_info(const mc_engine* e, const char* name, size_t* offset, size_t* bytes) {
+  if (!e || !name) return fail(MC_EINVAL, "null argument");
+  std::string n(name);
+  if (n == "residual_branch0" || n == "residual_branch1") {  // the slot currently held by a branch
+    static const char* names[3] = {"residual0", "residual1", "residual2"};
+    n = names[e->res_slot[n.back() - '0']];
+  }
+  auto it = e->bufs.find(n);
+  if (it == e->bufs.end()) return fail(MC_EINVAL, "unknown buffer '%s'", name);
+  if (offset) *offset = it->second.off;
+  if (bytes) *bytes = it->second.bytes;
+  return MC_OK;
+}
+
+mc_status mc_set_weight(mc_engine* e, const char* name, const void* src_dev, mc_dtype dtype, const int64_t* shape,
+                        int ndim, mc_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!e || !name || !src_dev || !shape) return fail(MC_EINVAL, "null argument");
+  auto it = e->slots.find(name);
+  if (it == e->slots.end()) return fail(MC_EINVAL, "unknown weight '%s'", name);
+  Slot& s = it->second;
+  size_t numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+  if (numel != s.numel) return fail(MC_EINVAL, "weight '%s': %zu elements given, %zu expected", name, numel, s.numel);
+  const bool is_patch = (std::string(name) == "patch_embedding.weight");
+  if (s.dst_dtype == MC_F32) {
+    if (dtype != MC_F32) return fail(MC_EINVAL, "weight '%s' must be given as fp32", name);
+    HIP_TRY(hipMemcpyAsync((float*)s.dst + s.row_off, src_dev, numel * 4, hipMemcpyDeviceToDevice, stream));
+  } else {
+    bf16_t* dst = (bf16_t*)s.dst + s.row_off;
+    const size_t kin = (size_t)e->cfg.in_dim * 4;
+    if (is_patch && kin != (size_t)e->Kp) {
+      // [d, kin] -> [d, Kp] row pitch (padding columns stay zero)
+      if (dtype == MC_F32) {
+        HIP_TRY(mc::launch_cast_pad_bf16((const float*)src_dev, (long)kin, e->d, e->d, (int)kin, dst, e->Kp, stream));
+      } else {
+        HIP_TRY(hipMemcpy2DAsync(dst, e->Kp * 2, src_dev, kin * 2, kin * 2, e->d, hipMemcpyDeviceToDevice, stream));
+      }
+    } else if (dtype == MC_F32) {
+      HIP_TRY(mc::launch_cast_bf16((const float*)src_dev, dst, numel, stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(dst, src_dev, numel * 2, hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  s.loaded = true;
+  return MC_OK;
+}
+
+int mc_weights_missing(const mc_engine* e, char* buf, size_t buflen) {
+  if (!e) return -1;
+  int n = 0;
+  size_t pos = 0;
+  if (buf && buflen) buf[0] = 0;
+  for (auto& kv : e->slots) {
+    if (kv.second.loaded) continue;
+    ++n;
+    if (buf && pos + kv.first.size() + 2 < buflen) {
+      memcpy(buf + pos, kv.first.c_str(), kv.first.size());
+      pos += kv.first.size();
+      buf[pos++] = '\n';
+      buf[pos] = 0;
+    }
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embeds: patch embedding, time embedding + projection, text embedding   (reference :236-262)
+mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
+                   const void* context_dev, mc_dtype ctx_dtype, int ctx_len, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  mc_status st = check_ready(e);
+  if (st != MC_OK) return st;
+  if (!latent_dev || !context_dev) return fail(MC_EINVAL, "null input");
+  const mc_config& c = e->cfg;
+  if (ctx_len <= 0 || ctx_len > c.text_len)
+    return fail(MC_EINVAL, "context length %d exceeds text_len %d", ctx_len, c.text_len);
+  const int d = e->d;
+  // x = patch_embedding(latent): im2col -> GEMM, x (fp32) and ori_x (bf16), zero rows past seq_len
+  bf16_t* tokens = e->buf<bf16_t>("tokens");
+  if (e->Kp != c.in_dim * 4) HIP_TRY(hipMemsetAsync(tokens, 0, (size_t)e->Lp * e->Kp * 2, s));
+  HIP_TRY(mc::launch_patchify(latent_dev, c.in_dim, c.latent_f, c.latent_h, c.latent_w, e->tok0, e->Lr, e->Lp,
+                              tokens, e->Kp, s));
+  {
+    mc::GemmParams p = gp(tokens, e->Kp, e->w_patch, e->Kp, e->b_patch, e->Lp, d, e->Kp);
+    p.X = e->buf<float>("x"); p.ldx = d;
+    p.X0out = e->buf<bf16_t>("x0"); p.ldx0out = d;
+    p.m_valid = e->Lr;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
+  }
+  // e = time_embedding(sinusoidal(t)) ; e0 = time_projection(e)   (fp32, :249-253)
+  float* temb = e->buf<float>("temb");
+  float* sinus = temb;
+  float* h1 = temb + c.freq_dim;
+  float* ev = h1 + d;
+  float* e0 = ev + d;
+  HIP_TRY(mc::launch_sinusoid(t_dev, t_host, c.freq_dim, sinus, s));
+  HIP_TRY(mc::launch_gemv_f32(e->w_time0, sinus, e->b_time0, h1, d, c.freq_dim, 0, 1, s));
+  HIP_TRY(mc::launch_gemv_f32(e->w_time1, h1, e->b_time1, ev, d, d, 0, 0, s));
+  HIP_TRY(mc::launch_gemv_f32(e->w_tproj, ev, e->b_tproj, e0, 6 * d, d, 1, 0, s));
+  // per-layer modulation vectors (block.modulation + e0) and the head's (head.modulation + e)
+  float* emod = e->buf<float>("emod");
+  for (int l = 0; l < e->NL; ++l)
+    HIP_TRY(mc::launch_add_bcast(e0, 6 * d, e->layers[l].mod, emod + (size_t)l * 6 * d, 6 * d, s));
+  HIP_TRY(mc::launch_add_bcast(ev, d, e->head_mod, e->buf<float>("ehead"), 2 * d, s));
+  // context = text_embedding(zero-padded context)   (:256-262)
+  bf16_t* ctx_in = e->buf<bf16_t>("ctx_in");
+  if (ctx_dtype == MC_F32) {
+    HIP_TRY(mc::launch_cast_pad_bf16((const float*)context_dev, c.text_dim, ctx_len, e->ctx_rows, c.text_dim, ctx_in,
+                                     c.text_dim, s));
+  } else {
+    HIP_TRY(hipMemsetAsync(ctx_in, 0, (size_t)e->ctx_rows * c.text_dim * 2, s));
+    HIP_TRY(hipMemcpyAsync(ctx_in, context_dev, (size_t)ctx_len * c.text_dim * 2, hipMemcpyDeviceToDevice, s));
+  }
+  {
+    mc::GemmParams p = gp(ctx_in, c.text_dim, e->w_text0, c.text_dim, e->b_text0, e->ctx_rows, d, c.text_dim);
+    p.Cb = e->buf<bf16_t>("ctx_h"); p.ldc = d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
+    mc::GemmParams q = gp(e->buf<bf16_t>("ctx_h"), d, e->w_text1, d, e->b_text1, e->ctx_rows, d, d);
+    q.Cb = e->buf<bf16_t>("ctx"); q.ldc = d;
+    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+  }
+  e->embedded = true;
+  return MC_OK;
+}
+
+// LN + modulate -> q,k,v Linear -> RMSNorm(q), RMSNorm(k) -> RoPE(q,k)      (upstream WanSelfAttention)
+mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
+  const Layer& l = e->layers[layer];
+  const int d = e->d, Lp = e->Lp;
+  const float* em = e->buf<float>("emod") + (size_t)layer * 6 * d;
+  float* x = e->buf<float>("x");
+  bf16_t* xn = e->buf<bf16_t>("xn");
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + d, em, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s));
+  if (e->P == 1) {
+    mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, 3 * d, d);
+    p.Cb = qkv; p.ldc = 3 * d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    HIP_TRY(mc::launch_rmsnorm_rope(qkv, 3 * d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
+    HIP_TRY(mc::launch_rmsnorm_rope(qkv + d, 3 * d, l.nk, e->cfg.eps, e->cs_table, 0, Lp, d, s));
+  } else {
+    // q -> qkv[:, :d] (ld d) ; [k|v] -> this rank's rows of the gather buffer (ld 2d)
+    bf16_t* kvl = e->buf<bf16_t>("kv_local");
+    mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, d, d);
+    p.Cb = qkv; p.ldc = d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    mc::GemmParams q = gp(xn, d, l.wqkv + (size_t)d * d, d, l.bqkv + d, Lp, 2 * d, d);
+    q.Cb = kvl; q.ldc = 2 * d;
+    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+    HIP_TRY(mc::launch_rmsnorm_rope(qkv, d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
+    HIP_TRY(mc::launch_rmsnorm_rope(kvl, 2 * d, l.nk, e->cfg.eps, e->cs_table, 0, Lp, d, s));
+  }
+  return MC_OK;
+}
+
+// attention -> o (+gated residual) -> norm3 -> cross-attn (+residual) -> LN+mod -> FFN (+gated residual)
+mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
+  if (branch < 0 || branch >= e->cfg.n_branches) return fail(MC_EINVAL, "branch %d out of range", branch);
+  const Layer& l = e->layers[layer];
+  const int d = e->d, Lp = e->Lp, ffn = e->ffn;
+  const float* em = e->buf<float>("emod") + (size_t)layer * 6 * d;
+  float* x = e->buf<float>("x");
+  bf16_t* xn = e->buf<bf16_t>("xn");
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  bf16_t* ao = e->buf<bf16_t>("ao");
+  const float scale = 1.0f / std::sqrt(128.0f);
+
+  // ---- self attention over the full sequence
+  {
+    mc::AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.O = ao; a.ldo = d; a.Lq_pad = Lp; a.n_heads = e->H; a.scale = scale;
+    if (e->P == 1) {
+      a.Q = qkv; a.ldq = 3 * d;
+      a.K = qkv + d; a.ldk = 3 * d; a.k_shard_stride = 0;
+      a.V = qkv + 2 * d; a.ldv = 3 * d; a.v_shard_stride = 0;
+      a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
+    } else {
+      bf16_t* kvg = e->buf<bf16_t>("kv_gather");
+      a.Q = qkv; a.ldq = d;
+      a.K = kvg; a.ldk = 2 * d; a.k_shard_stride = (long)Lp * 2 * d;
+      a.V = kvg + d; a.ldv = 2 * d; a.v_shard_stride = (long)Lp * 2 * d;
+      a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = e->P;
+    }
+    HIP_TRY(mc::launch_attention(a, s));
+  }
+  {  // x = x + o(attn) * e[2]
+    mc::GemmParams p = gp(ao, d, l.wo, d, l.bo, Lp, d, d);
+    p.X = x; p.ldx = d; p.gate = em + 2 * d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_RESID_GATE, s));
+  }
+  // ---- cross attention: x = x + o(attn(norm_q(q(norm3(x))), norm_k(k(ctx)), v(ctx)))
+  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, l.n3w, l.n3b, 1, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s));
+  bf16_t* cq = qkv;  // the self-attention q/k/v are dead now
+  bf16_t* ckv = e->buf<bf16_t>("ckv");
+  {
+    mc::GemmParams p = gp(xn, d, l.wcq, d, l.bcq, Lp, d, d);
+    p.Cb = cq; p.ldc = d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    HIP_TRY(mc::launch_rmsnorm_rope(cq, d, l.cnq, e->cfg.eps, nullptr, 0, Lp, d, s));
+    mc::GemmParams q = gp(e->buf<bf16_t>("ctx"), d, l.wckv, d, l.bckv, e->ctx_rows, 2 * d, d);
+    q.Cb = ckv; q.ldc = 2 * d;
+    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+    HIP_TRY(mc::launch_rmsnorm_rope(ckv, 2 * d, l.cnk, e->cfg.eps, nullptr, 0, e->ctx_rows, d, s));
+    mc::AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.Q = cq; a.ldq = d; a.K = ckv; a.ldk = 2 * d; a.V = ckv + d; a.ldv = 2 * d;
+    a.O = ao; a.ldo = d; a.Lq_pad = Lp; a.n_heads = e->H; a.scale = scale;
+    a.shard_rows = e->ctx_rows; a.shard_valid = e->cfg.text_len; a.n_shards = 1;
+    HIP_TRY(mc::launch_attention(a, s));
+    mc::GemmParams o = gp(ao, d, l.wco, d, l.bco, Lp, d, d);
+    o.X = x; o.ldx = d; o.gate = nullptr;
+    HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+  }
+  // ---- FFN: x = x + ffn(LN(x)*(1+e[4])+e[3]) * e[5]
+  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + 4 * d, em + 3 * d, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s));
+  bf16_t* h = e->buf<bf16_t>("h");
+  {
+    mc::GemmParams p = gp(xn, d, l.w1, d, l.b1, Lp, ffn, d);
+    p.Cb = h; p.ldc = ffn;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
+    mc::GemmParams q = gp(h, ffn, l.w2, ffn, l.b2, Lp, d, ffn);
+    q.X = x; q.ldx = d; q.gate = em + 5 * d;
+    if (layer == e->NL - 1) {
+      // MagCache residual capture fused into the last epilogue: residual = x_out - ori_x  (:299-301)
+      const int dst = (mode == MC_MODE_CALIB) ? e->res_scratch : e->res_slot[branch];
+      q.X0 = e->buf<bf16_t>("x0"); q.ldx0 = d;
+      q.R = e->residual(dst); q.ldr = d;
+      HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_RESID_CAPTURE, s));
+      if (mode == MC_MODE_CALIB) {
+        if (!e->cfg.calibration) return fail(MC_ESTATE, "engine was created without calibration=1");
+        if (e->have_res[branch]) {
+          HIP_TRY(mc::launch_calib_stats(e->residual(dst), d, e->residual(e->res_slot[branch]), d, e->Lr, d,
+                                         e->buf<double>("calib_partial"), 1024, e->buf<double>("calib_sums"),
+                                         e->buf<float>("calib_stats") + 3 * branch, s));
+          e->have_stats[branch] = true;
+        } else {
+          e->have_stats[branch] = false;
+        }
+        std::swap(e->res_slot[branch], e->res_scratch);
+      }
+      e->have_res[branch] = true;
+    } else {
+      HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_RESID_GATE, s));
+    }
+  }
+  return MC_OK;
+}
+
+// head(x, e) on this rank's tokens -> "head_tokens" [Lr, 4*out_dim] fp32       (reference :304)
+mc_status mc_head(mc_engine* e, int branch, mc_mode mode, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (branch < 0 || branch >= e->cfg.n_branches) return fail(MC_EINVAL, "branch %d out of range", branch);
+  const int d = e->d;
+  const float* eh = e->buf<float>("ehead");
+  float* hn = e->buf<float>("h");
+  if (mode == MC_MODE_SKIP) {
+    // skipped step: x = ori_x + residual_cache[branch] (:294-295), folded into the LayerNorm load
+    if (!e->have_res[branch]) return fail(MC_ESTATE, "skip requested but residual_cache[%d] is empty", branch);
+    HIP_TRY(mc::launch_ln_modulate(e->residual(e->res_slot[branch]), d, e->buf<bf16_t>("x0"), d, eh + d, eh, 0,
+                                   e->cfg.eps, nullptr, 0, hn, d, e->Lr, d, s));
+  } else {
+    HIP_TRY(mc::launch_ln_modulate(e->buf<float>("x"), d, nullptr, 0, eh + d, eh, 0, e->cfg.eps, nullptr, 0, hn, d,
+                                   e->Lr, d, s));
+  }
+  HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, e->buf<float>("head_tokens"), 64, e->Lr,
+                                 e->cfg.out_dim * 4, d, s));
+  return MC_OK;
+}
+
+mc_status mc_unpatchify(mc_engine* e, const float* tokens_dev, int tok0, int n_tok, float* out_dev,
+                        mc_stream stream_) {
+  if (!e || !tokens_dev || !out_dev) return fail(MC_EINVAL, "null argument");
+  if (tok0 < 0 || n_tok <= 0 || tok0 + n_tok > e->L) return fail(MC_EINVAL, "token range out of bounds");
+  const mc_config& c = e->cfg;
+  HIP_TRY(mc::launch_unpatchify(tokens_dev, 64, c.out_dim, c.latent_f, c.latent_h, c.latent_w, tok0, n_tok, out_dev,
+                                (hipStream_t)stream_));
+  return MC_OK;
+}
+
+mc_status mc_forward(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
+                     const void* context_dev, mc_dtype ctx_dtype, int ctx_len, int branch, mc_mode mode,
+                     float* out_dev, mc_stream stream) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (e->P != 1) return fail(MC_ESTATE, "mc_forward is single-GPU; drive a sharded engine through the phase calls");
+  if (!out_dev) return fail(MC_EINVAL, "null output");
+  mc_status st = mc_embed(e, latent_dev, t_dev, t_host, context_dev, ctx_dtype, ctx_len, stream);
+  if (st != MC_OK) return st;
+  if (mode != MC_MODE_SKIP) {
+    for (int l = 0; l < e->NL; ++l) {
+      st = mc_block_pre_attn(e, l, stream);
+      if (st != MC_OK) return st;
+      st = mc_block_post_attn(e, l, branch, mode, stream);
+      if (st != MC_OK) return st;
+    }
+  }
+  st = mc_head(e, branch, mode, stream);
+  if (st != MC_OK) return st;
+  return mc_unpatchify(e, e->buf<float>("head_tokens"), 0, e->L, out_dev, stream);
+}
+
+mc_status mc_calib_ready(const mc_engine* e, int branch, int* has_stats) {
+  if (!e || !has_stats || branch < 0 || branch > 1) return fail(MC_EINVAL, "bad argument");
+  *has_stats = e->have_stats[branch] ? 1 : 0;
+  return MC_OK;
+}
+
+mc_status mc_calib_finalize(mc_engine* e, int branch, mc_stream stream) {
+  if (!e || !e->ws) return fail(MC_ESTATE, "no workspace");
+  if (branch < 0 || branch > 1) return fail(MC_EINVAL, "branch %d out of range", branch);
+  HIP_TRY(mc::launch_calib_finalize(e->buf<double>("calib_sums"), e->buf<float>("calib_stats") + 3 * branch,
+                                    (hipStream_t)stream));
+  return MC_OK;
+}
+
+mc_status mc_state_reset(mc_engine* e) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  e->have_res[0] = e->have_res[1] = false;
+  e->have_stats[0] = e->have_stats[1] = false;
+  return MC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ops
+mc_status mc_op_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, int M, int N, int K,
+                          int epi, void* Cb, long ldc, float* X, long ldx, const float* gate, const void* X0,
+                          long ldx0, float* R, long ldr, void* X0out, long ldx0out, int m_valid, mc_stream s) {
+  mc::GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, M, N, K);
+  p.Cb = (bf16_t*)Cb; p.ldc = ldc; p.X = X; p.ldx = ldx; p.gate = gate;
+  p.X0 = (const bf16_t*)X0; p.ldx0 = ldx0; p.R = R; p.ldr = ldr;
+  p.X0out = (bf16_t*)X0out; p.ldx0out = ldx0out; p.m_valid = m_valid;
+  hipError_t err = mc::launch_gemm_bf16(p, epi, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "gemm: unsupported shape M=%d N=%d K=%d epi=%d", M, N, K, epi);
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_attention(const void* Q, long ldq, const void* K, long ldk, long kss, const void* V, long ldv,
+                          long vss, void* O, long ldo, int Lq_pad, int n_heads, int shard_rows, int shard_valid,
+                          int n_shards, float scale, mc_stream s) {
+  mc::AttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.k_shard_stride = kss;
+  a.V = (const bf16_t*)V; a.ldv = ldv; a.v_shard_stride = vss; a.O = (bf16_t*)O; a.ldo = ldo;
+  a.Lq_pad = Lq_pad; a.n_heads = n_heads; a.shard_rows = shard_rows; a.shard_valid = shard_valid;
+  a.n_shards = n_shards; a.scale = scale;
+  hipError_t err = mc::launch_attention(a, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "attention: unsupported shape");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_ln_modulate(const float* x, long ldx, const void* x0, long ldx0, const float* sc, const float* sh,
+                            int mode, float eps, void* out, long ldo, float* out_f32, long ldof, int M, int D,
+                            mc_stream s) {
+  hipError_t err = mc::launch_ln_modulate(x, ldx, (const bf16_t*)x0, ldx0, sc, sh, mode, eps, (bf16_t*)out, ldo,
+                                          out_f32, ldof, M, D, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "ln_modulate: unsupported D=%d", D);
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_rmsnorm_rope(void* x, long ldx, const float* w, float eps, const float* cs, int cs_row0, int M, int D,
+                             mc_stream s) {
+  hipError_t err = mc::launch_rmsnorm_rope((bf16_t*)x, ldx, w, eps, cs, cs_row0, M, D, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "rmsnorm_rope: unsupported D=%d", D);
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_skip_add(const void* x0, long ldx0, const float* r, long ldr, float* out, long ldo, int M, int D,
+                         mc_stream s) {
+  hipError_t err = mc::launch_skip_add((const bf16_t*)x0, ldx0, r, ldr, out, ldo, M, D, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "skip_add: unsupported shape");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_residual_sub(const float* x, long ldx, const void* x0, long ldx0, float* r, long ldr, int M, int D,
+                             mc_stream s) {
+  hipError_t err = mc::launch_residual_sub(x, ldx, (const bf16_t*)x0, ldx0, r, ldr, M, D, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "residual_sub: unsupported shape");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_calib_stats(const float* r, long ldr, const float* rp, long ldrp, int M, int D, double* partial,
+                            int n_blocks, double* sums, float* stats, mc_stream s) {
+  hipError_t err = mc::launch_calib_stats(r, ldr, rp, ldrp, M, D, partial, n_blocks, sums, stats, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "calib_stats: unsupported shape");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_cfg_euler(const float* cond, const float* uncond, float guide, float dt, float* x, float* eps_out,
+                          size_t n, mc_stream s) {
+  HIP_TRY(mc::launch_cfg_euler(cond, uncond, guide, dt, x, eps_out, n, (hipStream_t)s));
+  return MC_OK;
+}
+
+mc_status mc_op_cast_bf16(const float* src, void* dst, size_t n, mc_stream s) {
+  HIP_TRY(mc::launch_cast_bf16(src, (bf16_t*)dst, n, (hipStream_t)s));
+  return MC_OK;
+}
+
+mc_status mc_op_rope_table(int F, int Hp, int Wp, int tok0, int n_tok, float* cs_host) {
+  if (!cs_host || n_tok <= 0) return fail(MC_EINVAL, "bad argument");
+  rope_table_host(F, Hp, Wp, tok0, n_tok, cs_host);
+  return MC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogues).
+//
+// Used for every Linear of the Wan DiT block (reference call site
+// MagCache4Wan2.1/magcache_generate.py:297-298; the Linear layers themselves are upstream
+// wan/modules/model.py).  Both operands are K-contiguous, which is exactly the layout an MFMA
+// 32x32x16 operand wants: 8 consecutive k per lane = one 16-byte LDS read.
+//
+// Design (CDNA4):
+//  * 128x128 output tile, BK = 64, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA 32x32x16
+//    blocks (64 fp32 accumulators / lane).
+//  * The MFMA is issued "swapped": operand A = weight rows (n), operand B = activation rows (m), so
+//    every lane ends up holding 4 consecutive n for one m -> 8-byte bf16 / 16-byte fp32 stores and
+//    vector loads of bias / gate.
+//  * HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS stages (64 KiB), one
+//    barrier per K step; the load of step k+1 is in flight while step k is multiplied.
+//  * LDS rows are 128 B, so a plain image would put the 16 lanes of a ds_read_b128 group on two
+//    16-B slots (8-way conflict).  The image is XOR-swizzled: chunk' = chunk ^ ((row>>1)&7); since
+//    global_load_lds writes lane-linear, the permutation is applied to the *source* address and the
+//    same involution to the read address.
+//  * 1-D grid, remapped so each XCD (private 4 MiB L2) walks a contiguous group of tiles.
+#include "common.h"
+#include "ops.h"
+
+namespace mc {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int OPND_BYTES = BM * BK * 2;          // 16 KiB
+constexpr int GROUP_M = 8;
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmParams p, int tilesM, int tilesN) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  // ---- tile mapping: XCD-contiguous, grouped along M so a group of tiles shares W panels in L2
+  int v = xcd_remap(blockIdx.x, tilesM * tilesN);
+  const int per_group = GROUP_M * tilesN;
+  const int grp = v / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tilesM - first_m, GROUP_M);
+  const int in_grp = v - grp * per_group;
+  const int tm = first_m + in_grp % gsz;
+  const int tn = in_grp / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- global_load_lds source pointers: 4 x 1 KiB pieces per operand per wave
+  // piece g covers tile rows g*8 .. g*8+7; lane -> (row = g*8 + lane/8, slot = lane%8),
+  // source chunk = slot ^ ((row>>1)&7)
+  const bf16_t* srcA[4];
+  const bf16_t* srcW[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = wv * 4 + j;
+    const int row = g * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int ra = min(m0 + row, p.M - 1);
+    const int rw = min(n0 + row, p.N - 1);
+    srcA[j] = p.A + (size_t)ra * p.lda + chunk * 8;
+    srcW[j] = p.W + (size_t)rw * p.ldw + chunk * 8;
+  }
+
+  // ---- fragment read offsets (bytes inside an operand tile)
+  // lane reads row (blk*32 + l31), 16-B chunk (2*ks + half) ^ ((row>>1)&7); (row>>1)&7 == (lane>>1)&7
+  const int wm = wv >> 1, wn = wv & 1;
+  const int sw = (lane >> 1) & 7;
+  int offA[4], offW[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int x = (((2 * ks + half) ^ sw) << 4);
+    offA[ks] = (wm * 64 + l31) * 128 + x;
+    offW[ks] = OPND_BYTES + (wn * 64 + l31) * 128 + x;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+
+  auto issue = [&](int kt) {
+    char* st = smem + (kt & 1) * STAGE_BYTES;
+    const int koff = kt * BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = wv * 4 + j;
+      __builtin_amdgcn_global_load_lds(MC_GLOBAL_PTR(srcA[j] + koff), MC_LDS_PTR(st + g * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(MC_GLOBAL_PTR(srcW[j] + koff), MC_LDS_PTR(st + OPND_BYTES + g * 1024), 16,
+                                       0, 0);
+    }
+  };
+
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0);  // own pieces of step kt have landed
+    __syncthreads();                // everyone's pieces landed; everyone finished reading the other stage
+    if (kt + 1 < nk) issue(kt + 1);
+    const char* st = smem + (kt & 1) * STAGE_BYTES;
+    // register double-buffered fragment reads: the ds_reads of k-substep ks+1 are in flight
+    // behind the four MFMAs of substep ks
+    bf16x8 a0 = *(const bf16x8*)(st + offA[0]);
+    bf16x8 a1 = *(const bf16x8*)(st + offA[0] + 32 * 128);
+    bf16x8 w0 = *(const bf16x8*)(st + offW[0]);
+    bf16x8 w1 = *(const bf16x8*)(st + offW[0] + 32 * 128);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 na0, na1, nw0, nw1;
+      if (ks < 3) {
+        na0 = *(const bf16x8*)(st + offA[ks + 1]);
+        na1 = *(const bf16x8*)(st + offA[ks + 1] + 32 * 128);
+        nw0 = *(const bf16x8*)(st + offW[ks + 1]);
+        nw1 = *(const bf16x8*)(st + offW[ks + 1] + 32 * 128);
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[1][1], 0, 0, 0);
+      if (ks < 3) {
+        a0 = na0; a1 = na1; w0 = nw0; w1 = nw1;
+      }
+    }
+  }
+
+  // ---- epilogue.  acc[ni][mi][r] = C[m][n], m = m0+wm*64+mi*32+l31,
+  //      n = n0+wn*64+ni*32 + (r&3) + 8*(r>>2) + 4*half  -> 4 consecutive n per (r>>2)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * half;
+        if (n >= p.N) continue;
+        f32x4 val;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) val[i] = acc[ni][mi][4 * g + i] + b[i];
+
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+          if constexpr (EPI == EPI_GELU_BF16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) val[i] = gelu_tanh(bf16_round(val[i]));
+          }
+          u32x2 o = {pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
+          *(u32x2*)(p.Cb + (size_t)m * p.ldc + n) = o;
+        } else if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
+          f32x4 gt = {1.f, 1.f, 1.f, 1.f};
+          if (p.gate) gt = *(const f32x4*)(p.gate + n);
+          float* xp = p.X + (size_t)m * p.ldx + n;
+          f32x4 xv = *(const f32x4*)xp;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[i] = xv[i] + bf16_round(val[i]) * gt[i];
+          *(f32x4*)xp = xv;
+          if constexpr (EPI == EPI_RESID_CAPTURE) {
+            u32x2 x0 = *(const u32x2*)(p.X0 + (size_t)m * p.ldx0 + n);
+            f32x4 r;
+            r[0] = xv[0] - __uint_as_float(x0[0] << 16);
+            r[1] = xv[1] - __uint_as_float(x0[0] & 0xffff0000u);
+            r[2] = xv[2] - __uint_as_float(x0[1] << 16);
+            r[3] = xv[3] - __uint_as_float(x0[1] & 0xffff0000u);
+            *(f32x4*)(p.R + (size_t)m * p.ldr + n) = r;
+          }
+        } else if constexpr (EPI == EPI_EMBED) {
+          const bool valid = m < p.m_valid;
+          u32x2 o = {0u, 0u};
+          f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+          if (valid) {
+            o[0] = pack_bf16x2(val[0], val[1]);
+            o[1] = pack_bf16x2(val[2], val[3]);
+            xv[0] = __uint_as_float(o[0] << 16);
+            xv[1] = __uint_as_float(o[0] & 0xffff0000u);
+            xv[2] = __uint_as_float(o[1] << 16);
+            xv[3] = __uint_as_float(o[1] & 0xffff0000u);
+          }
+          *(f32x4*)(p.X + (size_t)m * p.ldx + n) = xv;
+          *(u32x2*)(p.X0out + (size_t)m * p.ldx0out + n) = o;
+        } else {  // EPI_F32
+          *(f32x4*)(p.X + (size_t)m * p.ldx + n) = val;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_tn_kernel<EPI>), dim3(tilesM * tilesN), dim3(256), 2 * STAGE_BYTES, stream, p,
+                     tilesM, tilesN);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.N % 4) != 0) return hipErrorInvalidValue;
+  if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
+  switch (epi) {
+    case EPI_BF16: return launch_t<EPI_BF16>(p, stream);
+    case EPI_GELU_BF16: return launch_t<EPI_GELU_BF16>(p, stream);
+    case EPI_RESID_GATE: return launch_t<EPI_RESID_GATE>(p, stream);
+    case EPI_RESID_CAPTURE: return launch_t<EPI_RESID_CAPTURE>(p, stream);
+    case EPI_EMBED: return launch_t<EPI_EMBED>(p, stream);
+    case EPI_F32: return launch_t<EPI_F32>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mc

@@ -1,0 +1,106 @@
+// Internal launch API of the HIP kernels (C++ side, below the C-ABI in include/magcache_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace mc {
+
+typedef uint16_t bf16_t;
+
+// ---------------------------------------------------------------- GEMM (gemm_bf16.hip)
+// C[M,N] = A[M,K] * W[N,K]^T  (bf16 inputs, fp32 MFMA accumulate), fused epilogues.
+enum GemmEpi {
+  EPI_BF16 = 0,          // Cb = bf16(acc + bias)
+  EPI_GELU_BF16 = 1,     // Cb = bf16(gelu_tanh(bf16(acc + bias)))
+  EPI_RESID_GATE = 2,    // X += gate[n] * bf16(acc + bias)         (gate == null -> 1)
+  EPI_RESID_CAPTURE = 3, // as 2, then R = X_new - X0               (MagCache residual capture)
+  EPI_EMBED = 4,         // X = bf16(acc + bias) (as fp32), X0out = same (bf16)
+  EPI_F32 = 5,           // X = acc + bias (fp32 store)
+};
+
+struct GemmParams {
+  const bf16_t* A; long lda;
+  const bf16_t* W; long ldw;
+  const float* bias;
+  int M, N, K;
+  bf16_t* Cb; long ldc;
+  float* X; long ldx;
+  const float* gate;
+  const bf16_t* X0; long ldx0;
+  float* R; long ldr;
+  bf16_t* X0out; long ldx0out;
+  int m_valid;  // EPI_EMBED: rows >= m_valid are written as zeros (sequence padding)
+};
+
+hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+struct AttnParams {
+  const bf16_t* Q; long ldq;
+  const bf16_t* K; long ldk; long k_shard_stride;
+  const bf16_t* V; long ldv; long v_shard_stride;
+  bf16_t* O; long ldo;
+  int Lq_pad;       // query rows, multiple of 256
+  int n_heads;      // head_dim is fixed at 128
+  int shard_rows;   // rows per KV shard in memory (multiple of 64)
+  int shard_valid;  // valid keys at the start of every shard
+  int n_shards;
+  float scale;      // softmax scale (1/sqrt(128))
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------- token-wise ops (elementwise.hip)
+// out[m,:] = bf16( LN(x[m,:]) * a + b ),  a = 1+scale (modulate) or weight (affine)
+//   mode 0: a = 1 + sc[d], b = sh[d]      (AdaLN modulate; sc/sh fp32 vectors)
+//   mode 1: a = sc[d],     b = sh[d]      (affine LayerNorm: weight / bias)
+// If x0 != null the row is x0[m,:] (bf16) + x[m,:] (fp32): the fused MagCache skip path.
+hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long ldx0, const float* sc,
+                              const float* sh, int mode, float eps, bf16_t* out, long ldo, float* out_f32,
+                              long ldof, int M, int D, hipStream_t stream);
+
+// in-place RMSNorm over D (all heads) + optional 3-D RoPE on bf16 rows.
+//   y = bf16(x * rsqrt(mean(x^2)+eps)) * w ; rope pairs (2i,2i+1) with cs[token][64] (cos,sin)
+hipError_t launch_rmsnorm_rope(bf16_t* x, long ldx, const float* w, float eps, const float* cs, int cs_row0,
+                               int M, int D, hipStream_t stream);
+
+// latent fp32 [C,F,H,W] -> im2col bf16 tokens [L_pad, C*pt*ph*pw] for patch (1,2,2)
+hipError_t launch_patchify(const float* lat, int C, int F, int H, int W, int tok0, int n_tok, int n_rows,
+                           bf16_t* out, long ldo, hipStream_t stream);
+// head output [L, 4*C] fp32 -> out [C,F,H,W] fp32 (unpatchify, patch (1,2,2))
+hipError_t launch_unpatchify(const float* tok, long ldt, int C, int F, int H, int W, int tok0, int n_tok,
+                             float* out, hipStream_t stream);
+// y[n] = act_out( dot(W[n,:], act_in(x)) + b[n] ), fp32 GEMV. act: 0 none, 1 silu
+hipError_t launch_gemv_f32(const float* W, const float* x, const float* b, float* y, int N, int K, int act_in,
+                           int act_out, hipStream_t stream);
+// sinusoidal_embedding_1d(dim, t) in float64 -> fp32; t read from device (t_dev) or host value
+hipError_t launch_sinusoid(const float* t_dev, double t_host, int dim, float* out, hipStream_t stream);
+// out[i] = a[i % na] + b[i]   (modulation + e0 broadcast)
+hipError_t launch_add_bcast(const float* a, int na, const float* b, float* out, int n, hipStream_t stream);
+// fp32 -> bf16 cast with zero padding of rows >= rows_valid
+hipError_t launch_cast_pad_bf16(const float* src, long lds, int rows_valid, int rows, int cols, bf16_t* dst,
+                                long ldd, hipStream_t stream);
+hipError_t launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
+// head: out[m, n] = dot(xn[m,:], W[n,:]) + b[n], fp32, N small (<= 64)
+hipError_t launch_head_linear(const float* xn, long ldx, const float* W, const float* b, float* out, long ldo,
+                              int M, int N, int K, hipStream_t stream);
+// sampler: eps = u + g (c - u);  x = x + dt * eps  (flow-matching Euler step)
+hipError_t launch_cfg_euler(const float* cond, const float* uncond, float g, float dt, float* x, float* eps_out,
+                            size_t n, hipStream_t stream);
+
+// ---------------------------------------------------------------- MagCache ops (magcache_ops.hip)
+// out = x0 (bf16) + r (fp32)     -- the skipped-step path (reference :294-295)
+hipError_t launch_skip_add(const bf16_t* x0, long ldx0, const float* r, long ldr, float* out, long ldo, int M,
+                           int D, hipStream_t stream);
+// r = x (fp32) - x0 (bf16)       -- residual capture (reference :299)
+hipError_t launch_residual_sub(const float* x, long ldx, const bf16_t* x0, long ldx0, float* r, long ldr, int M,
+                               int D, hipStream_t stream);
+// calibration statistics (reference :167-169): per token rho = |r|/|rp|, cos; then
+// stats[0]=mean(rho) stats[1]=std(rho, unbiased) stats[2]=mean(1-cos). partial = workspace of
+// 4*n_blocks doubles; sums[4] (double) receives (sum rho, sum rho^2, sum (1-cos), count) for
+// multi-rank reduction.
+hipError_t launch_calib_stats(const float* r, long ldr, const float* rp, long ldrp, int M, int D, double* partial,
+                              int n_blocks, double* sums, float* stats, hipStream_t stream);
+hipError_t launch_calib_finalize(const double* sums, float* stats, hipStream_t stream);
+
+}  // namespace mc

@@ -1,0 +1,131 @@
+// Host-side MagCache decision rule: a literal restatement, in double precision, of the scalar
+// state machine every reference script carries
+//   Wan2.1      MagCache4Wan2.1/magcache_generate.py:277-292, :306-311
+//   Wan2.2      MagCache4Wan2.2/magcache_generate.py:290-317, :328-333
+//   HunyuanVideo MagCache4HunyuanVideo/magcache_sample_video.py:88-102
+//   FLUX        MagCache4FLUX/magcache_flux.py:326-338, :432-437
+// It never touches the device (the reference's decision has no .item()/sync either), so the launch
+// path stays asynchronous.  Python floats are IEEE doubles: the arithmetic below is bit-identical.
+#include <cmath>
+#include <vector>
+
+#include "../../include/magcache_hip.h"
+
+struct mc_rule {
+  int variant, num_steps, K, split_step;
+  double thresh, retention;
+  std::vector<double> ratios;
+  int cnt = 0;
+  double acc_err[2] = {0.0, 0.0};
+  int acc_steps[2] = {0, 0};
+  double acc_ratio[2] = {1.0, 1.0};
+};
+
+namespace {
+
+bool two_slot(int variant) {
+  return variant == MC_RULE_WAN21 || variant == MC_RULE_WAN22_T2V || variant == MC_RULE_WAN22_I2V ||
+         variant == MC_RULE_WAN22_TI2V;
+}
+
+bool gate_open(const mc_rule* r) {
+  const int n = r->num_steps, cnt = r->cnt, sp = r->split_step;
+  const double R = r->retention;
+  switch (r->variant) {
+    case MC_RULE_WAN21:
+    case MC_RULE_WAN22_TI2V: return cnt >= (int)(n * R);
+    case MC_RULE_HUNYUAN: return cnt >= (int)(R * n);
+    case MC_RULE_FLUX: return cnt >= (int)(R * n + 0.5);
+    case MC_RULE_WAN22_I2V: return !(cnt < (int)(sp + (n - sp) * R));
+    case MC_RULE_WAN22_T2V:
+      return !(cnt < (int)(sp * R) || ((double)cnt <= ((n - sp) * R + sp) && cnt >= sp));
+    default: return false;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+mc_rule* mc_rule_create(int variant, int num_steps, double thresh, int K, double retention_ratio,
+                        const double* mag_ratios, int n_ratios, int split_step) {
+  if (variant < MC_RULE_WAN21 || variant > MC_RULE_WAN22_TI2V || num_steps <= 0 || !mag_ratios ||
+      n_ratios < num_steps)
+    return nullptr;
+  mc_rule* r = new mc_rule();
+  r->variant = variant;
+  r->num_steps = num_steps;
+  r->thresh = thresh;
+  r->K = K;
+  r->retention = retention_ratio;
+  r->split_step = split_step;
+  r->ratios.assign(mag_ratios, mag_ratios + n_ratios);
+  return r;
+}
+
+void mc_rule_destroy(mc_rule* r) { delete r; }
+
+int mc_rule_step(mc_rule* r, int* branch) {
+  const int p = two_slot(r->variant) ? (r->cnt % 2) : 0;
+  if (branch) *branch = p;
+  bool skip = false;
+  if (gate_open(r)) {
+    const double cur = r->ratios[r->cnt];
+    r->acc_ratio[p] = r->acc_ratio[p] * cur;
+    r->acc_steps[p] += 1;
+    r->acc_err[p] += std::fabs(1.0 - r->acc_ratio[p]);
+    bool ok;
+    if (two_slot(r->variant)) {
+      ok = r->acc_err[p] < r->thresh && r->acc_steps[p] <= r->K;
+    } else {
+      ok = r->acc_err[p] <= r->thresh && r->acc_steps[p] <= r->K;
+      if (r->variant == MC_RULE_FLUX) {
+        // np.round(cnt*((28-1)/(num_steps-1))).astype(int) != 11   (round-half-even)
+        const double pos = std::nearbyint(r->cnt * ((28.0 - 1.0) / (r->num_steps - 1)));
+        ok = ok && ((long)pos != 11);
+      }
+    }
+    if (ok) {
+      skip = true;
+    } else {
+      r->acc_err[p] = 0.0;
+      r->acc_steps[p] = 0;
+      r->acc_ratio[p] = 1.0;
+    }
+  }
+  r->cnt += 1;
+  if (r->cnt >= r->num_steps) {
+    r->cnt = 0;
+    for (int i = 0; i < 2; ++i) {
+      r->acc_ratio[i] = 1.0;
+      r->acc_err[i] = 0.0;
+      r->acc_steps[i] = 0;
+    }
+  }
+  return skip ? 1 : 0;
+}
+
+int mc_rule_cnt(const mc_rule* r) { return r->cnt; }
+
+void mc_rule_state(const mc_rule* r, double acc_err[2], int acc_steps[2], double acc_ratio[2]) {
+  for (int i = 0; i < 2; ++i) {
+    if (acc_err) acc_err[i] = r->acc_err[i];
+    if (acc_steps) acc_steps[i] = r->acc_steps[i];
+    if (acc_ratio) acc_ratio[i] = r->acc_ratio[i];
+  }
+}
+
+// nearest_interp (MagCache4Wan2.1/magcache_generate.py:27-34): np.round is round-half-even
+void mc_nearest_interp(const double* src, int src_len, double* dst, int target_length) {
+  if (target_length == 1) {
+    dst[0] = src[src_len - 1];
+    return;
+  }
+  const double scale = (double)(src_len - 1) / (double)(target_length - 1);
+  for (int i = 0; i < target_length; ++i) {
+    long idx = (long)std::nearbyint((double)i * scale);
+    dst[i] = src[idx];
+  }
+}
+
+}  // extern "C"
