@@ -1,0 +1,96 @@
+"""ctypes binding of libmagcache_hip.so (include/magcache_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or cannot be loaded the import
+of the product path fails loudly -- a silent CPU/PyTorch path would void every parity and
+performance claim made for the engine.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmagcache_hip.so")
+
+MC_OK, MC_EINVAL, MC_ENOMEM, MC_EHIP, MC_ESTATE = 0, 1, 2, 3, 4
+MC_F32, MC_BF16 = 0, 1
+MC_MODE_FULL, MC_MODE_SKIP, MC_MODE_CALIB = 0, 1, 2
+RULE_VARIANTS = {"wan21": 0, "hunyuan": 1, "flux": 2, "wan22_t2v": 3, "wan22_i2v": 4, "wan22_ti2v": 5}
+
+
+class McConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dim", "ffn_dim", "num_heads", "num_layers", "in_dim", "out_dim", "freq_dim",
+                                       "text_dim", "text_len", "latent_f", "latent_h", "latent_w")] + \
+               [("eps", C.c_float)] + \
+               [(n, C.c_int) for n in ("sp_rank", "sp_size", "n_branches", "calibration")]
+
+
+class MagCacheHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"magcache_hip status {status}: {msg}")
+        self.status = status
+
+
+_vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/magcache_hip.h declares
+SIGNATURES = {
+    "mc_last_error": (C.c_char_p, []),
+    "mc_version": (C.c_char_p, []),
+    "mc_create": (_i, [C.POINTER(McConfig), C.POINTER(_vp)]),
+    "mc_destroy": (None, [_vp]),
+    "mc_workspace_bytes": (_sz, [_vp]),
+    "mc_set_workspace": (_i, [_vp, _vp, _sz]),
+    "mc_buffer_info": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mc_set_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i, _vp]),
+    "mc_weights_missing": (_i, [_vp, C.c_char_p, _sz]),
+    "mc_forward": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mc_embed": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _vp]),
+    "mc_block_pre_attn": (_i, [_vp, _i, _vp]),
+    "mc_block_post_attn": (_i, [_vp, _i, _i, _i, _vp]),
+    "mc_head": (_i, [_vp, _i, _i, _vp]),
+    "mc_unpatchify": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "mc_calib_ready": (_i, [_vp, _i, C.POINTER(_i)]),
+    "mc_calib_finalize": (_i, [_vp, _i, _vp]),
+    "mc_state_reset": (_i, [_vp]),
+    "mc_rule_create": (_vp, [_i, _i, _d, _i, _d, C.POINTER(_d), _i, _i]),
+    "mc_rule_destroy": (None, [_vp]),
+    "mc_rule_step": (_i, [_vp, C.POINTER(_i)]),
+    "mc_rule_cnt": (_i, [_vp]),
+    "mc_rule_state": (None, [_vp, C.POINTER(_d), C.POINTER(_i), C.POINTER(_d)]),
+    "mc_nearest_interp": (None, [C.POINTER(_d), _i, C.POINTER(_d), _i]),
+    "mc_op_gemm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l,
+                             _i, _vp]),
+    "mc_op_attention": (_i, [_vp, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
+    "mc_op_ln_modulate": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _f, _vp, _l, _vp, _l, _i, _i, _vp]),
+    "mc_op_rmsnorm_rope": (_i, [_vp, _l, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "mc_op_skip_add": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp]),
+    "mc_op_residual_sub": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp]),
+    "mc_op_calib_stats": (_i, [_vp, _l, _vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "mc_op_cfg_euler": (_i, [_vp, _vp, _f, _f, _vp, _vp, _sz, _vp]),
+    "mc_op_cast_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "mc_op_rope_table": (_i, [_i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it is absent -- build it with
+    `python -m magcache_amd.build` (hipcc --offload-arch=gfx950)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: the HIP engine is not built (python -m magcache_amd.build). "
+                          "magcache_amd has no CPU fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != MC_OK:
+        raise MagCacheHipError(status, load().mc_last_error().decode())

@@ -1,0 +1,196 @@
+"""Thin Python wrapper over the C-ABI engine: PyTorch-ROCm owns device memory and the stream, the
+library does everything else.  No compute happens in torch here."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MC_BF16, MC_F32, MC_MODE_CALIB, MC_MODE_FULL, MC_MODE_SKIP, McConfig, check
+
+WAN_T2V_1_3B = dict(dim=1536, ffn_dim=8960, freq_dim=256, num_heads=12, num_layers=30, text_len=512, in_dim=16,
+                    out_dim=16, text_dim=4096, eps=1e-6)
+WAN_T2V_14B = dict(dim=5120, ffn_dim=13824, freq_dim=256, num_heads=40, num_layers=40, text_len=512, in_dim=16,
+                   out_dim=16, text_dim=4096, eps=1e-6)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def weight_names(cfg):
+    """(name, shape) of every parameter of the upstream WanModel state_dict the engine consumes."""
+    d, ffn = cfg["dim"], cfg["ffn_dim"]
+    out = [("patch_embedding.weight", (d, cfg["in_dim"], 1, 2, 2)), ("patch_embedding.bias", (d,)),
+           ("text_embedding.0.weight", (d, cfg["text_dim"])), ("text_embedding.0.bias", (d,)),
+           ("text_embedding.2.weight", (d, d)), ("text_embedding.2.bias", (d,)),
+           ("time_embedding.0.weight", (d, cfg["freq_dim"])), ("time_embedding.0.bias", (d,)),
+           ("time_embedding.2.weight", (d, d)), ("time_embedding.2.bias", (d,)),
+           ("time_projection.1.weight", (6 * d, d)), ("time_projection.1.bias", (6 * d,)),
+           ("head.head.weight", (4 * cfg["out_dim"], d)), ("head.head.bias", (4 * cfg["out_dim"],)),
+           ("head.modulation", (1, 2, d))]
+    for i in range(cfg["num_layers"]):
+        p = f"blocks.{i}."
+        for a in ("self_attn", "cross_attn"):
+            for w in ("q", "k", "v", "o"):
+                out += [(p + f"{a}.{w}.weight", (d, d)), (p + f"{a}.{w}.bias", (d,))]
+            out += [(p + f"{a}.norm_q.weight", (d,)), (p + f"{a}.norm_k.weight", (d,))]
+        out += [(p + "norm3.weight", (d,)), (p + "norm3.bias", (d,)),
+                (p + "ffn.0.weight", (ffn, d)), (p + "ffn.0.bias", (ffn,)),
+                (p + "ffn.2.weight", (d, ffn)), (p + "ffn.2.bias", (d,)),
+                (p + "modulation", (1, 6, d))]
+    return out
+
+
+def synthetic_weights(cfg, seed=0, std=0.02, device="cuda"):
+    """Seeded random-init weights of the named architecture, generated on the device one tensor at a
+    time (no checkpoint exists offline).  Same distribution family as oracle.init_synthetic_."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    for name, shape in weight_names(cfg):
+        if name.endswith("modulation"):
+            t = torch.randn(shape, generator=g, device=device) / cfg["dim"] ** 0.5
+        elif "norm" in name and name.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        elif "norm" in name and name.endswith("bias"):
+            t = 0.1 * torch.randn(shape, generator=g, device=device)
+        else:
+            t = std * torch.randn(shape, generator=g, device=device)
+        yield name, t
+
+
+class Engine:
+    """One DiT engine on one device (one per process).  latent grid = (F, H, W) of the VAE latent."""
+
+    def __init__(self, cfg, latent_grid, device="cuda:0", sp_rank=0, sp_size=1, n_branches=2, calibration=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("magcache_amd.Engine needs a ROCm device; there is no CPU fallback")
+        self.lib = _lib.load()
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        F_, H_, W_ = latent_grid
+        self.grid = (F_, H_, W_)
+        self.seq_len = F_ * (H_ // 2) * (W_ // 2)
+        c = McConfig(dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"], num_layers=cfg["num_layers"],
+                     in_dim=cfg["in_dim"], out_dim=cfg["out_dim"], freq_dim=cfg["freq_dim"], text_dim=cfg["text_dim"],
+                     text_len=cfg["text_len"], latent_f=F_, latent_h=H_, latent_w=W_, eps=cfg.get("eps", 1e-6),
+                     sp_rank=sp_rank, sp_size=sp_size, n_branches=n_branches, calibration=int(calibration))
+        self.sp_rank, self.sp_size, self.n_branches = sp_rank, sp_size, n_branches
+        h = C.c_void_p()
+        check(self.lib.mc_create(C.byref(c), C.byref(h)))
+        self.h = h
+        nbytes = self.lib.mc_workspace_bytes(self.h)
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-self.workspace.data_ptr()) % 256
+        self.ws = self.workspace[off:off + nbytes]
+        # finite, deterministic scratch: padded rows feed MFMAs (0 * NaN would poison valid rows)
+        self.ws.zero_()
+        check(self.lib.mc_set_workspace(self.h, _ptr(self.ws), nbytes))
+        self.tokens_per_rank = self.seq_len // sp_size
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                torch.cuda.synchronize(self.device)
+                self.lib.mc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- weights
+    def set_weight(self, name, tensor):
+        t = tensor.detach()
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            t = t.float()
+        t = t.to(self.device).contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        dt = MC_F32 if t.dtype == torch.float32 else MC_BF16
+        check(self.lib.mc_set_weight(self.h, name.encode(), _ptr(t), dt, shape, t.dim(), _stream()))
+        torch.cuda.current_stream().synchronize()  # t may be freed by the caller right after
+
+    def load_weights(self, named_tensors):
+        items = named_tensors.items() if hasattr(named_tensors, "items") else named_tensors
+        for name, t in items:
+            self.set_weight(name, t)
+        buf = C.create_string_buffer(4096)
+        n = self.lib.mc_weights_missing(self.h, buf, 4096)
+        if n:
+            raise KeyError(f"{n} weights missing, e.g.: {buf.value.decode().split()[:5]}")
+
+    # ---- buffers
+    def buffer(self, name, dtype=torch.uint8):
+        off, nb = C.c_size_t(), C.c_size_t()
+        check(self.lib.mc_buffer_info(self.h, name.encode(), C.byref(off), C.byref(nb)))
+        return self.ws[off.value:off.value + nb.value].view(dtype)
+
+    def residual(self, branch):
+        """fp32 [seq_len/sp, dim] view of residual_cache[branch] (rows past the valid tokens cut off)."""
+        d = self.cfg["dim"]
+        return self.buffer(f"residual_branch{branch}", torch.float32).view(-1, d)[:self.tokens_per_rank]
+
+    # ---- forward
+    def _ctx(self, context):
+        if context.dtype == torch.bfloat16:
+            return context.contiguous(), MC_BF16
+        return context.float().contiguous(), MC_F32
+
+    def forward(self, latent, t, context, branch=0, mode=MC_MODE_FULL, out=None):
+        """latent fp32 [C,F,H,W]; t python float or 1-element tensor on the device; context
+        [ctx_len, text_dim].  Returns fp32 [out_dim, F, H, W].  Asynchronous on the current stream."""
+        assert self.sp_size == 1, "use magcache_amd.parallel.SequenceParallelForward for sp_size > 1"
+        latent = latent.float().contiguous()
+        ctx, cdt = self._ctx(context)
+        if out is None:
+            out = torch.empty((self.cfg["out_dim"],) + self.grid, dtype=torch.float32, device=self.device)
+        t_dev, t_host = self._t(t)
+        check(self.lib.mc_forward(self.h, _ptr(latent), _ptr(t_dev), t_host, _ptr(ctx), cdt, ctx.shape[0], branch,
+                                  mode, _ptr(out), _stream()))
+        self._keep = (latent, ctx, t_dev)  # keep inputs alive until the stream has consumed them
+        return out
+
+    def _t(self, t):
+        if torch.is_tensor(t):
+            if t.is_cuda:
+                return t.reshape(-1)[:1].to(torch.float32), 0.0
+            return None, float(t.reshape(-1)[0])
+        return None, float(t)
+
+    # ---- phase API (sequence parallel)
+    def embed(self, latent, t, context):
+        latent = latent.float().contiguous()
+        ctx, cdt = self._ctx(context)
+        t_dev, t_host = self._t(t)
+        check(self.lib.mc_embed(self.h, _ptr(latent), _ptr(t_dev), t_host, _ptr(ctx), cdt, ctx.shape[0], _stream()))
+        self._keep = (latent, ctx, t_dev)
+
+    def block_pre_attn(self, layer):
+        check(self.lib.mc_block_pre_attn(self.h, layer, _stream()))
+
+    def block_post_attn(self, layer, branch, mode):
+        check(self.lib.mc_block_post_attn(self.h, layer, branch, mode, _stream()))
+
+    def head(self, branch, mode):
+        check(self.lib.mc_head(self.h, branch, mode, _stream()))
+
+    def unpatchify(self, tokens, tok0, n_tok, out):
+        check(self.lib.mc_unpatchify(self.h, _ptr(tokens), tok0, n_tok, _ptr(out), _stream()))
+
+    def calib_stats(self, branch):
+        """(norm_ratio, norm_std, cos_dis) of the last CALIB forward of `branch` or None.  Reading them
+        is a device->host sync, exactly like the reference's three .item() calls (:167-169)."""
+        has = C.c_int()
+        check(self.lib.mc_calib_ready(self.h, branch, C.byref(has)))
+        if not has.value:
+            return None
+        s = self.buffer("calib_stats", torch.float32)[3 * branch:3 * branch + 3].cpu()
+        return float(s[0]), float(s[1]), float(s[2])
+
+    def reset(self):
+        check(self.lib.mc_state_reset(self.h))
+
+
+__all__ = ["Engine", "WAN_T2V_1_3B", "WAN_T2V_14B", "weight_names", "synthetic_weights", "MC_MODE_FULL",
+           "MC_MODE_SKIP", "MC_MODE_CALIB"]

@@ -1,0 +1,212 @@
+"""Host-side mirror of the reference's monkey-patch surface for Wan2.1.
+
+The reference patches the upstream model CLASS (MagCache4Wan2.1/magcache_generate.py:896-928):
+
+    wan_t2v.model.__class__.forward = magcache_forward
+    wan_t2v.model.__class__.cnt = 0 ; .num_steps ; .magcache_thresh ; .K ; .retention_ratio
+    .accumulated_err/.accumulated_steps/.accumulated_ratio = [.,.] ; .residual_cache = [None, None]
+    .mag_ratios = np.array(...)
+
+`WanModelHIP` stands where upstream `WanModel` stands (same forward signature, :198-206), and
+`magcache_forward` / `magcache_calibration` below are drop-ins for the reference functions of the
+same name: same arguments, same class-attribute names with the same meaning (readable and writable
+between calls), same asserts -- but everything between the embeds and the head runs in the HIP
+engine.  The skip decision is pure host arithmetic on those attributes, as in the reference
+(:277-292): no device sync on the launch path.
+"""
+import json
+
+import numpy as np
+import torch
+
+from .engine import MC_MODE_CALIB, MC_MODE_FULL, MC_MODE_SKIP, Engine
+from .mag_ratios import TABLES
+
+
+def nearest_interp(src_array, target_length):
+    """Resample a ratio table by nearest index (reference nearest_interp, :27-34)."""
+    src_array = np.asarray(src_array)
+    if target_length == 1:
+        return np.array([src_array[-1]])
+    pos = np.arange(target_length) * ((len(src_array) - 1) / (target_length - 1))
+    return src_array[np.round(pos).astype(int)]
+
+
+def resample_cfg_table(mag_ratios, sample_steps):
+    """cond (even) and uncond (odd) entries are resampled separately and re-interleaved (:915-919)."""
+    mag_ratios = np.asarray(mag_ratios, dtype=np.float64)
+    if len(mag_ratios) == sample_steps * 2:
+        return mag_ratios
+    pair = [nearest_interp(mag_ratios[i::2], sample_steps) for i in (0, 1)]
+    return np.stack(pair, axis=1).reshape(-1)
+
+
+def select_table(ckpt_dir, task="t2v"):
+    """The reference picks the table by substring of --ckpt_dir (:909-912, :1001-1004, :1141-1144)."""
+    s = str(ckpt_dir)
+    if "vace" in task:
+        return TABLES["wan2.1_vace_14B" if "14B" in s else "wan2.1_vace_1.3B"]
+    if "i2v" in task:
+        return TABLES["wan2.1_i2v_720P" if "720P" in s else "wan2.1_i2v_480P"]
+    if "T2V-14B" in s:
+        return TABLES["wan2.1_t2v_14B"]
+    if "T2V-1.3B" in s:
+        return TABLES["wan2.1_t2v_1.3B"]
+    raise ValueError(f"no mag_ratios table for ckpt_dir={ckpt_dir!r}; run --magcache_calibration first")
+
+
+class WanModelHIP:
+    """Wan2.1 T2V DiT whose forward runs on the HIP engine.  One latent grid per instance."""
+
+    model_type = "t2v"
+    patch_size = (1, 2, 2)
+
+    def __init__(self, cfg, latent_grid, device="cuda:0", calibration=True, engine=None):
+        self.cfg = dict(cfg)
+        for k in ("dim", "ffn_dim", "freq_dim", "text_len", "text_dim", "in_dim", "out_dim", "num_heads",
+                  "num_layers"):
+            setattr(self, k, cfg[k])
+        self.latent_grid = tuple(latent_grid)
+        self.engine = engine or Engine(cfg, latent_grid, device=device, n_branches=2, calibration=calibration)
+        self.device = self.engine.device
+
+    def load_state_dict(self, state_dict):
+        self.engine.load_weights(state_dict)
+        return self
+
+    # -- input checks shared by all forwards (the reference's asserts :226-227, :242)
+    def _check_inputs(self, x, context, seq_len, clip_fea, y):
+        if self.model_type == "i2v":
+            assert clip_fea is not None and y is not None
+        assert len(x) == 1 and len(context) == 1, "the engine evaluates one sample per call, as the Wan sampler does"
+        u = x[0]
+        assert tuple(u.shape[1:]) == self.latent_grid and u.shape[0] == self.in_dim, \
+            f"latent {tuple(u.shape)} does not match the engine grid {(self.in_dim,) + self.latent_grid}"
+        assert self.engine.seq_len <= seq_len  # seq_lens.max() <= seq_len (:242)
+        assert context[0].shape[0] <= self.text_len and context[0].shape[1] == self.text_dim
+
+    def _run(self, x, t, context, branch, mode):
+        out = self.engine.forward(x[0].to(self.device), t if not torch.is_tensor(t) else t.to(self.device),
+                                  context[0].to(self.device), branch=branch, mode=mode)
+        return [out.float()]
+
+    def __call__(self, *args, **kwargs):
+        # dispatch through the CLASS attribute so that `Model.__class__.forward = fn` takes effect,
+        # exactly as it does for an nn.Module
+        return type(self).forward(self, *args, **kwargs)
+
+
+def plain_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
+    """Plain (no-cache) forward: upstream WanModel.forward."""
+    self._check_inputs(x, context, seq_len, clip_fea, y)
+    return self._run(x, t, context, 0, MC_MODE_FULL)
+
+
+WanModelHIP.forward = plain_forward
+
+
+def _advance(self):
+    # :306-311 -- the residual cache is NOT cleared, only the accumulators
+    self.cnt += 1
+    if self.cnt >= self.num_steps:
+        self.cnt = 0
+        self.accumulated_ratio = [1.0, 1.0]
+        self.accumulated_err = [0.0, 0.0]
+        self.accumulated_steps = [0, 0]
+
+
+def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
+    """Drop-in for the reference's magcache_forward (:198-312)."""
+    self._check_inputs(x, context, seq_len, clip_fea, y)
+    p = self.cnt % 2  # cond calls are even, uncond odd
+    skip_forward = False
+    if self.cnt >= int(self.num_steps * self.retention_ratio):
+        # magnitude-ratio bookkeeping, host scalars only (:279-292)
+        self.accumulated_ratio[p] = self.accumulated_ratio[p] * self.mag_ratios[self.cnt]
+        self.accumulated_steps[p] += 1
+        self.accumulated_err[p] += np.abs(1 - self.accumulated_ratio[p])
+        if self.accumulated_err[p] < self.magcache_thresh and self.accumulated_steps[p] <= self.K:
+            skip_forward = True
+        else:
+            self.accumulated_err[p] = 0
+            self.accumulated_steps[p] = 0
+            self.accumulated_ratio[p] = 1.0
+    if skip_forward and self.residual_cache[p] is None:
+        raise RuntimeError("MagCache asked to skip before any residual was cached (retention_ratio too small?)")
+    out = self._run(x, t, context, p, MC_MODE_SKIP if skip_forward else MC_MODE_FULL)
+    self.residual_cache[p] = self.engine.residual(p)  # a view of the engine's HBM slot
+    _advance(self)
+    return out
+
+
+def magcache_calibration(self, x, t, context, seq_len, clip_fea=None, y=None):
+    """Drop-in for the reference's magcache_calibration (:80-194): never skips, records
+    norm_ratio / norm_std / cos_dis against the previous residual of the same branch and dumps the
+    three JSON files when the video is finished."""
+    self._check_inputs(x, context, seq_len, clip_fea, y)
+    p = self.cnt % 2
+    out = self._run(x, t, context, p, MC_MODE_CALIB)
+    if self.cnt >= 2:
+        norm_ratio, norm_std, cos_dis = self.engine.calib_stats(p)
+        self.norm_ratio.append(round(norm_ratio, 5))
+        self.norm_std.append(round(norm_std, 5))
+        self.cos_dis.append(round(cos_dis, 5))
+        print(f"time: {self.cnt}, norm_ratio: {norm_ratio}, norm_std: {norm_std}, cos_dis: {cos_dis}")
+    self.residual_cache[p] = self.engine.residual(p)
+    self.cnt += 1
+    if self.cnt >= self.num_steps:
+        self.cnt = 0
+        self.accumulated_ratio = [1.0, 1.0]
+        self.accumulated_err = [0.0, 0.0]
+        self.accumulated_steps = [0, 0]
+        print("norm ratio")
+        print(self.norm_ratio)
+        print("norm std")
+        print(self.norm_std)
+        print("cos_dis")
+        print(self.cos_dis)
+        for fn, v in (("wan2_1_mag_ratio", self.norm_ratio), ("wan2_1_mag_std", self.norm_std),
+                      ("wan2_1_cos_dis", self.cos_dis)):
+            with open(fn + ".json", "w") as f:
+                json.dump(v, f)
+    return out
+
+
+def init_magcache(model, sample_steps, magcache_thresh=0.12, magcache_K=2, retention_ratio=0.2, mag_ratios=None,
+                  ckpt_dir="Wan2.1-T2V-1.3B"):
+    """What the reference does at its patch site (:896-919), on the model's CLASS."""
+    cls = model.__class__
+    cls.forward = magcache_forward
+    cls.cnt = 0
+    cls.num_steps = sample_steps * 2
+    cls.magcache_thresh = magcache_thresh
+    cls.K = magcache_K
+    cls.accumulated_err = [0.0, 0.0]
+    cls.accumulated_steps = [0, 0]
+    cls.accumulated_ratio = [1.0, 1.0]
+    cls.retention_ratio = retention_ratio
+    cls.residual_cache = [None, None]
+    table = select_table(ckpt_dir) if mag_ratios is None else np.asarray(mag_ratios, dtype=np.float64)
+    cls.mag_ratios = resample_cfg_table(table, sample_steps)
+    model.engine.reset()
+    return model
+
+
+def init_magcache_calibration(model, sample_steps):
+    """The calibration patch site (:921-928)."""
+    cls = model.__class__
+    cls.forward = magcache_calibration
+    cls.cnt = 0
+    cls.num_steps = sample_steps * 2
+    cls.norm_ratio, cls.norm_std, cls.cos_dis = [], [], []
+    cls.residual_cache = [None, None]
+    cls.accumulated_err, cls.accumulated_steps, cls.accumulated_ratio = [0.0, 0.0], [0, 0], [1.0, 1.0]
+    model.engine.reset()
+    return model
+
+
+def disable_magcache(model):
+    """Back to the plain forward (for the no-cache baseline)."""
+    model.__class__.forward = plain_forward
+    model.engine.reset()
+    return model

@@ -1,0 +1,200 @@
+"""CPU: the product's host logic (no GPU, no compute calls): the C-ABI library loads and exports
+every symbol include/magcache_hip.h declares; the C decision rule and the Python monkey-patch shim
+reproduce the reference's skip schedules (tests/golden/rule_schedules.json) and state machine."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from magcache_amd import _lib
+from magcache_amd import model as M
+from magcache_amd.mag_ratios import TABLES
+from test_oracle_golden import parse_key, table_for
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "magcache_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == declared
+    assert b"gfx950" in lib.mc_version()
+
+
+def test_no_oracle_import_in_product():
+    """the product path must never route through the oracle"""
+    pkg = os.path.join(ROOT, "magcache_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_c_rule_matches_reference_schedules(golden_dir):
+    lib = _lib.load()
+    g = json.load(open(os.path.join(golden_dir, "rule_schedules.json")))
+    for key, want in g.items():
+        d = parse_key(key)
+        table, n = table_for(d)
+        arr = (C.c_double * len(table))(*table)
+        split = d.get("split")
+        r = lib.mc_rule_create(_lib.RULE_VARIANTS[d["variant"]], n, d["thresh"], d["K"], d["R"], arr, len(table),
+                               0 if split is None else split * 2)
+        assert r
+        b = C.c_int()
+        got, branches = [], []
+        for _ in range(n):
+            got.append(lib.mc_rule_step(r, C.byref(b)))
+            branches.append(b.value)
+        assert got == want, key
+        assert lib.mc_rule_cnt(r) == 0
+        two = d["variant"] in ("wan21", "wan22_t2v", "wan22_i2v", "wan22_ti2v")
+        assert branches == [(i % 2 if two else 0) for i in range(n)]
+        err, steps, ratio = (C.c_double * 2)(), (C.c_int * 2)(), (C.c_double * 2)()
+        lib.mc_rule_state(r, err, steps, ratio)
+        assert list(err) == [0.0, 0.0] and list(steps) == [0, 0] and list(ratio) == [1.0, 1.0]
+        lib.mc_rule_destroy(r)
+
+
+def test_c_rule_rejects_bad_arguments():
+    lib = _lib.load()
+    arr = (C.c_double * 4)(1, 1, 1, 1)
+    assert not lib.mc_rule_create(0, 10, 0.1, 2, 0.2, arr, 4, 0)   # table shorter than num_steps
+    assert not lib.mc_rule_create(99, 4, 0.1, 2, 0.2, arr, 4, 0)   # unknown variant
+
+
+def test_c_nearest_interp(golden_dir):
+    lib = _lib.load()
+    g = json.load(open(os.path.join(golden_dir, "nearest_interp.json")))
+    for key, want in g.items():
+        if "-cfg->" in key:
+            continue
+        name, n = key.split("->")
+        src = TABLES[name]
+        a = (C.c_double * len(src))(*src)
+        out = (C.c_double * int(n))()
+        lib.mc_nearest_interp(a, len(src), out, int(n))
+        assert list(out) == want, key
+
+
+def test_python_nearest_interp_and_table_selection(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "nearest_interp.json")))
+    for key, want in g.items():
+        if "-cfg->" in key:
+            name, n = key.split("-cfg->")
+            got = M.resample_cfg_table(TABLES[name], int(n))
+        else:
+            name, n = key.split("->")
+            got = M.nearest_interp(TABLES[name], int(n))
+        assert np.array_equal(got, np.asarray(want)), key
+    assert M.select_table("./Wan2.1-T2V-1.3B") is TABLES["wan2.1_t2v_1.3B"]
+    assert M.select_table("/x/Wan2.1-T2V-14B") is TABLES["wan2.1_t2v_14B"]
+    assert M.select_table("Wan2.1-I2V-14B-720P", task="i2v-14B") is TABLES["wan2.1_i2v_720P"]
+    with pytest.raises(ValueError):
+        M.select_table("somewhere/else")
+
+
+class FakeEngine:
+    """records what the shim asks the engine to do; no compute"""
+    seq_len = 4
+
+    def __init__(self):
+        self.calls = []
+
+    def reset(self):
+        self.calls.append("reset")
+
+    def residual(self, p):
+        return ("residual", p)
+
+    def calib_stats(self, p):
+        return 1.0, 0.5, 0.25
+
+
+def make_shim():
+    cls = type("PatchedModel", (M.WanModelHIP,), {})
+    m = cls.__new__(cls)
+    m.engine = FakeEngine()
+    m.trace = []
+    cls._check_inputs = lambda self, *a: None
+    cls._run = lambda self, x, t, ctx, branch, mode: (self.trace.append((branch, mode)) or ["out"])
+    return m
+
+
+def test_monkey_patch_surface_and_schedule(golden_dir):
+    """magcache_amd.magcache_forward keeps the reference's attribute surface (:896-919) and skip order"""
+    g = json.load(open(os.path.join(golden_dir, "rule_schedules.json")))
+    for key, want in g.items():
+        d = parse_key(key)
+        if d["variant"] != "wan21":
+            continue
+        m = make_shim()
+        M.init_magcache(m, d["steps"], d["thresh"], d["K"], d["R"], mag_ratios=TABLES[d["table"]])
+        cls = m.__class__
+        for attr in ("cnt", "num_steps", "magcache_thresh", "K", "retention_ratio", "accumulated_err",
+                     "accumulated_steps", "accumulated_ratio", "residual_cache", "mag_ratios"):
+            assert hasattr(cls, attr), attr
+        assert cls.forward is M.magcache_forward and cls.num_steps == 2 * d["steps"]
+        assert len(cls.mag_ratios) == 2 * d["steps"]
+        for i in range(2 * d["steps"]):
+            assert m.cnt == i
+            out = m(["x"], t=0, context=["c"], seq_len=4)
+            assert out == ["out"]
+        assert [int(mode == _lib.MC_MODE_SKIP) for _, mode in m.trace] == want, key
+        assert [b for b, _ in m.trace] == [i % 2 for i in range(2 * d["steps"])]
+        assert m.cnt == 0 and m.accumulated_err == [0.0, 0.0] and m.accumulated_steps == [0, 0]
+        assert m.residual_cache == [("residual", 0), ("residual", 1)]  # not cleared at wrap-around (:306-311)
+
+
+def test_state_is_class_level_and_writable():
+    """Same Python semantics as the reference: `self.cnt += 1` rebinds an int on the instance, the
+    accumulator LISTS are mutated in place on the class until the first wrap-around, and every
+    hyper-parameter can be retuned on the class between calls."""
+    m = make_shim()
+    M.init_magcache(m, 50, 0.12, 2, 0.2, mag_ratios=TABLES["wan2.1_t2v_1.3B"])
+    cls = m.__class__
+    for _ in range(25):
+        m(["x"], t=0, context=["c"], seq_len=4)
+    assert m.cnt == 25 and cls.cnt == 0
+    assert cls.accumulated_steps is m.accumulated_steps      # shared list object, mutated in place
+    assert any(mode == _lib.MC_MODE_SKIP for _, mode in m.trace)
+    n_before = len(m.trace)
+    cls.magcache_thresh = 0.0                                # retune: nothing is skipped any more
+    for _ in range(75):
+        m(["x"], t=0, context=["c"], seq_len=4)
+    assert all(mode == _lib.MC_MODE_FULL for _, mode in m.trace[n_before:])
+    assert m.cnt == 0
+
+
+def test_calibration_shim(tmp_path, monkeypatch, capsys):
+    monkeypatch.chdir(tmp_path)
+    m = make_shim()
+    M.init_magcache_calibration(m, 3)
+    assert m.__class__.forward is M.magcache_calibration
+    for _ in range(6):
+        m(["x"], t=0, context=["c"], seq_len=4)
+    assert all(mode == _lib.MC_MODE_CALIB for _, mode in m.trace)
+    assert m.norm_ratio == [1.0] * 4 and m.norm_std == [0.5] * 4 and m.cos_dis == [0.25] * 4   # cnt >= 2 only
+    for fn in ("wan2_1_mag_ratio.json", "wan2_1_mag_std.json", "wan2_1_cos_dis.json"):           # :191-193
+        assert json.load(open(tmp_path / fn)) in ([1.0] * 4, [0.5] * 4, [0.25] * 4)
+    assert m.cnt == 0
+    M.disable_magcache(m)
+    assert m.__class__.forward is M.plain_forward
+
+
+def test_skip_before_any_residual_is_an_error():
+    m = make_shim()
+    M.init_magcache(m, 2, 10.0, 10, 0.0, mag_ratios=np.ones(4))
+    m.engine.residual = lambda p: None
+    with pytest.raises(RuntimeError):
+        m(["x"], t=0, context=["c"], seq_len=4)

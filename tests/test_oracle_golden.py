@@ -1,0 +1,166 @@
+"""CPU: the oracle (oracle/*.py) against the golden vectors produced by running the reference's own
+code (oracle/gen_golden.py) and against the known answers SURVEY.md section 8c lists."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import magcache_ref as MR
+from oracle import wan_dit_ref as W
+from magcache_amd.mag_ratios import TABLES
+
+VARIANT_OF = {"wan21": "wan21", "hunyuan": "hunyuan", "flux": "flux", "wan22_t2v": "wan22_t2v",
+              "wan22_i2v": "wan22_i2v", "wan22_ti2v": "wan22_ti2v"}
+
+
+def parse_key(key):
+    parts = key.split("|")
+    d = dict(variant=parts[0], table=parts[1])
+    for p in parts[2:]:
+        if p.startswith("steps"):
+            d["steps"] = int(p[5:])
+        elif p.startswith("E"):
+            d["thresh"] = float(p[1:])
+        elif p.startswith("K"):
+            d["K"] = int(p[1:])
+        elif p.startswith("R"):
+            d["R"] = float(p[1:])
+        elif p.startswith("split"):
+            d["split"] = None if p[5:] == "None" else int(p[5:])
+    return d
+
+
+def table_for(d):
+    t = TABLES[d["table"]]
+    two = d["variant"] in ("wan21", "wan22_t2v", "wan22_i2v", "wan22_ti2v")
+    if two:
+        return MR.interp_cfg_table(t, d["steps"]), d["steps"] * 2
+    return (t if len(t) == d["steps"] else MR.nearest_interp(t, d["steps"])), d["steps"]
+
+
+def test_rule_schedules_match_reference(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "rule_schedules.json")))
+    assert len(g) >= 20
+    for key, want in g.items():
+        d = parse_key(key)
+        table, n = table_for(d)
+        split = d.get("split")
+        st = MR.RuleState(d["variant"], n, d["thresh"], d["K"], d["R"], table,
+                          split_step=None if split is None else split * 2)
+        got = [int(s) for s, _ in st.schedule()]
+        assert got == want, key
+        assert st.cnt == 0
+
+
+def test_known_answer_schedules():
+    # T2V-1.3B, 50 steps, R=0.2, thresh 0.12
+    t = TABLES["wan2.1_t2v_1.3B"]
+    k4 = [10, 11, 12, 13, 15, 16, 17, 18, 20, 21, 22, 23, 25, 26, 27, 28, 30, 31, 32, 33, 35, 36, 37, 39, 40, 42, 43,
+          45, 47]
+    k2 = [10, 11, 13, 14, 16, 17, 19, 20, 22, 23, 25, 26, 28, 29, 31, 32, 34, 35, 37, 38, 40, 41, 43, 45, 47]
+    for K, want, total in ((4, k4, 58), (2, k2, 50)):
+        sk = [s for s, _ in MR.RuleState("wan21", 100, 0.12, K, 0.2, t).schedule()]
+        assert [i // 2 for i in range(0, 100, 2) if sk[i]] == want
+        assert [i // 2 for i in range(1, 100, 2) if sk[i]] == want
+        assert sum(sk) == total
+    assert sum(s for s, _ in MR.RuleState("wan21", 100, 0.24, 6, 0.2, t).schedule()) == 64
+    assert sum(s for s, _ in MR.RuleState("wan21", 100, 0.24, 6, 0.2, TABLES["wan2.1_t2v_14B"]).schedule()) == 64
+
+
+def test_table_lengths():
+    want = {"wan2.1_t2v_14B": 100, "wan2.1_t2v_1.3B": 100, "wan2.1_i2v_480P": 80, "wan2.1_i2v_720P": 80,
+            "wan2.1_vace_1.3B": 100, "wan2.1_vace_14B": 100, "wan2.2_t2v_A14B": 80, "wan2.2_ti2v_5B_t2v": 100,
+            "wan2.2_ti2v_5B_i2v": 100, "wan2.2_i2v_A14B": 80, "hunyuan_720p": 50, "hunyuan_540p": 50, "flux_dev": 28}
+    for k, n in want.items():
+        assert len(TABLES[k]) == n, k
+        assert TABLES[k][0] == 1.0
+
+
+def test_nearest_interp(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "nearest_interp.json")))
+    for key, want in g.items():
+        if "-cfg->" in key:
+            name, n = key.split("-cfg->")
+            got = MR.interp_cfg_table(TABLES[name], int(n))
+        else:
+            name, n = key.split("->")
+            got = MR.nearest_interp(TABLES[name], int(n))
+        assert np.array_equal(np.asarray(got), np.asarray(want)), key
+    t = TABLES["flux_dev"]
+    assert MR.nearest_interp(t, 1)[0] == t[-1]           # target==1 -> last element (:29-30)
+    assert np.array_equal(MR.nearest_interp(t, len(t)), t)
+
+
+@pytest.fixture(scope="module")
+def golden_run(golden_dir):
+    g = np.load(os.path.join(golden_dir, "wan_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    model = W.init_synthetic_(W.WanModel(**meta["cfg"]), seed=meta["weight_seed"], std=meta["weight_std"])
+    return g, meta, model
+
+
+def test_magcache_forward_matches_reference_run(golden_run):
+    """oracle MagCacheWan == the reference's magcache_forward executed around the same model."""
+    g, meta, model = golden_run
+    steps = meta["steps"]
+    mc = MR.MagCacheWan(model, steps * 2, meta["thresh"], meta["K"], meta["R"],
+                        MR.interp_cfg_table(TABLES[meta["table"]], steps), autocast=True)
+    x = torch.from_numpy(g["latent0"]).clone()
+    ctx, ctxn = torch.from_numpy(g["ctx"]), torch.from_numpy(g["ctx_null"])
+    sig, ts = MR.flow_timesteps(steps, meta["shift"])
+    assert np.array_equal(ts, g["timesteps"]) and np.allclose(sig, g["sigmas"])
+    seq_len = meta["F"] * (meta["H"] // 2) * (meta["W"] // 2)
+    for i in range(steps):
+        t = torch.tensor([float(ts[i])])
+        ec = mc.forward([x], t, [ctx], seq_len)[0]
+        eu = mc.forward([x], t, [ctxn], seq_len)[0]
+        np.testing.assert_allclose(ec.numpy(), g["outs"][2 * i], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(eu.numpy(), g["outs"][2 * i + 1], rtol=2e-3, atol=2e-3)
+        x, _ = MR.cfg_euler_step(x, ec, eu, meta["guide"], float(sig[i + 1] - sig[i]))
+    assert [int(s) for _, s in mc.trace] == g["skipped"].tolist()
+    assert g["skipped"].sum() > 0
+    np.testing.assert_allclose(x.numpy(), g["final_latent"], rtol=5e-3, atol=5e-3)
+
+
+def test_calibration_matches_reference_run(golden_run, golden_dir):
+    g, meta, model = golden_run
+    want = json.load(open(os.path.join(golden_dir, "wan_calibration_golden.json")))
+    steps = meta["steps"]
+    mc = MR.MagCacheWan(model, steps * 2, 0.0, 0, 0.2, np.ones(steps * 2), autocast=True)
+    x = torch.from_numpy(g["latent0"]).clone()
+    ctx, ctxn = torch.from_numpy(g["ctx"]), torch.from_numpy(g["ctx_null"])
+    sig, ts = MR.flow_timesteps(steps, meta["shift"])
+    seq_len = meta["F"] * (meta["H"] // 2) * (meta["W"] // 2)
+    for i in range(steps):
+        t = torch.tensor([float(ts[i])])
+        ec = mc.calibrate([x], t, [ctx], seq_len)[0]
+        eu = mc.calibrate([x], t, [ctxn], seq_len)[0]
+        x, _ = MR.cfg_euler_step(x, ec, eu, meta["guide"], float(sig[i + 1] - sig[i]))
+    assert len(mc.norm_ratio) == len(want["norm_ratio"]) == 2 * steps - 2
+    np.testing.assert_allclose(mc.norm_ratio, want["norm_ratio"], atol=2e-4)
+    np.testing.assert_allclose(mc.norm_std, want["norm_std"], atol=2e-4)
+    np.testing.assert_allclose(mc.cos_dis, want["cos_dis"], atol=2e-4)
+
+
+def test_autocast_oracle_close_to_fp32_oracle(golden_run):
+    """states the precision gap of the reference's own execution mode (bf16 autocast) against the
+    all-fp32 ground truth; the HIP engine is held to the same gap in the GPU tests."""
+    g, meta, model = golden_run
+    x = torch.from_numpy(g["latent0"])
+    ctx = torch.from_numpy(g["ctx"])
+    seq_len = meta["F"] * (meta["H"] // 2) * (meta["W"] // 2)
+    t = torch.tensor([float(g["timesteps"][0])])
+    a = model.forward([x], t, [ctx], seq_len, autocast=True)[0]
+    model.set_fp32_attention(True)
+    b = model.forward([x], t, [ctx], seq_len, autocast=False)[0]
+    model.set_fp32_attention(False)
+    rel = (a - b).norm() / b.norm()
+    assert rel < 2e-2, rel
+    assert MR.psnr(a.numpy(), b.numpy(), data_range=float(b.abs().max())) > 35
+
+
+def test_psnr_identity():
+    a = np.random.RandomState(0).rand(4, 4)
+    assert MR.psnr(a, a) == 100.0   # calculate_psnr.py:13-14
