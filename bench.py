@@ -1,0 +1,232 @@
+"""bench.py -- denoising steps/sec of the MagCache hot path on MI355X (the driver's contract).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): Wan2.1-T2V-1.3B, 480p, 81 frames -> latent 16x21x60x104,
+L = 32760 tokens; one "step" = cond forward + uncond forward + CFG + scheduler update, MagCache
+thresh 0.12, K 4, retention 0.2 (the README command, MagCache4Wan2.1/README.md:13), table
+T2V-1.3B resampled to the step count exactly as the reference does (:915-919).  Synthetic latents,
+synthetic contexts, random-init weights of the real architecture (no checkpoint offline).
+`value` = K / wall time of the timed MagCache region (whole job; N>1 = the same video with the token
+sequence sharded over N GPUs, i.e. strong scaling).  A second timed region runs the same K steps
+with the cache off for `speedup_vs_nocache`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GRID = (21, 60, 104)
+SEQ = 21 * 30 * 52
+
+
+def flops_forward(cfg, L, Lc=512):
+    d, f, n = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
+    per_layer = 8 * L * d * d + 4 * L * L * d + 4 * L * d * d + 4 * Lc * d * d + 4 * L * Lc * d + 4 * L * d * f
+    return n * per_layer + 2 * L * 64 * d * 2
+
+
+def timed(fn, sync, barrier):
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = fn()
+    sync()
+    barrier()
+    return time.perf_counter() - t0, out
+
+
+def kernel_rooflines(cfg, device):
+    """Live per-kernel measurements with HIP events on the launch stream (torch's current stream is
+    the stream every mc_* call is issued on)."""
+    import hip_ops as H
+    d, heads, ffn = cfg["dim"], cfg["num_heads"], cfg["ffn_dim"]
+    Lp = (SEQ + 255) // 256 * 256
+    res = {}
+
+    def ev_time(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters * 1e-3
+
+    g = torch.Generator(device=device).manual_seed(1)
+    qkv = torch.randn(Lp, 3 * d, generator=g, device=device).bfloat16()
+    o = torch.empty(Lp, d, dtype=torch.bfloat16, device=device)
+    t = ev_time(lambda: H.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, heads, Lp, SEQ, 1, 128 ** -0.5), 5)
+    fl = 4.0 * SEQ * SEQ * d
+    res["attention"] = dict(bound="mfma", achieved=fl / t / 1e12, peak=2500.0, unit="TFLOP/s",
+                            frac=fl / t / 2.5e15, traffic=None, ms=t * 1e3, shape=f"L={SEQ} heads={heads} hd=128")
+    for name, (N, K, epi) in dict(gemm_qkv=(3 * d, d, 0), gemm_ffn1=(ffn, d, 1), gemm_ffn2=(d, ffn, 2),
+                                  gemm_o=(d, d, 2)).items():
+        A = torch.randn(Lp, K, generator=g, device=device).bfloat16()
+        Wt = (0.02 * torch.randn(N, K, generator=g, device=device)).bfloat16()
+        bias = torch.zeros(N, device=device)
+        Cb = torch.empty(Lp, N, dtype=torch.bfloat16, device=device) if epi < 2 else None
+        X = torch.zeros(Lp, N, device=device) if epi >= 2 else None
+        gate = torch.ones(N, device=device) if epi >= 2 else None
+        t = ev_time(lambda: H.gemm(A, Wt, bias, epi, Cb=Cb, X=X, gate=gate), 5)
+        fl = 2.0 * Lp * N * K
+        res[name] = dict(bound="mfma", achieved=fl / t / 1e12, peak=2500.0, unit="TFLOP/s", frac=fl / t / 2.5e15,
+                         ms=t * 1e3, shape=f"M={Lp} N={N} K={K}")
+        del A, Wt, Cb, X
+    x0 = torch.randn(SEQ, d, generator=g, device=device).bfloat16()
+    r = torch.randn(SEQ, d, generator=g, device=device)
+    out = torch.empty(SEQ, d, device=device)
+    t = ev_time(lambda: H.skip_add(x0, r, out), 20)
+    by = SEQ * d * 10.0
+    res["skip_add"] = dict(bound="hbm", achieved=by / t / 1e9, peak=8000.0, unit="GB/s", frac=by / t / 8e12,
+                           ms=t * 1e3, shape=f"[{SEQ},{d}] bf16+fp32->fp32")
+    t = ev_time(lambda: H.calib_stats(r, out), 20)
+    by = SEQ * d * 8.0
+    res["calib_stats"] = dict(bound="hbm", achieved=by / t / 1e9, peak=8000.0, unit="GB/s", frac=by / t / 8e12,
+                              ms=t * 1e3, shape=f"2x[{SEQ},{d}] fp32")
+    return res
+
+
+def cpu_baseline(cfg, threads):
+    """The oracle (PyTorch CPU restatement, bf16 autocast = the reference's execution mode) timed on
+    this box's host cores on a bounded sample, extrapolated with the FLOP model."""
+    from oracle import wan_dit_ref as W
+    torch.set_num_threads(threads)
+    n_layers, grid = 6, (4, 60, 104)
+    L = grid[0] * 30 * 52
+    c = dict(cfg, num_layers=n_layers)
+    oracle = W.init_synthetic_(W.WanModel(**c), seed=0)
+    g = torch.Generator().manual_seed(42)
+    lat = torch.randn(16, *grid, generator=g)
+    ctx = torch.randn(512, cfg["text_dim"], generator=g)
+    t0 = time.perf_counter()
+    oracle.forward([lat], torch.tensor([500.0]), [ctx], L, autocast=True)
+    dt = time.perf_counter() - t0
+    f_sample, f_full = flops_forward(c, L), flops_forward(cfg, SEQ)
+    t_full = dt * f_full / f_sample
+    return dict(value=1.0 / (2 * t_full), unit="denoising steps/s (no cache)", cores=threads, kind="port",
+                sample=f"one oracle forward, {n_layers} of {cfg['num_layers']} blocks, L={L} of {SEQ} tokens: "
+                       f"{dt:.1f} s = {f_sample / dt / 1e12:.2f} TFLOP/s; extrapolated by the FLOP model "
+                       f"({f_full / 1e12:.0f} TFLOP/forward) to {t_full:.0f} s/forward",
+                seconds_measured=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--magcache_thresh", type=float, default=0.12)
+    ap.add_argument("--magcache_K", type=int, default=4)
+    ap.add_argument("--retention_ratio", type=float, default=0.2)
+    ap.add_argument("--guide_scale", type=float, default=5.0)
+    ap.add_argument("--shift", type=float, default=5.0)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_kernels", action="store_true")
+    ap.add_argument("--no_nocache", action="store_true", help="skip the second (cache off) timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    from magcache_amd import model as M
+    from magcache_amd.engine import WAN_T2V_1_3B, synthetic_weights
+    from magcache_amd.mag_ratios import TABLES
+    from magcache_amd.sampler import sample
+
+    cfg = WAN_T2V_1_3B
+    model = M.WanModelHIP(cfg, GRID, device=device, calibration=False, sp_rank=rank, sp_size=world)
+    model.engine.load_weights(synthetic_weights(cfg, seed=0, device=device))
+    g = torch.Generator(device=device).manual_seed(42)
+    noise = torch.randn(16, *GRID, generator=g, device=device)
+    ctx = torch.randn(512, cfg["text_dim"], generator=g, device=device)
+    ctx_null = torch.randn(512, cfg["text_dim"], generator=g, device=device)
+
+    sync = torch.cuda.synchronize
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+
+    def run(steps):
+        return sample(model, noise, ctx, ctx_null, sampling_steps=steps, shift=args.shift,
+                      guide_scale=args.guide_scale)
+
+    M.disable_magcache(model)
+    if args.warmup > 0:
+        run(args.warmup)
+    # ---- timed region 1: K steps with MagCache
+    M.init_magcache(model, args.steps, args.magcache_thresh, args.magcache_K, args.retention_ratio,
+                    mag_ratios=TABLES["wan2.1_t2v_1.3B"])
+    modes = []
+    fwd = model._run
+    model._run = lambda x, t, c, branch, mode: (modes.append(mode), fwd(x, t, c, branch, mode))[1]
+    t_mc, lat_mc = timed(lambda: run(args.steps), sync, barrier)
+    model._run = fwd
+    skipped = int(sum(1 for m in modes if m == 1))
+    # ---- timed region 2: the same K steps with the cache off
+    t_nc, psnr = None, None
+    if not args.no_nocache:
+        M.disable_magcache(model)
+        t_nc, lat_nc = timed(lambda: run(args.steps), sync, barrier)
+        mse = float(((lat_mc - lat_nc) ** 2).mean())
+        rng = float(lat_nc.abs().max())
+        psnr = 100.0 if mse < 1e-10 else float(20 * np.log10(rng / np.sqrt(mse)))
+    if world > 1:
+        tt = torch.tensor([t_mc, t_nc or 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_mc, t_nc = float(tt[0]), (float(tt[1]) if t_nc is not None else None)
+
+    if rank == 0:
+        fl = flops_forward(cfg, SEQ)
+        ran = 2 * args.steps - skipped
+        line = {
+            "metric": "denoising steps/sec (MagCache on), Wan2.1-T2V-1.3B 480p 81f",
+            "value": args.steps / t_mc, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": t_mc / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Wan2.1-T2V-1.3B 832x480 81 frames: latent 16x21x60x104, 32760 tokens, "
+                                   "30 layers d=1536 12 heads ffn=8960; cond+uncond per step, CFG 5.0, flow-Euler; "
+                                   "synthetic latents/contexts, random-init weights",
+                       "magcache_thresh": args.magcache_thresh, "magcache_K": args.magcache_K,
+                       "retention_ratio": args.retention_ratio, "sampling_steps": args.steps,
+                       "parallelism": "single GPU" if world == 1 else f"sequence-parallel sp{world} (K/V all-gather)"},
+            "forwards_skipped": skipped, "forwards_total": 2 * args.steps,
+            "speedup_bound": (2 * args.steps) / max(ran, 1),
+            "nocache_steps_per_s": (args.steps / t_nc) if t_nc else None,
+            "speedup_vs_nocache": (t_nc / t_mc) if t_nc else None,
+            "psnr_vs_nocache_db": psnr,
+            "model_tflops_per_s_nocache": (2 * args.steps * fl / t_nc / 1e12 / world) if t_nc else None,
+            "model_tflops_per_s_magcache_ran": ran * fl / t_mc / 1e12 / world,
+        }
+        if world == 1 and not args.no_kernels:
+            k = kernel_rooflines(cfg, device)
+            line["roofline"] = {kk: k["attention"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+            line["roofline"]["kernel"] = "attn_fwd_kernel (self-attention, 71% of forward FLOPs)"
+            line["kernels"] = k
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

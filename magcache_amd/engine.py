@@ -178,6 +178,14 @@ class Engine:
     def unpatchify(self, tokens, tok0, n_tok, out):
         check(self.lib.mc_unpatchify(self.h, _ptr(tokens), tok0, n_tok, _ptr(out), _stream()))
 
+    def calib_has_stats(self, branch):
+        has = C.c_int()
+        check(self.lib.mc_calib_ready(self.h, branch, C.byref(has)))
+        return bool(has.value)
+
+    def calib_finalize(self, branch):
+        check(self.lib.mc_calib_finalize(self.h, branch, _stream()))
+
     def calib_stats(self, branch):
         """(norm_ratio, norm_std, cos_dis) of the last CALIB forward of `branch` or None.  Reading them
         is a device->host sync, exactly like the reference's three .item() calls (:167-169)."""

@@ -61,13 +61,14 @@ class WanModelHIP:
     model_type = "t2v"
     patch_size = (1, 2, 2)
 
-    def __init__(self, cfg, latent_grid, device="cuda:0", calibration=True, engine=None):
+    def __init__(self, cfg, latent_grid, device="cuda:0", calibration=True, engine=None, sp_rank=0, sp_size=1):
         self.cfg = dict(cfg)
         for k in ("dim", "ffn_dim", "freq_dim", "text_len", "text_dim", "in_dim", "out_dim", "num_heads",
                   "num_layers"):
             setattr(self, k, cfg[k])
         self.latent_grid = tuple(latent_grid)
-        self.engine = engine or Engine(cfg, latent_grid, device=device, n_branches=2, calibration=calibration)
+        self.engine = engine or Engine(cfg, latent_grid, device=device, n_branches=2, calibration=calibration,
+                                       sp_rank=sp_rank, sp_size=sp_size)
         self.device = self.engine.device
 
     def load_state_dict(self, state_dict):
@@ -86,8 +87,16 @@ class WanModelHIP:
         assert context[0].shape[0] <= self.text_len and context[0].shape[1] == self.text_dim
 
     def _run(self, x, t, context, branch, mode):
-        out = self.engine.forward(x[0].to(self.device), t if not torch.is_tensor(t) else t.to(self.device),
-                                  context[0].to(self.device), branch=branch, mode=mode)
+        lat = x[0].to(self.device)
+        t = t if not torch.is_tensor(t) else t.to(self.device)
+        ctx = context[0].to(self.device)
+        if self.engine.sp_size > 1:
+            if getattr(self, "_sp", None) is None:
+                from .parallel import SequenceParallelForward
+                self._sp = SequenceParallelForward(self.engine)
+            out = self._sp.forward(lat, t, ctx, branch, mode)
+        else:
+            out = self.engine.forward(lat, t, ctx, branch=branch, mode=mode)
         return [out.float()]
 
     def __call__(self, *args, **kwargs):

@@ -1,0 +1,80 @@
+"""Test-side helpers: call the single-op C-ABI entry points (mc_op_*) on torch tensors."""
+import ctypes as C
+
+import torch
+
+from magcache_amd import _lib
+from magcache_amd._lib import check
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def bf16(t):
+    return t.to(torch.bfloat16).contiguous()
+
+
+def gemm(A, W, bias, epi, Cb=None, X=None, gate=None, X0=None, R=None, X0out=None, m_valid=0):
+    lib = _lib.load()
+    M, K = A.shape
+    N = W.shape[0]
+    check(lib.mc_op_gemm_bf16(P(A), A.stride(0), P(W), W.stride(0), P(bias), M, N, K, epi,
+                              P(Cb), Cb.stride(0) if Cb is not None else 0,
+                              P(X), X.stride(0) if X is not None else 0, P(gate),
+                              P(X0), X0.stride(0) if X0 is not None else 0,
+                              P(R), R.stride(0) if R is not None else 0,
+                              P(X0out), X0out.stride(0) if X0out is not None else 0, m_valid, S()))
+
+
+def attention(Q, K, V, O, n_heads, shard_rows, shard_valid, n_shards, scale, k_shard_stride=0, v_shard_stride=0):
+    lib = _lib.load()
+    check(lib.mc_op_attention(P(Q), Q.stride(0), P(K), K.stride(0), k_shard_stride, P(V), V.stride(0),
+                              v_shard_stride, P(O), O.stride(0), Q.shape[0], n_heads, shard_rows, shard_valid,
+                              n_shards, scale, S()))
+
+
+def ln_modulate(x, sc, sh, mode, eps, out_bf16=None, out_f32=None, x0=None):
+    lib = _lib.load()
+    M, D = x.shape
+    check(lib.mc_op_ln_modulate(P(x), x.stride(0), P(x0), x0.stride(0) if x0 is not None else 0, P(sc), P(sh), mode,
+                                eps, P(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0, P(out_f32),
+                                out_f32.stride(0) if out_f32 is not None else 0, M, D, S()))
+
+
+def rmsnorm_rope(x, w, eps, cs, cs_row0=0, D=None):
+    lib = _lib.load()
+    check(lib.mc_op_rmsnorm_rope(P(x), x.stride(0), P(w), eps, P(cs), cs_row0, x.shape[0], D or x.shape[1], S()))
+
+
+def rope_table(F_, Hp, Wp, tok0, n_tok):
+    lib = _lib.load()
+    cs = torch.empty(n_tok, 128, dtype=torch.float32)
+    check(lib.mc_op_rope_table(F_, Hp, Wp, tok0, n_tok, C.c_void_p(cs.data_ptr())))
+    return cs
+
+
+def skip_add(x0, r, out):
+    lib = _lib.load()
+    check(lib.mc_op_skip_add(P(x0), x0.stride(0), P(r), r.stride(0), P(out), out.stride(0), r.shape[0], r.shape[1],
+                             S()))
+
+
+def residual_sub(x, x0, r):
+    lib = _lib.load()
+    check(lib.mc_op_residual_sub(P(x), x.stride(0), P(x0), x0.stride(0), P(r), r.stride(0), x.shape[0], x.shape[1],
+                                 S()))
+
+
+def calib_stats(r, rp, n_blocks=256):
+    lib = _lib.load()
+    partial = torch.empty(4 * n_blocks, dtype=torch.float64, device=r.device)
+    sums = torch.empty(4, dtype=torch.float64, device=r.device)
+    stats = torch.empty(3, dtype=torch.float32, device=r.device)
+    check(lib.mc_op_calib_stats(P(r), r.stride(0), P(rp), rp.stride(0), r.shape[0], r.shape[1], P(partial), n_blocks,
+                                P(sums), P(stats), S()))
+    return stats.cpu(), sums.cpu()

@@ -1,0 +1,186 @@
+"""GPU parity of the whole hot path through the C ABI: one DiT forward vs the oracle, the MagCache
+sampler loop vs the golden run of the reference's own magcache_forward (tests/golden), calibration,
+the monkey-patch shim on the real engine, error behaviour, and the sequence-parallel phase API
+(2 ranks over gloo on one GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from magcache_amd import _lib  # noqa: E402
+from magcache_amd import model as M  # noqa: E402
+from magcache_amd.engine import Engine, MC_MODE_FULL, MC_MODE_SKIP  # noqa: E402
+from magcache_amd.mag_ratios import TABLES  # noqa: E402
+from magcache_amd.sampler import cfg_euler_, flow_timesteps, sample  # noqa: E402
+from oracle import magcache_ref as MR  # noqa: E402
+from oracle import wan_dit_ref as W  # noqa: E402
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "wan_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    oracle = W.init_synthetic_(W.WanModel(**meta["cfg"]), seed=meta["weight_seed"], std=meta["weight_std"])
+    return g, meta, oracle
+
+
+@pytest.fixture(scope="module")
+def hip_model(golden):
+    g, meta, oracle = golden
+    cls = type("WanModelHIPUnderTest", (M.WanModelHIP,), {})
+    m = cls(meta["cfg"], (meta["F"], meta["H"], meta["W"]), device=DEV, calibration=True)
+    m.load_state_dict(oracle.state_dict())
+    return m
+
+
+def test_forward_vs_oracle(golden, hip_model):
+    """Tolerance (floating point): the engine computes like the reference's bf16-autocast mode, so it
+    must be as close to the all-fp32 oracle as that mode is (factor 2 + 1e-3), and within 2e-2
+    relative L2 of the autocast oracle itself."""
+    g, meta, oracle = golden
+    x = torch.from_numpy(g["latent0"])
+    ctx = torch.from_numpy(g["ctx"])
+    L = meta["F"] * (meta["H"] // 2) * (meta["W"] // 2)
+    for tval in (float(g["timesteps"][0]), 37.0):
+        t = torch.tensor([tval])
+        ref_ac = oracle.forward([x], t, [ctx], L, autocast=True)[0]
+        oracle.set_fp32_attention(True)
+        ref_32 = oracle.forward([x], t, [ctx], L, autocast=False)[0]
+        oracle.set_fp32_attention(False)
+        M.disable_magcache(hip_model)
+        got = hip_model([x.to(DEV)], t=torch.tensor([tval], device=DEV), context=[ctx.to(DEV)], seq_len=L)[0]
+        assert got.dtype == torch.float32 and tuple(got.shape) == tuple(ref_32.shape)
+        e_hip, e_ac = rel_l2(got, ref_32), rel_l2(ref_ac, ref_32)
+        assert e_hip < 2 * e_ac + 1e-3, (e_hip, e_ac)
+        assert rel_l2(got, ref_ac) < 2e-2
+        assert MR.psnr(got.cpu().numpy(), ref_32.numpy(), data_range=float(ref_32.abs().max())) > 35.0
+
+
+def test_host_scalar_t_equals_device_t(golden, hip_model):
+    g, meta, _ = golden
+    x, ctx = torch.from_numpy(g["latent0"]).to(DEV), torch.from_numpy(g["ctx"]).to(DEV)
+    L = hip_model.engine.seq_len
+    M.disable_magcache(hip_model)
+    a = hip_model([x], t=torch.tensor([500.0], device=DEV), context=[ctx], seq_len=L)[0]
+    b = hip_model([x], t=500.0, context=[ctx], seq_len=L)[0]
+    c = hip_model([x], t=torch.tensor([500], dtype=torch.int64, device=DEV), context=[ctx.bfloat16()], seq_len=L)[0]
+    assert torch.equal(a, b)
+    assert rel_l2(c, a) < 1e-2      # bf16 context: the same values after the engine's own cast
+
+
+def test_magcache_loop_vs_reference_golden(golden, hip_model):
+    """The sampler loop with MagCache on, against the tensors the reference's magcache_forward
+    produced around the oracle model (oracle/gen_golden.py): identical skip schedule, per-call
+    outputs within 3e-2 relative L2, final latent PSNR > 35 dB."""
+    g, meta, _ = golden
+    steps = meta["steps"]
+    M.init_magcache(hip_model, steps, meta["thresh"], meta["K"], meta["R"], mag_ratios=TABLES[meta["table"]])
+    x = torch.from_numpy(g["latent0"]).to(DEV).clone()
+    ctx, ctxn = torch.from_numpy(g["ctx"]).to(DEV), torch.from_numpy(g["ctx_null"]).to(DEV)
+    sig, ts = flow_timesteps(steps, meta["shift"])
+    assert np.array_equal(ts, g["timesteps"])
+    L = hip_model.engine.seq_len
+    modes = []
+    orig = hip_model.engine.forward
+    hip_model.engine.forward = lambda *a, **k: (modes.append(k["mode"]), orig(*a, **k))[1]
+    try:
+        for i in range(steps):
+            t = torch.tensor([float(ts[i])], device=DEV)
+            outs = [hip_model([x], t=t, context=[c], seq_len=L)[0] for c in (ctx, ctxn)]
+            assert rel_l2(outs[0], g["outs"][2 * i]) < 3e-2, i
+            assert rel_l2(outs[1], g["outs"][2 * i + 1]) < 3e-2, i
+            cfg_euler_(x, outs[0].contiguous(), outs[1].contiguous(), meta["guide"], float(sig[i + 1] - sig[i]))
+    finally:
+        hip_model.engine.forward = orig
+    skipped = [int(m == MC_MODE_SKIP) for m in modes]
+    assert skipped == g["skipped"].tolist()
+    final = x.cpu().numpy()
+    assert MR.psnr(final, g["final_latent"], data_range=float(np.abs(g["final_latent"]).max())) > 35.0
+    assert hip_model.cnt == 0
+    # residual_cache entries are live views of the engine's HBM slots
+    r = hip_model.residual_cache[0]
+    assert r.dtype == torch.float32 and tuple(r.shape) == (L, meta["cfg"]["dim"]) and bool(torch.isfinite(r).all())
+
+
+def test_skip_is_exactly_cached_residual_add(golden, hip_model):
+    """a skipped forward equals head(ori_x + residual_cache[p]): run FULL, then SKIP with the same
+    inputs -> identical output up to fp32 rounding of the re-association"""
+    g, meta, _ = golden
+    x, ctx = torch.from_numpy(g["latent0"]).to(DEV), torch.from_numpy(g["ctx"]).to(DEV)
+    eng = hip_model.engine
+    eng.reset()
+    a = eng.forward(x, 600.0, ctx, branch=1, mode=MC_MODE_FULL).clone()
+    b = eng.forward(x, 600.0, ctx, branch=1, mode=MC_MODE_SKIP).clone()
+    assert rel_l2(b, a) < 1e-5
+    with pytest.raises(_lib.MagCacheHipError) as e:
+        eng.reset()
+        eng.forward(x, 600.0, ctx, branch=0, mode=MC_MODE_SKIP)      # nothing cached yet
+    assert e.value.status == _lib.MC_ESTATE
+
+
+def test_calibration_vs_reference_golden(golden, hip_model, golden_dir, tmp_path, monkeypatch, capsys):
+    g, meta, _ = golden
+    want = json.load(open(os.path.join(golden_dir, "wan_calibration_golden.json")))
+    monkeypatch.chdir(tmp_path)
+    steps = meta["steps"]
+    M.init_magcache_calibration(hip_model, steps)
+    x = torch.from_numpy(g["latent0"]).to(DEV)
+    sample(hip_model, x, torch.from_numpy(g["ctx"]).to(DEV), torch.from_numpy(g["ctx_null"]).to(DEV),
+           sampling_steps=steps, shift=meta["shift"], guide_scale=meta["guide"])
+    assert len(hip_model.norm_ratio) == 2 * steps - 2
+    # tolerance: the statistics are means over 360 tokens of bf16-noisy residuals
+    np.testing.assert_allclose(hip_model.norm_ratio, want["norm_ratio"], atol=1e-2)
+    np.testing.assert_allclose(hip_model.norm_std, want["norm_std"], atol=1e-2)
+    np.testing.assert_allclose(hip_model.cos_dis, want["cos_dis"], atol=1e-2)
+    assert json.load(open(tmp_path / "wan2_1_mag_ratio.json")) == hip_model.norm_ratio
+    M.disable_magcache(hip_model)
+
+
+def test_error_behaviour(golden, hip_model):
+    g, meta, _ = golden
+    x, ctx = torch.from_numpy(g["latent0"]).to(DEV), torch.from_numpy(g["ctx"]).to(DEV)
+    eng = hip_model.engine
+    long_ctx = torch.zeros(meta["cfg"]["text_len"] + 1, meta["cfg"]["text_dim"], device=DEV)
+    with pytest.raises(_lib.MagCacheHipError) as e:
+        eng.forward(x, 1.0, long_ctx)
+    assert e.value.status == _lib.MC_EINVAL
+    with pytest.raises(AssertionError):                       # the shim mirrors the reference's asserts
+        hip_model([x[:, :2]], t=1.0, context=[ctx], seq_len=eng.seq_len)
+    with pytest.raises(AssertionError):
+        hip_model([x], t=1.0, context=[ctx], seq_len=eng.seq_len - 1)
+    e2 = Engine(meta["cfg"], (meta["F"], meta["H"], meta["W"]), device=DEV)
+    with pytest.raises(_lib.MagCacheHipError) as e:
+        e2.forward(x, 1.0, ctx)                               # weights never set
+    assert e.value.status == _lib.MC_ESTATE
+    with pytest.raises(_lib.MagCacheHipError):
+        Engine(dict(meta["cfg"], dim=200), (1, 2, 2), device=DEV)
+
+
+def test_sequence_parallel_two_ranks_one_gpu(tmp_path):
+    """2 processes (gloo) sharing cuda:0 drive the sharded engine through the phase API with the K/V
+    all-gather between pre_attn and post_attn; the result must match the 1-rank engine."""
+    out = tmp_path / "sp.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "tests", "sp_worker.py"),
+           "--backend", "gloo", "--out", str(out)]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res["rel_full"] < 1e-3, res          # same kernels, different tiling of the key loop only
+    assert res["rel_skip"] < 1e-3, res
+    assert res["rel_calib"] < 1e-4, res

@@ -1,0 +1,273 @@
+"""GPU parity: every HIP kernel through the C ABI against a plain PyTorch fp32 reference of the same
+op (floating-point kernels; tolerances stated per test), plus size-independent properties at the
+full Wan2.1-1.3B 480p shape (L = 32760, d = 1536, 12 heads)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import hip_ops as H  # noqa: E402
+from magcache_amd import _lib  # noqa: E402
+from oracle import magcache_ref as MR  # noqa: E402
+from oracle import wan_dit_ref as W  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def rel_l2(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20))
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (512, 1536, 1536), (1000, 384, 4096),
+                                   (77, 8960, 1536), (256, 1536, 8960)])
+def test_gemm_bf16_epilogues(M, N, K):
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    Wt = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)   # asymmetric operands (transposes would show)
+    bias = rnd(N, seed=3)
+    ref = A.float() @ Wt.float().t() + bias
+    # 0: bf16 store            tolerance: one bf16 rounding (2^-8 rel) + fp32 accumulation noise
+    Cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    H.gemm(A, Wt, bias, 0, Cb=Cb)
+    torch.testing.assert_close(Cb.float(), ref, rtol=1e-2, atol=1e-2)
+    assert rel_l2(Cb, ref) < 4e-3
+    # 1: gelu(tanh) on the bf16-rounded pre-activation, like autocast Linear -> GELU
+    H.gemm(A, Wt, bias, 1, Cb=Cb)
+    want = F.gelu(ref.bfloat16().float(), approximate="tanh")
+    torch.testing.assert_close(Cb.float(), want, rtol=2e-2, atol=2e-2)
+    # 5: fp32 store -- tight: only accumulation order differs
+    X = torch.zeros(M, N, device=DEV)
+    H.gemm(A, Wt, bias, 5, X=X)
+    torch.testing.assert_close(X, ref, rtol=1e-4, atol=1e-3 * math.sqrt(K / 64))
+    # 2: x += gate * bf16(acc + bias)
+    x_in = rnd(M, N, seed=4)
+    gate = rnd(N, seed=5)
+    X = x_in.clone()
+    H.gemm(A, Wt, bias, 2, X=X, gate=gate)
+    want = x_in + ref.bfloat16().float() * gate
+    torch.testing.assert_close(X, want, rtol=1e-2, atol=2e-2)
+    X = x_in.clone()
+    H.gemm(A, Wt, bias, 2, X=X, gate=None)
+    torch.testing.assert_close(X, x_in + ref.bfloat16().float(), rtol=1e-2, atol=2e-2)
+    # 3: residual capture R = X_new - X0
+    X = x_in.clone()
+    X0 = rnd(M, N, seed=6, dtype=torch.bfloat16)
+    R = torch.zeros(M, N, device=DEV)
+    H.gemm(A, Wt, bias, 3, X=X, gate=gate, X0=X0, R=R)
+    torch.testing.assert_close(R, X - X0.float(), rtol=0, atol=0)     # exact: one fp32 subtraction
+    torch.testing.assert_close(X, want, rtol=1e-2, atol=2e-2)
+    # 4: embed: rows >= m_valid are zero, x (fp32) holds the bf16-rounded values, x0 the same bits
+    X = torch.full((M, N), 7.0, device=DEV)
+    X0o = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    mv = M - 5
+    H.gemm(A, Wt, bias, 4, X=X, X0out=X0o, m_valid=mv)
+    torch.testing.assert_close(X[:mv], ref[:mv].bfloat16().float(), rtol=1e-2, atol=1e-2)
+    assert torch.equal(X, X0o.float())
+    assert float(X[mv:].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_shapes():
+    A = rnd(64, 48, dtype=torch.bfloat16)
+    Wt = rnd(64, 48, dtype=torch.bfloat16)
+    Cb = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.MagCacheHipError) as e:
+        H.gemm(A, Wt, None, 0, Cb=Cb)           # K % 64 != 0
+    assert e.value.status == _lib.MC_EINVAL
+
+
+def test_gemm_linearity_full_shape():
+    """size-independent property at the real shape (M = 32768 rows): G(a+b) = G(a) + G(b) for
+    bf16-exact inputs, fp32 output"""
+    M, N, K = 32768, 1536, 1536
+    a = (torch.randint(-8, 9, (M, K), device=DEV) / 8.0).bfloat16()
+    b = (torch.randint(-8, 9, (M, K), device=DEV) / 8.0).bfloat16()
+    Wt = (torch.randint(-8, 9, (N, K), device=DEV) / 16.0).bfloat16()
+    outs = []
+    for inp in (a, b, (a.float() + b.float()).bfloat16()):
+        X = torch.empty(M, N, device=DEV)
+        H.gemm(inp, Wt, None, 5, X=X)
+        outs.append(X)
+    # all products/sums are exactly representable -> exact equality
+    assert torch.equal(outs[0] + outs[1], outs[2])
+    idx = torch.randint(0, M, (64,), device=DEV)
+    torch.testing.assert_close(outs[0][idx], a[idx].float() @ Wt.float().t(), rtol=0, atol=0)
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, n_heads, valid_idx):
+    Lq = q.shape[0]
+    qh = q.float().view(Lq, n_heads, 128).transpose(0, 1)
+    kh = k.float()[valid_idx].view(-1, n_heads, 128).transpose(0, 1)
+    vh = v.float()[valid_idx].view(-1, n_heads, 128).transpose(0, 1)
+    s = qh @ kh.transpose(1, 2) / math.sqrt(128)
+    return (torch.softmax(s, -1) @ vh).transpose(0, 1).reshape(Lq, n_heads * 128)
+
+
+@pytest.mark.parametrize("Lq,heads,shard_rows,valid,n_shards", [(256, 1, 64, 64, 1), (512, 2, 320, 300, 1),
+                                                                (256, 3, 128, 77, 3), (768, 2, 512, 512, 1),
+                                                                (256, 2, 256, 193, 2)])
+def test_attention_vs_fp32_reference(Lq, heads, shard_rows, valid, n_shards):
+    d = heads * 128
+    q = rnd(Lq, d, seed=1, dtype=torch.bfloat16)
+    k = rnd(n_shards * shard_rows, d, seed=2, dtype=torch.bfloat16)
+    v = rnd(n_shards * shard_rows, d, seed=3, dtype=torch.bfloat16)
+    # invalid rows hold huge finite garbage: it must be masked, not merely down-weighted
+    rows = torch.arange(n_shards * shard_rows, device=DEV)
+    invalid = (rows % shard_rows) >= valid
+    k[invalid] = 50.0
+    v[invalid] = 1000.0
+    o = torch.zeros(Lq, d, dtype=torch.bfloat16, device=DEV)
+    H.attention(q, k, v, o, heads, shard_rows, valid, n_shards, 1 / math.sqrt(128),
+                k_shard_stride=shard_rows * d, v_shard_stride=shard_rows * d)
+    want = attn_ref(q, k, v, heads, rows[~invalid])
+    # tolerance: P and O are rounded to bf16 (2^-8 relative each), |O| <= max|v| ~ 4
+    torch.testing.assert_close(o.float(), want, rtol=2e-2, atol=2e-2)
+    assert rel_l2(o, want) < 1e-2
+
+
+def test_attention_strided_qkv_and_online_softmax_rescale():
+    """q/k/v interleaved in one [L, 3d] buffer (the engine's layout) and a key whose score dwarfs all
+    earlier tiles, forcing the running-max rescale late in the loop"""
+    L, heads = 512, 2
+    d = heads * 128
+    qkv = rnd(L, 3 * d, seed=5, dtype=torch.bfloat16)
+    qkv[400, d:2 * d] = qkv[7, 0:d] * 6.0      # key 400 aligned with query 7
+    o = torch.zeros(L, d, dtype=torch.bfloat16, device=DEV)
+    H.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, heads, L, L - 3, 1, 1 / math.sqrt(128))
+    want = attn_ref(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], heads, torch.arange(L - 3, device=DEV))
+    torch.testing.assert_close(o.float(), want, rtol=2e-2, atol=2e-2)
+
+
+def test_attention_full_shape_properties():
+    """L = 32760 (padded to 32768), 12 heads: (i) V = 1 -> O = 1 (softmax rows sum to one);
+    (ii) permuting the keys does not change the result"""
+    L, Lp, heads = 32760, 32768, 12
+    d = heads * 128
+    q = rnd(Lp, d, seed=1, dtype=torch.bfloat16)
+    k = rnd(Lp, d, seed=2, dtype=torch.bfloat16)
+    v = torch.ones(Lp, d, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(Lp, d, dtype=torch.bfloat16, device=DEV)
+    H.attention(q, k, v, o, heads, Lp, L, 1, 1 / math.sqrt(128))
+    assert float((o[:L].float() - 1).abs().max()) < 1e-2
+    v = rnd(Lp, d, seed=3, dtype=torch.bfloat16)
+    H.attention(q, k, v, o, heads, Lp, L, 1, 1 / math.sqrt(128))
+    perm = torch.cat([torch.randperm(L, device=DEV), torch.arange(L, Lp, device=DEV)])
+    o2 = torch.zeros_like(o)
+    H.attention(q, k[perm].contiguous(), v[perm].contiguous(), o2, heads, Lp, L, 1, 1 / math.sqrt(128))
+    assert float((o[:L].float() - o2[:L].float()).abs().max()) < 2e-2
+    # spot-check 64 query rows of one head against the fp32 reference
+    idx = torch.randint(0, L, (64,), device=DEV)
+    h = 5
+    s = q[idx, h * 128:(h + 1) * 128].float() @ k[:L, h * 128:(h + 1) * 128].float().t() / math.sqrt(128)
+    want = torch.softmax(s, -1) @ v[:L, h * 128:(h + 1) * 128].float()
+    torch.testing.assert_close(o[idx, h * 128:(h + 1) * 128].float(), want, rtol=2e-2, atol=2e-2)
+
+
+def test_attention_rejects_bad_shapes():
+    q = rnd(100, 128, dtype=torch.bfloat16)
+    o = torch.zeros_like(q)
+    with pytest.raises(_lib.MagCacheHipError) as e:
+        H.attention(q, q, q, o, 1, 64, 64, 1, 0.1)   # Lq not a multiple of 256
+    assert e.value.status == _lib.MC_EINVAL
+
+
+# ----------------------------------------------------------------------------- token-wise ops
+@pytest.mark.parametrize("D", [256, 1536, 5120])
+def test_ln_modulate(D):
+    M = 333
+    x = rnd(M, D, seed=1, scale=3.0) + 0.5
+    sc, sh = rnd(D, seed=2, scale=0.3), rnd(D, seed=3)
+    n = F.layer_norm(x, (D,), eps=1e-6)
+    out = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    H.ln_modulate(x, sc, sh, 0, 1e-6, out_bf16=out)
+    torch.testing.assert_close(out.float(), (n * (1 + sc) + sh), rtol=1e-2, atol=1e-2)
+    outf = torch.zeros(M, D, device=DEV)
+    H.ln_modulate(x, sc, sh, 0, 1e-6, out_f32=outf)
+    torch.testing.assert_close(outf, n * (1 + sc) + sh, rtol=1e-4, atol=1e-4)   # fp32 path: tight
+    H.ln_modulate(x, sc, sh, 1, 1e-6, out_f32=outf)
+    torch.testing.assert_close(outf, n * sc + sh, rtol=1e-4, atol=1e-4)         # affine LayerNorm (norm3)
+    # fused skip: row = ori_x (bf16) + residual (fp32)
+    x0 = rnd(M, D, seed=4, dtype=torch.bfloat16)
+    H.ln_modulate(x, sc, sh, 0, 1e-6, out_f32=outf, x0=x0)
+    torch.testing.assert_close(outf, F.layer_norm(x + x0.float(), (D,), eps=1e-6) * (1 + sc) + sh, rtol=1e-4,
+                               atol=1e-4)
+
+
+def test_rmsnorm_rope_matches_upstream_formulas():
+    Fg, Hp, Wp, heads = 3, 5, 7, 2
+    L, D = Fg * Hp * Wp, heads * 128
+    x = rnd(L, D, seed=1, scale=2.0, dtype=torch.bfloat16)
+    w = 1 + rnd(D, seed=2, scale=0.1)
+    norm = W.WanRMSNorm(D, eps=1e-6)
+    norm.weight.data = w.cpu()
+    d = 128
+    freqs = torch.cat([W.rope_params(1024, d - 4 * (d // 6)), W.rope_params(1024, 2 * (d // 6)),
+                       W.rope_params(1024, 2 * (d // 6))], dim=1)
+    y = norm(x.cpu()).view(1, L, heads, d)
+    want = W.rope_apply(y, torch.tensor([[Fg, Hp, Wp]]), freqs).view(L, D)
+    cs = H.rope_table(Fg, Hp, Wp, 0, L).to(DEV)
+    got = x.clone()
+    H.rmsnorm_rope(got, w, 1e-6, cs)
+    torch.testing.assert_close(got.float().cpu(), want.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    # without rope, and on a strided view (k inside a [L, 2D] buffer)
+    buf = torch.zeros(L, 2 * D, dtype=torch.bfloat16, device=DEV)
+    buf[:, :D] = x
+    H.rmsnorm_rope(buf, w, 1e-6, None, D=D)
+    torch.testing.assert_close(buf[:, :D].float().cpu(), norm(x.cpu()).bfloat16().float(), rtol=1e-2, atol=1e-2)
+    assert float(buf[:, D:].abs().max()) == 0.0
+    # sequence-parallel table offset: rows of the second half use global token positions
+    half = L // 2 + 1
+    cs2 = H.rope_table(Fg, Hp, Wp, half, L - half).to(DEV)
+    got2 = x[half:].clone()
+    H.rmsnorm_rope(got2, w, 1e-6, cs2)
+    assert torch.equal(got2, got[half:])
+
+
+# ----------------------------------------------------------------------------- MagCache ops
+def test_skip_add_and_residual_sub_small():
+    M, D = 77, 256
+    x0 = rnd(M, D, seed=1, dtype=torch.bfloat16)
+    r = rnd(M, D, seed=2)
+    out = torch.zeros(M, D, device=DEV)
+    H.skip_add(x0, r, out)
+    assert torch.equal(out, x0.float() + r)           # one fp32 add per element: exact
+    r2 = torch.zeros(M, D, device=DEV)
+    H.residual_sub(out, x0, r2)
+    assert torch.equal(r2, out - x0.float())
+
+
+def test_skip_add_residual_roundtrip_full_shape():
+    """Wan2.1-1.3B 480p slab [32760, 1536]: residual_sub(skip_add(x0, r), x0) == r up to one fp32
+    rounding of the sum, and the checksum of the output equals the sum of input checksums"""
+    M, D = 32760, 1536
+    x0 = rnd(M, D, seed=1, dtype=torch.bfloat16)
+    r = rnd(M, D, seed=2, scale=0.1)
+    out = torch.empty(M, D, device=DEV)
+    H.skip_add(x0, r, out)
+    back = torch.empty(M, D, device=DEV)
+    H.residual_sub(out, x0, back)
+    assert float((back - r).abs().max()) <= 2.0 ** -22 * float(out.abs().max())
+    assert abs(float(out.double().sum()) - float(x0.double().sum() + r.double().sum())) < 1e-2
+
+
+def test_calib_stats_matches_torch_ops():
+    M, D = 4097, 1536
+    rp = rnd(M, D, seed=1)
+    r = rp * (1.0 + 0.05 * rnd(M, 1, seed=2)) + 0.1 * rnd(M, D, seed=3)
+    stats, sums = H.calib_stats(r, rp)
+    want = MR.calibration_stats(r.cpu(), rp.cpu())     # the reference's torch expressions (:167-169)
+    assert abs(float(stats[0]) - want[0]) < 2e-6
+    assert abs(float(stats[1]) - want[1]) < 2e-6
+    assert abs(float(stats[2]) - want[2]) < 2e-6
+    assert float(sums[3]) == M
+    # idempotence / edge: identical slabs -> ratio 1, std 0, cos distance 0
+    stats, _ = H.calib_stats(rp, rp)
+    assert abs(float(stats[0]) - 1) < 1e-6 and float(stats[1]) < 1e-6 and abs(float(stats[2])) < 1e-6
