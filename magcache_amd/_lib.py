@@ -82,6 +82,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: the HIP engine is not built (python -m magcache_amd.build). "
                           "magcache_amd has no CPU fallback by design.")
+    # PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime of this process BEFORE our
+    # library is mapped, otherwise libmagcache_hip.so binds /opt/rocm's copy and the two runtimes
+    # do not share devices, streams or allocations ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
