@@ -35,6 +35,7 @@ _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double,
 SIGNATURES = {
     "mc_last_error": (C.c_char_p, []),
     "mc_version": (C.c_char_p, []),
+    "mc_set_option": (_i, [C.c_char_p, _i]),
     "mc_create": (_i, [C.POINTER(McConfig), C.POINTER(_vp)]),
     "mc_destroy": (None, [_vp]),
     "mc_workspace_bytes": (_sz, [_vp]),

@@ -10,7 +10,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagcache_hip.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "elementwise.hip", "magcache_ops.hip", "engine.cpp", "rule.cpp"]
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_big.hip", "attention.hip", "attention_v2.hip", "elementwise.hip",
+           "magcache_ops.hip", "engine.cpp", "rule.cpp"]
+# attention_v2's hand-interleaved VALU stream must stay scalar: the SLP vectoriser packs the row-sum
+# adds into v_pk_add_f32 and moves them out of the MFMA shadow
+EXTRA_FLAGS = {"attention_v2.hip": ["-fno-slp-vectorize"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -23,7 +27,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "ops.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "ops.h", "gemm_epilogue.h")]
     headers.append(os.path.join(HERE, "..", "include", "magcache_hip.h"))
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -33,7 +37,8 @@ def build(force=False, verbose=False):
         op = os.path.join(objdir, src + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + headers):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + \
+                  ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p, int nqb,
 
 }  // namespace
 
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream) {
   if (p.Lq_pad <= 0 || (p.Lq_pad % QB) != 0 || (p.shard_rows % KT) != 0 || p.shard_valid <= 0 ||
       p.shard_valid > p.shard_rows || p.n_shards <= 0 || p.n_heads <= 0)
     return hipErrorInvalidValue;
@@ -223,6 +223,13 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(nqb * p.n_heads), dim3(512), 2 * STAGE, stream, p, nqb,
                      tiles_per_shard);
   return hipGetLastError();
+}
+
+// mc_set_option("attn_kernel", v): 0 default, 1 = this kernel, 2 = attention_v2.hip
+int g_attn_kernel = 0;
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+  return g_attn_kernel == 1 ? launch_attention_v1(p, stream) : launch_attention_v2(p, stream);
 }
 
 }  // namespace mc

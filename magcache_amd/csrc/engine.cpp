@@ -168,7 +168,7 @@ mc::GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, const fl
 extern "C" {
 
 const char* mc_last_error(void) { return g_err; }
-const char* mc_version(void) { return "magcache_hip 0.1 (gfx950)"; }
+const char* mc_version(void) { return "magcache_hip 0.2 (gfx950)"; }
 
 mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (!cfg || !out) return fail(MC_EINVAL, "null argument");
@@ -741,6 +741,21 @@ mc_status mc_op_cfg_euler(const float* cond, const float* uncond, float guide, f
 
 mc_status mc_op_cast_bf16(const float* src, void* dst, size_t n, mc_stream s) {
   HIP_TRY(mc::launch_cast_bf16(src, (bf16_t*)dst, n, (hipStream_t)s));
+  return MC_OK;
+}
+
+mc_status mc_set_option(const char* key, int value) {
+  if (!key) return fail(MC_EINVAL, "null key");
+  const std::string k(key);
+  if (k == "gemm_kernel") {
+    if (value < 0 || value > 2) return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128) or 2 (256x256)");
+    mc::g_gemm_kernel = value;
+  } else if (k == "attn_kernel") {
+    if (value < 0 || value > 2) return fail(MC_EINVAL, "attn_kernel must be 0 (default), 1 (8-wave) or 2 (4-wave pipelined)");
+    mc::g_attn_kernel = value;
+  } else {
+    return fail(MC_EINVAL, "unknown option '%s'", key);
+  }
   return MC_OK;
 }
 

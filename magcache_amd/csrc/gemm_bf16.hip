@@ -19,6 +19,7 @@
 //    same involution to the read address.
 //  * 1-D grid, remapped so each XCD (private 4 MiB L2) walks a contiguous group of tiles.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "ops.h"
 
 namespace mc {
@@ -149,47 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmParams p, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i) val[i] = acc[ni][mi][4 * g + i] + b[i];
 
-        if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
-          if constexpr (EPI == EPI_GELU_BF16) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) val[i] = gelu_tanh(bf16_round(val[i]));
-          }
-          u32x2 o = {pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
-          *(u32x2*)(p.Cb + (size_t)m * p.ldc + n) = o;
-        } else if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
-          f32x4 gt = {1.f, 1.f, 1.f, 1.f};
-          if (p.gate) gt = *(const f32x4*)(p.gate + n);
-          float* xp = p.X + (size_t)m * p.ldx + n;
-          f32x4 xv = *(const f32x4*)xp;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) xv[i] = xv[i] + bf16_round(val[i]) * gt[i];
-          *(f32x4*)xp = xv;
-          if constexpr (EPI == EPI_RESID_CAPTURE) {
-            u32x2 x0 = *(const u32x2*)(p.X0 + (size_t)m * p.ldx0 + n);
-            f32x4 r;
-            r[0] = xv[0] - __uint_as_float(x0[0] << 16);
-            r[1] = xv[1] - __uint_as_float(x0[0] & 0xffff0000u);
-            r[2] = xv[2] - __uint_as_float(x0[1] << 16);
-            r[3] = xv[3] - __uint_as_float(x0[1] & 0xffff0000u);
-            *(f32x4*)(p.R + (size_t)m * p.ldr + n) = r;
-          }
-        } else if constexpr (EPI == EPI_EMBED) {
-          const bool valid = m < p.m_valid;
-          u32x2 o = {0u, 0u};
-          f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-          if (valid) {
-            o[0] = pack_bf16x2(val[0], val[1]);
-            o[1] = pack_bf16x2(val[2], val[3]);
-            xv[0] = __uint_as_float(o[0] << 16);
-            xv[1] = __uint_as_float(o[0] & 0xffff0000u);
-            xv[2] = __uint_as_float(o[1] << 16);
-            xv[3] = __uint_as_float(o[1] & 0xffff0000u);
-          }
-          *(f32x4*)(p.X + (size_t)m * p.ldx + n) = xv;
-          *(u32x2*)(p.X0out + (size_t)m * p.ldx0out + n) = o;
-        } else {  // EPI_F32
-          *(f32x4*)(p.X + (size_t)m * p.ldx + n) = val;
-        }
+        gemm_epilogue_quad<EPI>(p, m, n, val);
       }
     }
   }
@@ -212,7 +173,7 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.N % 4) != 0) return hipErrorInvalidValue;
   if ((p.lda % 8) != 0 || (p.ldw % 8) != 0) return hipErrorInvalidValue;
   switch (epi) {
@@ -224,6 +185,22 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
     case EPI_F32: return launch_t<EPI_F32>(p, stream);
     default: return hipErrorInvalidValue;
   }
+}
+
+// Kernel choice.  g_gemm_kernel: 0 = by shape, 1 = always the 128x128 kernel, 2 = the 256x256
+// kernel wherever it is supported (mc_set_option("gemm_kernel", v); used by the A/B benchmarks).
+// By shape: the 256^2 kernel runs one workgroup per CU and its epilogue is not overlapped with
+// another tile's main loop, so it is used where the main loop dominates: K >= 1024 and at least
+// one full wave of 256 tiles.
+int g_gemm_kernel = 0;
+
+hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+  bool big = false;
+  if (g_gemm_kernel != 1 && epi != EPI_EMBED && gemm_bf16_big_supported(p)) {
+    const long tiles = (long)(p.M / 256) * (p.N / 256);
+    big = (g_gemm_kernel == 2) || (p.K >= 1024 && tiles >= 256);
+  }
+  return big ? launch_gemm_bf16_big(p, epi, stream) : launch_gemm_bf16_small(p, epi, stream);
 }
 
 }  // namespace mc

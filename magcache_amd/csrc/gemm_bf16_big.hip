@@ -1,0 +1,287 @@
+// 256x256x64 bf16 MFMA GEMM for gfx950 with a counted-vmcnt LDS-DMA pipeline:
+//   C[M,N] = A[M,K] * W[N,K]^T  (+ the fused epilogues of gemm_epilogue.h),  M % 256 == N % 256 == 0.
+//
+// This is the kernel behind the large Linears of the Wan DiT block (QKV, cross-Q, FFN-1, FFN-2 at
+// M = 32768 tokens; reference call site MagCache4Wan2.1/magcache_generate.py:297-298, the Linear
+// layers themselves are upstream wan/modules/model.py).  The 128x128 kernel in gemm_bf16.hip drains
+// its LDS-DMA queue (vmcnt(0)) before every barrier; this one never does inside the main loop.
+//
+// Geometry
+//   * workgroup = 8 waves (2 along M x 4 along N), one 256x256 output tile, 1 workgroup per CU
+//     (128 KiB LDS); wave tile 128(M) x 64(N) = 2x2x2 MFMA 32x32x16 blocks = 128 fp32 accumulators.
+//   * MFMA issued "swapped" (operand A = weight rows, B = activation rows) like the 128^2 kernel, so
+//     a lane owns 4 consecutive n of one m and the epilogues are 8/16-byte vector accesses.
+//   * a K tile (64 k) of each operand is split into two 16 KiB "halves" by WHEN a wave needs them:
+//        Am0 / Am1 : for each wave row wr, rows wr*128 + [0,64) / [64,128) of the A tile
+//        Wn0 / Wn1 : for each wave col wc, rows wc*64  + [0,32) / [32,64)  of the W tile
+//     LDS = 2 stages x 4 halves x 16 KiB.  Each half is 16 pieces of 1 KiB (8 rows x 128 B); a wave
+//     moves 2 pieces per half with global_load_lds_dwordx4 (HBM/L2 -> LDS, no VGPR round trip).
+//   * LDS rows are 128 B; the image is XOR-swizzled, chunk' = chunk ^ ((row >> 1) & 7), applied to
+//     the SOURCE address (LDS-DMA writes lane-linear) and to the ds_read_b128 address.
+//
+// Pipeline (one "interval" = the code between two barriers; 4 intervals per K tile kt)
+//     interval   MFMA block (8 MFMAs)     ds_read for later      LDS-DMA issued
+//       q0       (m0,n0): Am0 x Wn0       Wn1(kt)                Wn0(kt+2)
+//       q1       (m0,n1): Am0 x Wn1       Am1(kt)                Am0(kt+2)
+//       q2       (m1,n1): Am1 x Wn1       Wn0(kt+1)              Wn1(kt+2)
+//       q3       (m1,n0): Am1 x Wn0       Am0(kt+1)              Am1(kt+2)
+//   - fragments are read one interval before the MFMAs that use them (register double buffering),
+//     so ds_read latency hides behind the wave's own MFMAs;
+//   - every half is re-filled exactly two intervals after its last ds_read (WAR safe by two
+//     barriers) and is needed six intervals after it was issued; each interval ends with
+//     s_waitcnt vmcnt(10): of the 12 DMA instructions (6 halves) a wave has in flight only the
+//     oldest half must have landed.  The data is read one interval AFTER the wait + barrier that
+//     retires it (every wave waits for its own pieces, the barrier publishes them).
+//   - the last two K tiles use exact smaller counts (8,6,4,2 / 0).
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "ops.h"
+
+namespace mc {
+
+namespace {
+
+constexpr int TB = 256;                // tile edge (M and N)
+constexpr int BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB
+constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // Am0 | Am1 | Wn0 | Wn1
+constexpr int OFF_AM0 = 0, OFF_AM1 = HALF_BYTES, OFF_WN0 = 2 * HALF_BYTES, OFF_WN1 = 3 * HALF_BYTES;
+constexpr int GROUP_M = 8;
+
+// end-of-interval wait: at most n LDS-DMA instructions of this wave still in flight, and every
+// ds_read older than the r issued in this interval complete (their LDS region is re-filled two
+// barriers later; the count makes that formally safe, the reads are long done in practice)
+#define MC_WAIT(n, r) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(" #r ")" ::: "memory")
+// interval boundary: nothing (MFMAs included -- they are register-only and would otherwise drift
+// across the asm statements) is scheduled across it
+#define MC_BARRIER()                          \
+  do {                                        \
+    asm volatile("s_barrier" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
+struct Frag4 {  // one 32-row block x 64 k = 4 MFMA operands
+  bf16x8 v[4];
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int tilesM, int tilesN) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int wr = wv >> 2, wc = wv & 3;
+
+  // ---- tile mapping: XCD-contiguous, grouped along M so neighbouring tiles share W panels in L2
+  int v = xcd_remap(blockIdx.x, tilesM * tilesN);
+  const int per_group = GROUP_M * tilesN;
+  const int grp = v / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tilesM - first_m, GROUP_M);
+  const int in_grp = v - grp * per_group;
+  const int tm = first_m + in_grp % gsz;
+  const int tn = in_grp / gsz;
+  const int m0 = tm * TB, n0 = tn * TB;
+
+  // ---- LDS-DMA sources.  Piece g (0..15) of a half = image rows 8g..8g+7; a wave owns pieces
+  // 2wv, 2wv+1; lane -> (image row = 8g + lane/8, slot = lane%8), source chunk = slot ^ ((row>>1)&7).
+  // image row r of Am<h>: tile row (r>>6)*128 + h*64 + (r&63);  of Wn<h>: (r>>5)*64 + h*32 + (r&31)
+  uint32_t srcA[2][2], srcW[2][2];  // [half][piece] BYTE offsets from p.A / p.W (without k)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wv * 2 + j) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+      const int ra = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      const int rw = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+      srcA[h][j] = ((uint32_t)ra * (uint32_t)p.lda + chunk * 8) * 2u;
+      srcW[h][j] = ((uint32_t)rw * (uint32_t)p.ldw + chunk * 8) * 2u;
+    }
+  }
+  // LDS byte address (M0 value) of this wave's two pieces inside half 0 of stage 0
+  const uint32_t dma_lds = (uint32_t)(uintptr_t)MC_LDS_PTR(smem) + wv * 2048;
+
+  // ---- fragment read offsets inside a half: image row = blk*32 + l31 (+64 for wave row 1 of an
+  // A half / + wc*32 for W), 16-B chunk (2*ks + half) ^ ((row>>1)&7); (row>>1)&7 == (lane>>1)&7
+  const int sw = (lane >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) fo[ks] = l31 * 128 + ((((2 * ks + half) ^ sw)) << 4);
+  const int a_base = wr * (64 * 128);  // + ms*32*128
+  const int w_base = wc * (32 * 128);
+
+  f32x16 acc[2][2][2];  // [m half][ms][n half]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+
+  const int nk = p.K / BK;
+
+  // LDS-DMA issue in inline asm: hipcc's waitcnt pass makes every ds_read that follows a
+  // __builtin_amdgcn_global_load_lds wait for it (vmcnt(0) in the loop); an asm DMA is invisible to
+  // that pass and ordered only by the counted waits below.  saddr form: 64-bit uniform base in
+  // SGPRs + one 32-bit byte offset per lane.  M0 = LDS byte address of the piece (wave-uniform);
+  // s_nop covers the SALU-write-M0 -> LDS-DMA hazard; M0 is restored for the compiler.
+  auto dma2 = [&](const bf16_t* base, uint32_t off0, uint32_t off1, uint32_t lds) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(off0), "v"(off1), "s"(lds), "s"(lds + 1024u), "s"(base)
+        : "memory");
+  };
+  auto dma_a = [&](int kt, int st, int h) {  // issue A half h of K tile kt into stage st (= kt & 1)
+    dma2(p.A + (size_t)kt * BK, srcA[h][0], srcA[h][1], dma_lds + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0));
+  };
+  auto dma_w = [&](int kt, int st, int h) {
+    dma2(p.W + (size_t)kt * BK, srcW[h][0], srcW[h][1], dma_lds + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0));
+  };
+  auto read_a = [&](int st, int h, Frag4 (&f)[2]) {  // both 32-row blocks of this wave's A half h
+    const char* src = smem + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0) + a_base;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) f[ms].v[ks] = *(const bf16x8*)(src + ms * (32 * 128) + fo[ks]);
+  };
+  auto read_w = [&](int st, int h, Frag4& f) {
+    const char* src = smem + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0) + w_base;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f.v[ks] = *(const bf16x8*)(src + fo[ks]);
+  };
+  auto mma = [&](const Frag4& w, const Frag4 (&a)[2], f32x16 (&c0), f32x16 (&c1)) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[ks], a[0].v[ks], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[ks], a[1].v[ks], c1, 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: K tiles 0 and 1 in the steady-state issue order; Wn0(0), Am0(0), Wn1(0) landed
+  dma_w(0, 0, 0); dma_a(0, 0, 0); dma_w(0, 0, 1); dma_a(0, 0, 1);
+  dma_w(1, 1, 0); dma_a(1, 1, 0); dma_w(1, 1, 1); dma_a(1, 1, 1);
+  MC_WAIT(10, 0);
+  MC_BARRIER();
+  // A0/A1: this wave's m0/m1 halves; W0/W1: n0/n1 of the current tile, W2: n0 of the next (W0 is
+  // still live when it is read, so W0/W2 ping-pong by renaming; A0 is dead by then and is reused)
+  Frag4 A0[2], A1[2], W0, W1, W2;
+  read_w(0, 0, W0);
+  read_a(0, 0, A0);
+
+  // TAIL 0: steady state (tile kt+2 exists); 1: kt == nk-2; 2: kt == nk-1.  ST = kt & 1, a literal.
+  // Wait counts: at the end of an interval the half that is read in the NEXT interval must have
+  // landed.  Steady state: 6 halves (12 DMAs) issued since, the oldest must be done -> vmcnt(10).
+  // Tile nk-2 issues nothing: 4,3,2,1 halves may stay in flight -> 8,6,4,2; tile nk-1: 0 once.
+#define MC_TILE(TAIL, kt, ST, W0, W2)                                        \
+  {                                                                           \
+    /* q0 */                                                                  \
+    if (TAIL == 0) dma_w((kt) + 2, ST, 0);                                    \
+    read_w(ST, 1, W1);                                                        \
+    mma(W0, A0, acc[0][0][0], acc[0][1][0]);                                  \
+    if (TAIL == 0) MC_WAIT(10, 4); else if (TAIL == 1) MC_WAIT(8, 4); else MC_WAIT(0, 4); \
+    MC_BARRIER();                                                             \
+    /* q1 */                                                                  \
+    if (TAIL == 0) dma_a((kt) + 2, ST, 0);                                    \
+    read_a(ST, 1, A1);                                                        \
+    mma(W1, A0, acc[0][0][1], acc[0][1][1]);                                  \
+    if (TAIL == 0) MC_WAIT(10, 8); else if (TAIL == 1) MC_WAIT(6, 8);           \
+    MC_BARRIER();                                                             \
+    /* q2 */                                                                  \
+    if (TAIL == 0) dma_w((kt) + 2, ST, 1);                                    \
+    if (TAIL != 2) read_w(1 - ST, 0, W2);                                     \
+    mma(W1, A1, acc[1][0][1], acc[1][1][1]);                                  \
+    if (TAIL == 0) MC_WAIT(10, 4); else if (TAIL == 1) MC_WAIT(4, 4);           \
+    MC_BARRIER();                                                             \
+    /* q3 */                                                                  \
+    if (TAIL == 0) dma_a((kt) + 2, ST, 1);                                    \
+    if (TAIL != 2) read_a(1 - ST, 0, A0);                                     \
+    mma(W0, A1, acc[1][0][0], acc[1][1][0]);                                  \
+    if (TAIL == 0) MC_WAIT(10, 8); else if (TAIL == 1) MC_WAIT(2, 8);           \
+    MC_BARRIER();                                                             \
+  }
+
+  // nk is even (checked by the launcher): steady pairs, then the two tail tiles
+  int kt = 0;
+  for (; kt < nk - 2; kt += 2) {
+    MC_TILE(0, kt, 0, W0, W2);
+    MC_TILE(0, kt + 1, 1, W2, W0);
+  }
+  MC_TILE(1, kt, 0, W0, W2);
+  MC_TILE(2, kt + 1, 1, W2, W0);
+#undef MC_TILE
+
+  // ---- epilogue.  acc[mh][ms][nh][r] = C[m][n], m = m0 + wr*128 + mh*64 + ms*32 + l31,
+  //      n = n0 + wc*64 + nh*32 + (r&3) + 8*(r>>2) + 4*half  -> 4 consecutive n per (r>>2)
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      const int m = m0 + wr * 128 + mh * 64 + ms * 32 + l31;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wc * 64 + nh * 32 + 8 * g + 4 * half;
+          f32x4 val;
+          f32x4 b = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) val[i] = acc[mh][ms][nh][4 * g + i] + b[i];
+          gemm_epilogue_quad<EPI>(p, m, n, val);
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
+  const int tilesM = p.M / TB, tilesN = p.N / TB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI>), dim3(tilesM * tilesN), dim3(512), 2 * STAGE_BYTES, stream, p,
+                     tilesM, tilesN);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm_bf16_big_supported(const GemmParams& p) {
+  // 32-bit byte offsets for the DMA sources; 256-multiples; an even number (>= 4) of K tiles
+  return p.M > 0 && p.N > 0 && (p.M % TB) == 0 && (p.N % TB) == 0 && (p.K % (2 * BK)) == 0 && p.K >= 4 * BK &&
+         (p.lda % 8) == 0 && (p.ldw % 8) == 0 && (size_t)p.M * (size_t)p.lda < (1ull << 31) &&
+         (size_t)p.N * (size_t)p.ldw < (1ull << 31);
+}
+
+hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream) {
+  if (!gemm_bf16_big_supported(p)) return hipErrorInvalidValue;
+  switch (epi) {
+    case EPI_BF16: return launch_big_t<EPI_BF16>(p, stream);
+    case EPI_GELU_BF16: return launch_big_t<EPI_GELU_BF16>(p, stream);
+    case EPI_RESID_GATE: return launch_big_t<EPI_RESID_GATE>(p, stream);
+    case EPI_RESID_CAPTURE: return launch_big_t<EPI_RESID_CAPTURE>(p, stream);
+    case EPI_F32: return launch_big_t<EPI_F32>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mc

@@ -1,0 +1,72 @@
+// Fused GEMM epilogues shared by the 128x128 and the 256x256 bf16 MFMA kernels.
+//
+// Both kernels issue the MFMA "swapped" (operand A = weight rows, operand B = activation rows), so
+// a lane owns 4 consecutive output columns n..n+3 of one row m per accumulator quad: every
+// epilogue is a 16-byte fp32 / 8-byte bf16 vector access.  Rounding points mimic torch autocast:
+// a Linear's output is rounded to bf16 before anything else touches it (GELU, gate, residual add).
+#pragma once
+#include "common.h"
+#include "ops.h"
+
+namespace mc {
+
+// GELU(approximate='tanh'):  0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = k0 (x + k1 x^3).
+// Written with exp2 + rcp (2 transcendentals) instead of tanhf (~30 VALU ops): the FFN-1 epilogue
+// evaluates it 293 M times per layer at 480p.  Relative error of v_exp_f32 / v_rcp_f32 is ~1 ulp,
+// far below the bf16 rounding that follows.
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x);
+  // sigmoid(2u) = 1 / (1 + 2^(-2u log2 e)); large |u| saturates cleanly (exp2 -> 0 or inf)
+  const float e = __builtin_amdgcn_exp2f(-2.885390081777927f * u);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// val = acc + bias for columns n..n+3 of row m.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_quad(const GemmParams& p, int m, int n, f32x4 val) {
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+    if constexpr (EPI == EPI_GELU_BF16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) val[i] = gelu_tanh_fast(bf16_round(val[i]));
+    }
+    u32x2 o = {pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
+    *(u32x2*)(p.Cb + (size_t)m * p.ldc + n) = o;
+  } else if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
+    f32x4 gt = {1.f, 1.f, 1.f, 1.f};
+    if (p.gate) gt = *(const f32x4*)(p.gate + n);
+    float* xp = p.X + (size_t)m * p.ldx + n;
+    f32x4 xv = *(const f32x4*)xp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xv[i] = xv[i] + bf16_round(val[i]) * gt[i];
+    *(f32x4*)xp = xv;
+    if constexpr (EPI == EPI_RESID_CAPTURE) {
+      // MagCache residual capture (reference magcache_generate.py:299): R = x_out - ori_x
+      u32x2 x0 = *(const u32x2*)(p.X0 + (size_t)m * p.ldx0 + n);
+      f32x4 r;
+      r[0] = xv[0] - __uint_as_float(x0[0] << 16);
+      r[1] = xv[1] - __uint_as_float(x0[0] & 0xffff0000u);
+      r[2] = xv[2] - __uint_as_float(x0[1] << 16);
+      r[3] = xv[3] - __uint_as_float(x0[1] & 0xffff0000u);
+      *(f32x4*)(p.R + (size_t)m * p.ldr + n) = r;
+    }
+  } else if constexpr (EPI == EPI_EMBED) {
+    const bool valid = m < p.m_valid;
+    u32x2 o = {0u, 0u};
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      o[0] = pack_bf16x2(val[0], val[1]);
+      o[1] = pack_bf16x2(val[2], val[3]);
+      xv[0] = __uint_as_float(o[0] << 16);
+      xv[1] = __uint_as_float(o[0] & 0xffff0000u);
+      xv[2] = __uint_as_float(o[1] << 16);
+      xv[3] = __uint_as_float(o[1] & 0xffff0000u);
+    }
+    *(f32x4*)(p.X + (size_t)m * p.ldx + n) = xv;
+    *(u32x2*)(p.X0out + (size_t)m * p.ldx0out + n) = o;
+  } else {  // EPI_F32
+    *(f32x4*)(p.X + (size_t)m * p.ldx + n) = val;
+  }
+}
+
+}  // namespace mc

@@ -33,7 +33,11 @@ struct GemmParams {
   int m_valid;  // EPI_EMBED: rows >= m_valid are written as zeros (sequence padding)
 };
 
-hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);
+hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
+hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stream);  // 128x128 tiles
+hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);    // 256x256 tiles
+bool gemm_bf16_big_supported(const GemmParams& p);
+extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported
 
 // ---------------------------------------------------------------- attention (attention.hip)
 struct AttnParams {
@@ -48,7 +52,11 @@ struct AttnParams {
   int n_shards;
   float scale;      // softmax scale (1/sqrt(128))
 };
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+// K/V rows in [shard_valid, shard_rows) are read (and masked) but must hold finite values.
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream);     // picks a kernel
+hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows
+hipError_t launch_attention_v2(const AttnParams& p, hipStream_t stream);  // 4 waves x 64 rows, pipelined
+extern int g_attn_kernel;  // 0 default (v2), 1 v1, 2 v2
 
 // ---------------------------------------------------------------- token-wise ops (elementwise.hip)
 // out[m,:] = bf16( LN(x[m,:]) * a + b ),  a = 1+scale (modulate) or weight (affine)

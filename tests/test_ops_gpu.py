@@ -26,10 +26,22 @@ def rel_l2(a, b):
     return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20))
 
 
+@pytest.fixture(params=[1, 2], ids=["kernels-v1", "kernels-v2"])
+def kernel_variant(request):
+    """Every GEMM / attention test runs on both kernel generations: 1 = 128x128 GEMM + 8-wave
+    attention, 2 = 256x256 counted-vmcnt GEMM (where the shape allows) + 4-wave pipelined attention."""
+    lib = _lib.load()
+    _lib.check(lib.mc_set_option(b"gemm_kernel", request.param))
+    _lib.check(lib.mc_set_option(b"attn_kernel", request.param))
+    yield request.param
+    _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
+    _lib.check(lib.mc_set_option(b"attn_kernel", 0))
+
+
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (512, 1536, 1536), (1000, 384, 4096),
-                                   (77, 8960, 1536), (256, 1536, 8960)])
-def test_gemm_bf16_epilogues(M, N, K):
+                                   (77, 8960, 1536), (256, 1536, 8960), (768, 512, 256), (256, 256, 4096)])
+def test_gemm_bf16_epilogues(M, N, K, kernel_variant):
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
     Wt = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)   # asymmetric operands (transposes would show)
     bias = rnd(N, seed=3)
@@ -83,7 +95,7 @@ def test_gemm_rejects_bad_shapes():
     assert e.value.status == _lib.MC_EINVAL
 
 
-def test_gemm_linearity_full_shape():
+def test_gemm_linearity_full_shape(kernel_variant):
     """size-independent property at the real shape (M = 32768 rows): G(a+b) = G(a) + G(b) for
     bf16-exact inputs, fp32 output"""
     M, N, K = 32768, 1536, 1536
@@ -113,8 +125,9 @@ def attn_ref(q, k, v, n_heads, valid_idx):
 
 @pytest.mark.parametrize("Lq,heads,shard_rows,valid,n_shards", [(256, 1, 64, 64, 1), (512, 2, 320, 300, 1),
                                                                 (256, 3, 128, 77, 3), (768, 2, 512, 512, 1),
-                                                                (256, 2, 256, 193, 2)])
-def test_attention_vs_fp32_reference(Lq, heads, shard_rows, valid, n_shards):
+                                                                (256, 2, 256, 193, 2), (256, 1, 64, 1, 1),
+                                                                (512, 2, 448, 448, 1), (256, 2, 192, 129, 4)])
+def test_attention_vs_fp32_reference(Lq, heads, shard_rows, valid, n_shards, kernel_variant):
     d = heads * 128
     q = rnd(Lq, d, seed=1, dtype=torch.bfloat16)
     k = rnd(n_shards * shard_rows, d, seed=2, dtype=torch.bfloat16)
@@ -133,7 +146,7 @@ def test_attention_vs_fp32_reference(Lq, heads, shard_rows, valid, n_shards):
     assert rel_l2(o, want) < 1e-2
 
 
-def test_attention_strided_qkv_and_online_softmax_rescale():
+def test_attention_strided_qkv_and_online_softmax_rescale(kernel_variant):
     """q/k/v interleaved in one [L, 3d] buffer (the engine's layout) and a key whose score dwarfs all
     earlier tiles, forcing the running-max rescale late in the loop"""
     L, heads = 512, 2
@@ -146,7 +159,7 @@ def test_attention_strided_qkv_and_online_softmax_rescale():
     torch.testing.assert_close(o.float(), want, rtol=2e-2, atol=2e-2)
 
 
-def test_attention_full_shape_properties():
+def test_attention_full_shape_properties(kernel_variant):
     """L = 32760 (padded to 32768), 12 heads: (i) V = 1 -> O = 1 (softmax rows sum to one);
     (ii) permuting the keys does not change the result"""
     L, Lp, heads = 32760, 32768, 12
