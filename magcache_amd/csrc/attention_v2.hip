@@ -29,6 +29,13 @@
 #include "common.h"
 #include "ops.h"
 
+// Timing ablations (tools/build_variants.py; results are wrong by construction): bit 0 no softmax
+// VALU, 1 no V^T reads, 2 no K reads, 3 no DMA, 4 no barrier/vmcnt, 5 no row max, 6 no QK MFMAs,
+// 7 no PV MFMAs.
+#ifndef MC_ABL
+#define MC_ABL 0
+#endif
+
 namespace mc {
 
 namespace {
@@ -67,12 +74,21 @@ __device__ __forceinline__ float rowmax32(const f32x16& a, const f32x16& b) {
 // states.  The accumulate chains rotate over 4 accumulators, K comes from ds_read (the compiler
 // waits lgkmcnt before the asm) and Q was written once, long before.
 __device__ __forceinline__ void mfma_qk_first(f32x16& s, const bf16x8& k, const bf16x8& q) {
+#if MC_ABL & 64
+  asm volatile("" : "=v"(s) : "v"(k), "a"(q));
+  return;
+#endif
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(k), "a"(q));
 }
 __device__ __forceinline__ void mfma_qk(f32x16& s, const bf16x8& k, const bf16x8& q) {
+#if MC_ABL & 64
+  asm volatile("" : "+v"(s) : "v"(k), "a"(q));
+  return;
+#endif
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(k), "a"(q));
 }
 #define MC_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory")
+
 #define MC_PIN() __builtin_amdgcn_sched_barrier(0)
 
 __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int nqb, int tiles_per_shard) {
@@ -140,6 +156,22 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
           "s"(lds + 3072u), "s"(base)
         : "memory");
   };
+  // one 1 KiB piece: issued between MFMAs inside the pipelined loop (an LDS-DMA instruction costs
+  // 60-180 cycles of issue; eight of them back to back at the top of an iteration leave the
+  // matrix pipe idle, spread out they hide behind the MFMAs in flight)
+  auto dma1 = [&](const bf16_t* base, uint32_t off, uint32_t lds) {
+    if (MC_ABL & 8) return;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(off), "s"(lds), "s"(base)
+        : "memory");
+  };
   // Tile cursors (all scalar, branch-free): the DMA streams run ahead of the compute, each with its
   // own position.  Past the last tile a cursor stays on it: the reload lands in a dead slot and
   // keeps the number of DMA instructions per iteration constant (the vmcnt counts rely on that).
@@ -185,16 +217,31 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[b][i][r] = 0.f;
-  float m_run[2] = {NEG_INF, NEG_INF}, l_run[2] = {0.f, 0.f};
-  float mc_[2], rs[2][2], mx[2];
+  // Row sums l = sum_k P[k][q] ride on the matrix pipe: one extra MFMA per key step and block with an
+  // all-ones A operand (every row of the 32x32 result holds the sum).  64 v_add_f32 per tile would
+  // cost more than these 8 MFMAs: one wave per SIMD issues only ~4 VALU instructions per MFMA for
+  // free (tools/ubench_issue.cpp), the matrix pipe has slack.  The sum is over the bf16-rounded P,
+  // i.e. exactly the weights that multiply V.
+  f32x16 lacc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[b][r] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+  float m_run[2] = {NEG_INF, NEG_INF};
+  float mc_[2], mx[2];
   const float c = p.scale * 1.4426950408889634f;
   const float thr = RTHR / c;  // the same threshold in raw-score units
 
   auto read_k = [&](const char* st, int ds, bf16x8& k0, bf16x8& k1) {  // keys l31 and 32 + l31
+    if (MC_ABL & 4) { k0 = qf[1][ds]; k1 = qf[1][ds ^ 1]; return; }
     k0 = *(const bf16x8*)(st + koff[ds]);
     k1 = *(const bf16x8*)(st + koff[ds] + 32 * 256);
   };
   auto read_v = [&](const char* st, int i, bf16x8& vf) {  // V^T fragment of PV micro-step i = 4*ks + db
+    if (MC_ABL & 2) { vf = qf[0][i & 7]; return; }
     const char* vp = st + voff[i & 3] + (i >> 2) * (16 * 256);
     const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp));
     const bf16x4 v1 =
@@ -210,7 +257,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
         const float m_new = fmaxf(m_run[b], mx[b]);
         const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * c);
         m_run[b] = m_new;
-        l_run[b] *= alpha;
+        asm volatile("" : "+a"(lacc[b]));
+        lacc[b] = lacc[b] * alpha;
         // The empty asm re-defines O inside this (rare) block: without it hipcc hoists the 128
         // AGPR->VGPR copies the multiplies need into the common path of every iteration.
 #pragma unroll
@@ -223,8 +271,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       mc_[b] = m_run[b] * c;
-      rs[b][0] = 0.f;
-      rs[b][1] = 0.f;
     }
   };
   // keys >= nvalid of a tile are padding: -inf before the max and the exponentials
@@ -256,11 +302,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
   // Two P values: exp2(S c - m c) of accumulator registers 2j, 2j+1 of S[b][kb] -> one packed bf16
   // pair, the B-operand word 8*kb + j of the PV MFMA (key step ks = 2*kb + j/4); row sums in two chains.
 #define MC_FIN_PAIR(S, b, kb, j)                                                              \
-  {                                                                                           \
+  if (MC_ABL & 1) {                                                                           \
+    asm volatile("" ::"v"(S[b][kb][2 * (j)]), "v"(S[b][kb][2 * (j) + 1]));                    \
+  } else {                                                                                    \
     const float e0_ = __builtin_amdgcn_exp2f(__builtin_fmaf(S[b][kb][2 * (j)], c, -mc_[b]));     \
     const float e1_ = __builtin_amdgcn_exp2f(__builtin_fmaf(S[b][kb][2 * (j) + 1], c, -mc_[b])); \
-    rs[b][0] += e0_;                                                                          \
-    rs[b][1] += e1_;                                                                          \
     pk[b][8 * (kb) + (j)] = pack_bf16x2(e0_, e1_);                                            \
   }
   // pair number n = 0..31 in key-step order: ks = n/8, then block, then word
@@ -276,6 +322,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
   asm volatile("s_barrier" ::: "memory");
   f32x16 s[2][2], sn[2][2];
   uint32_t pk[2][16];
+  if (MC_ABL & 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pk[0][i] = pk[1][i] = 0x3c003c00u + lane;
+  }
   {
     const char* st = smem;
 #pragma unroll
@@ -304,11 +354,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
 #define MC_ATTN_BODY(S_cur, S_nxt)                                                                  \
   {                                                                                                  \
     /* K(t+1), V(t) were issued two iterations ago; only the last iteration's 8 DMAs may be pending */ \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                 \
-    asm volatile("s_barrier" ::: "memory");                                                          \
-    /* refill the slots freed by iteration t-1: K(t) -> K(t+3), V(t-1) -> V(t+2) */                  \
-    dma_k((slot_k == 0) ? NST - 1 : slot_k - 1);                                                     \
-    dma_v((slot_v == 0) ? NST - 1 : slot_v - 1);                                                     \
+    if (!(MC_ABL & 16)) {                                                                            \
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                               \
+      asm volatile("s_barrier" ::: "memory");                                                        \
+    }                                                                                                \
+    /* the slots freed by iteration t-1 are refilled piece by piece inside the phases below: */      \
+    /* K(t) -> K(t+3) during phase 1, V(t-1) -> V(t+2) during phase 2 */                             \
+    const uint32_t kdst_ = dma_lds + ((slot_k == 0) ? NST - 1 : slot_k - 1) * TILE_BYTES;            \
+    const uint32_t vdst_ = dma_lds + V_RING + ((slot_v == 0) ? NST - 1 : slot_v - 1) * TILE_BYTES;   \
     mask_partial(S_cur);                                                                             \
     decide(mx);                                                                                      \
     MC_PIN();                                                                                        \
@@ -324,9 +377,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
     /* ---- phase 2: 16 micro-steps x 2 MFMAs; P pairs of key step 3, then the row maxima */         \
     {                                                                                                \
       const char* st_ = smem + slot_v * TILE_BYTES;                                                  \
-      bf16x8 vf_, vn_;                                                                               \
+      bf16x8 va_cur_, vb_cur_, va_x_, vb_;   /* even / odd micro-steps: current and the one after next */ \
       float ra_[4], rb_[4];                                                                          \
-      read_v(st_, 0, vf_);                                                                           \
+      read_v(st_, 0, va_cur_);                                                                       \
+      read_v(st_, 1, vb_cur_);                                                                       \
       MC_PV_STEP(S_cur, S_nxt, 0) MC_PV_STEP(S_cur, S_nxt, 1) MC_PV_STEP(S_cur, S_nxt, 2)            \
       MC_PV_STEP(S_cur, S_nxt, 3) MC_PV_STEP(S_cur, S_nxt, 4) MC_PV_STEP(S_cur, S_nxt, 5)            \
       MC_PV_STEP(S_cur, S_nxt, 6) MC_PV_STEP(S_cur, S_nxt, 7) MC_PV_STEP(S_cur, S_nxt, 8)            \
@@ -334,12 +388,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
       MC_PV_STEP(S_cur, S_nxt, 12) MC_PV_STEP(S_cur, S_nxt, 13) MC_PV_STEP(S_cur, S_nxt, 14)         \
       MC_PV_STEP(S_cur, S_nxt, 15)                                                                   \
     }                                                                                                \
-    l_run[0] += rs[0][0] + rs[0][1];                                                                 \
-    l_run[1] += rs[1][0] + rs[1][1];                                                                 \
-    /* uses the sums inside this block: otherwise the 64 adds are sunk into the next block and */    \
-    /* the exponentials stay live across the whole iteration */                                      \
-    asm volatile("" : "+v"(l_run[0]), "+v"(l_run[1]));                                               \
-    MC_PIN();                                                                                        \
     slot_k = (slot_k + 1 == NST) ? 0 : slot_k + 1;                                                   \
     slot_v = (slot_v + 1 == NST) ? 0 : slot_v + 1;                                                   \
   }
@@ -348,6 +396,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
 #define MC_QK_STEP(S_cur, S_nxt, ds)                                                                \
   if ((ds) < 7) read_k(st_, (ds) + 1, n0_, n1_);                                                     \
   if ((ds) == 0) mfma_qk_first(S_nxt[0][0], k0_, qf[0][0]); else mfma_qk(S_nxt[0][0], k0_, qf[0][ds]); \
+  if ((ds) & 1) dma1(ck.ptr, srcK[(ds) >> 1], kdst_ + ((ds) >> 1) * 1024);                           \
+  if ((ds) == 7) advance(ck, p.ldk, p.k_shard_stride);                                               \
   MC_FIN_N(S_cur, 3 * (ds));                                                                         \
   MC_PIN();                                                                                          \
   if ((ds) == 0) mfma_qk_first(S_nxt[1][0], k0_, qf[1][0]); else mfma_qk(S_nxt[1][0], k0_, qf[1][ds]); \
@@ -363,23 +413,34 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
   // PV micro-step i = 4*ks + db: [V^T fragment of step i+1] 2 MFMAs + a slice of VALU work:
   //   i 0..7 : P pair 24+i (key step 3);  i 8..11 / 12..15: row maximum of S_nxt block 0 / 1
 #define MC_PV_STEP(S_cur, S_nxt, i)                                                                 \
-  if ((i) < 15) read_v(st_, (i) + 1, vn_);                                                           \
+  if ((i) < 14) read_v(st_, (i) + 2, ((i) & 1) ? vb_ : va_x_);                                       \
   {                                                                                                  \
     const int ks_ = (i) >> 2;                                                                        \
     const u32x4 pa_ = {pk[0][4 * ks_], pk[0][4 * ks_ + 1], pk[0][4 * ks_ + 2], pk[0][4 * ks_ + 3]};   \
     const u32x4 pb_ = {pk[1][4 * ks_], pk[1][4 * ks_ + 1], pk[1][4 * ks_ + 2], pk[1][4 * ks_ + 3]};   \
-    o[0][(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_, __builtin_bit_cast(bf16x8, pa_), o[0][(i) & 3], 0, 0, 0); \
-    o[1][(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_, __builtin_bit_cast(bf16x8, pb_), o[1][(i) & 3], 0, 0, 0); \
+    const bf16x8 vcur_ = ((i) & 1) ? vb_cur_ : va_cur_;                                              \
+    if (!(MC_ABL & 128)) o[0][(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur_, __builtin_bit_cast(bf16x8, pa_), o[0][(i) & 3], 0, 0, 0); \
+    else asm volatile("" ::"v"(vcur_), "v"(pa_));                                                    \
+    if (((i) & 3) == 1) dma1(cv.ptr, srcV[(i) >> 2], vdst_ + ((i) >> 2) * 1024);                     \
+    if ((i) == 13) advance(cv, p.ldv, p.v_shard_stride);                                             \
+    if (!(MC_ABL & 128)) o[1][(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur_, __builtin_bit_cast(bf16x8, pb_), o[1][(i) & 3], 0, 0, 0); \
+    else asm volatile("" ::"v"(vcur_), "v"(pb_));                                                    \
+    if (((i) & 3) == 3) {                                                                            \
+      lacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8, pa_), lacc[0], 0, 0, 0); \
+      lacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8, pb_), lacc[1], 0, 0, 0); \
+    }                                                                                                \
   }                                                                                                  \
   if ((i) < 8) MC_FIN_N(S_cur, 24 + (i))                                                             \
   else if ((i) < 12) MC_ROWMAX_PART(S_nxt, 0, (i) - 8, ra_, mx[0])                                   \
   else MC_ROWMAX_PART(S_nxt, 1, (i) - 12, rb_, mx[1])                                                \
-  vf_ = vn_;                                                                                         \
+  if ((i) & 1) vb_cur_ = vb_; else va_cur_ = va_x_;                                                  \
   MC_PIN();
 
   // row maximum of block b in four parts (4 partial maxima over the 32 accumulator registers)
 #define MC_ROWMAX_PART(S, b, part, r_, out)                                                         \
-  {                                                                                                  \
+  if (MC_ABL & 32) {                                                                                 \
+    if ((part) == 3) out = S[b][0][0];                                                               \
+  } else {                                                                                           \
     if ((part) == 0) {                                                                               \
       r_[0] = max3(S[b][0][0], S[b][0][1], S[b][0][2]);  r_[1] = max3(S[b][0][3], S[b][0][4], S[b][0][5]);    \
       r_[2] = max3(S[b][0][6], S[b][0][7], S[b][0][8]);  r_[3] = max3(S[b][0][9], S[b][0][10], S[b][0][11]);  \
@@ -420,8 +481,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
       const int b = (n >> 2) & 1, kb = n >> 4, j = ((n >> 3) & 1) * 4 + (n & 3);
       MC_FIN_PAIR(s, b, kb, j);
     }
-    l_run[0] += rs[0][0] + rs[0][1];
-    l_run[1] += rs[1][0] + rs[1][1];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       bf16x8 vf;
@@ -431,6 +490,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
       const u32x4 pb = {pk[1][4 * ks], pk[1][4 * ks + 1], pk[1][4 * ks + 2], pk[1][4 * ks + 3]};
       o[0][i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pa), o[0][i & 3], 0, 0, 0);
       o[1][i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pb), o[1][i & 3], 0, 0, 0);
+      if ((i & 3) == 3) {
+        lacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8, pa), lacc[0], 0, 0, 0);
+        lacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8, pb), lacc[1], 0, 0, 0);
+      }
     }
   }
 #undef MC_ATTN_BODY
@@ -443,7 +506,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_v2_kernel(AttnParams p, int n
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + 8*g + 4*half + 0..3
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const float inv = 1.0f / half_swap_sum(l_run[b]);
+    const float inv = 1.0f / lacc[b][0];
     bf16_t* op = p.O + (size_t)(qrow + 32 * b) * p.ldo + head * HD + 4 * half;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {

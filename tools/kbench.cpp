@@ -251,6 +251,11 @@ int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "all";
   const int iters = argc > 2 ? atoi(argv[2]) : 10;
   printf("%s\n", mc_version());
+  if (what == "attn1") bench_attn(32768, 12, 32768, 32760, 1, "self480p", iters);
+  if (what == "gemm1") {
+    bench_gemm(32768, 4608, 1536, 0, "qkv", iters);
+    bench_gemm(32768, 1536, 8960, 2, "ffn2_resid", iters);
+  }
   if (what == "attn" || what == "all") {
     // correctness-first small cases (odd tile counts, partial tails, shards), then the 480p shape
     bench_attn(256, 2, 64, 37, 1, "1tile", 3);
