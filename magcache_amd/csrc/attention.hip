@@ -225,11 +225,15 @@ hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// mc_set_option("attn_kernel", v): 0 default, 1 = this kernel, 2 = attention_v2.hip
+// mc_set_option("attn_kernel", v): 0 default, 1 = this kernel, 2 = attention_v2.hip, 3 = attention_v3.hip
 int g_attn_kernel = 0;
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
-  return g_attn_kernel == 1 ? launch_attention_v1(p, stream) : launch_attention_v2(p, stream);
+  switch (g_attn_kernel) {
+    case 1: return launch_attention_v1(p, stream);
+    case 2: return launch_attention_v2(p, stream);
+    default: return launch_attention_v3(p, stream);
+  }
 }
 
 }  // namespace mc

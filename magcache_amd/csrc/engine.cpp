@@ -751,7 +751,8 @@ mc_status mc_set_option(const char* key, int value) {
     if (value < 0 || value > 2) return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128) or 2 (256x256)");
     mc::g_gemm_kernel = value;
   } else if (k == "attn_kernel") {
-    if (value < 0 || value > 2) return fail(MC_EINVAL, "attn_kernel must be 0 (default), 1 (8-wave) or 2 (4-wave pipelined)");
+    if (value < 0 || value > 3)
+      return fail(MC_EINVAL, "attn_kernel must be 0 (default), 1 (8-wave), 2 (4-wave pipelined) or 3 (8-wave pipelined)");
     mc::g_attn_kernel = value;
   } else {
     return fail(MC_EINVAL, "unknown option '%s'", key);

@@ -56,7 +56,8 @@ struct AttnParams {
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);     // picks a kernel
 hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows
 hipError_t launch_attention_v2(const AttnParams& p, hipStream_t stream);  // 4 waves x 64 rows, pipelined
-extern int g_attn_kernel;  // 0 default (v2), 1 v1, 2 v2
+hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows, pipelined
+extern int g_attn_kernel;  // 0 default, 1 v1, 2 v2, 3 v3
 
 // ---------------------------------------------------------------- token-wise ops (elementwise.hip)
 // out[m,:] = bf16( LN(x[m,:]) * a + b ),  a = 1+scale (modulate) or weight (affine)

@@ -26,12 +26,13 @@ def rel_l2(a, b):
     return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20))
 
 
-@pytest.fixture(params=[1, 2], ids=["kernels-v1", "kernels-v2"])
+@pytest.fixture(params=[1, 2, 3], ids=["kernels-v1", "kernels-v2", "kernels-v3"])
 def kernel_variant(request):
-    """Every GEMM / attention test runs on both kernel generations: 1 = 128x128 GEMM + 8-wave
-    attention, 2 = 256x256 counted-vmcnt GEMM (where the shape allows) + 4-wave pipelined attention."""
+    """Every GEMM / attention test runs on all kernel generations: 1 = 128x128 GEMM + 8-wave
+    attention, 2 = 256x256 counted-vmcnt GEMM (where the shape allows) + 4-wave pipelined attention,
+    3 = GEMM chosen by shape + 8-wave pipelined attention (the defaults)."""
     lib = _lib.load()
-    _lib.check(lib.mc_set_option(b"gemm_kernel", request.param))
+    _lib.check(lib.mc_set_option(b"gemm_kernel", request.param % 3))
     _lib.check(lib.mc_set_option(b"attn_kernel", request.param))
     yield request.param
     _lib.check(lib.mc_set_option(b"gemm_kernel", 0))

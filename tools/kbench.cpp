@@ -172,39 +172,40 @@ static void bench_gemm(int M, int N, int K, int epi, const char* name, int iters
 // Q [Lq_pad, H*128], K/V [n_shards*shard_rows, H*128] bf16; fp64 reference for `nsample` query rows
 static void bench_attn(int Lq_pad, int H, int shard_rows, int shard_valid, int n_shards, const char* name, int iters) {
   const int D = H * 128;
+  const int NV = 3;
   const size_t kv_rows = (size_t)n_shards * shard_rows;
-  uint16_t *Q, *K, *V, *O[2];
+  uint16_t *Q, *K, *V, *O;
   CK(hipMalloc(&Q, (size_t)Lq_pad * D * 2));
   CK(hipMalloc(&K, kv_rows * D * 2));
   CK(hipMalloc(&V, kv_rows * D * 2));
-  for (int v = 0; v < 2; ++v) CK(hipMalloc(&O[v], (size_t)Lq_pad * D * 2));
+  CK(hipMalloc(&O, (size_t)Lq_pad * D * 2));
   fill_bf16<<<2048, 256>>>(Q, (size_t)Lq_pad * D, 11, 1.7f);  // uniform(-1.7,1.7): unit variance -> scores ~ N(0,1)
   fill_bf16<<<2048, 256>>>(K, kv_rows * D, 12, 1.7f);
   fill_bf16<<<2048, 256>>>(V, kv_rows * D, 13, 1.0f);
   CK(hipDeviceSynchronize());
   const float scale = 1.0f / std::sqrt(128.0f);
   const double flops = 4.0 * (double)Lq_pad * ((double)n_shards * shard_valid) * D;
-  double ms[2];
-  std::vector<uint16_t> ho[2];
-  for (int v = 0; v < 2; ++v) {
+  double ms[NV];
+  std::vector<uint16_t> ho[NV];
+  for (int v = 0; v < NV; ++v) {
     MC(mc_set_option("attn_kernel", v + 1));
-    CK(hipMemset(O[v], 0xff, (size_t)Lq_pad * D * 2));  // NaN poison
+    CK(hipMemset(O, 0xff, (size_t)Lq_pad * D * 2));  // NaN poison
     auto run = [&]() {
-      MC(mc_op_attention(Q, D, K, D, (long)shard_rows * D, V, D, (long)shard_rows * D, O[v], D, Lq_pad, H, shard_rows,
+      MC(mc_op_attention(Q, D, K, D, (long)shard_rows * D, V, D, (long)shard_rows * D, O, D, Lq_pad, H, shard_rows,
                          shard_valid, n_shards, scale, nullptr));
     };
     ms[v] = time_ms(run, iters);
     ho[v].resize((size_t)Lq_pad * D);
-    CK(hipMemcpy(ho[v].data(), O[v], ho[v].size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ho[v].data(), O, ho[v].size() * 2, hipMemcpyDeviceToHost));
   }
-  Diff dv;
-  for (size_t i = 0; i < ho[0].size(); ++i) dv.add(bf16_to_f(ho[1][i]), bf16_to_f(ho[0][i]));
   // fp64 reference on sampled (row, head) pairs
   std::vector<uint16_t> hq((size_t)Lq_pad * D), hk(kv_rows * D), hv(kv_rows * D);
   CK(hipMemcpy(hq.data(), Q, hq.size() * 2, hipMemcpyDeviceToHost));
   CK(hipMemcpy(hk.data(), K, hk.size() * 2, hipMemcpyDeviceToHost));
   CK(hipMemcpy(hv.data(), V, hv.size() * 2, hipMemcpyDeviceToHost));
-  Diff dr[2];
+  Diff dr[NV], dv[NV];
+  for (int v = 1; v < NV; ++v)
+    for (size_t i = 0; i < ho[0].size(); ++i) dv[v].add(bf16_to_f(ho[v][i]), bf16_to_f(ho[0][i]));
   const int nsample = 24;
   for (int sidx = 0; sidx < nsample; ++sidx) {
     const int row = (int)(((uint64_t)sidx * 2654435761ull + 12345) % (uint64_t)Lq_pad);
@@ -232,19 +233,19 @@ static void bench_attn(int Lq_pad, int H, int shard_rows, int shard_valid, int n
         const size_t kr = (size_t)sh * shard_rows + k;
         for (int d = 0; d < 128; ++d) acc[d] += pw * bf16_to_f(hv[kr * D + head * 128 + d]);
       }
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < NV; ++v)
       for (int d = 0; d < 128; ++d) dr[v].add(bf16_to_f(ho[v][(size_t)row * D + head * 128 + d]), acc[d] / den);
   }
-  printf("  attn %-8s v2 vs v1: max_abs %.3e rel_l2 %.3e nan %zu | vs fp64 (%d rows): v1 rel_l2 %.3e max_abs %.3e nan %zu ; "
-         "v2 rel_l2 %.3e max_abs %.3e nan %zu\n",
-         name, dv.max_abs, dv.rel_l2(), dv.nan, nsample, dr[0].rel_l2(), dr[0].max_abs, dr[0].nan, dr[1].rel_l2(),
-         dr[1].max_abs, dr[1].nan);
-  printf("attn %-8s Lq=%d H=%d keys=%dx%d(valid %d) | v1 %.3f ms %.0f TF | v2 %.3f ms %.0f TF | x%.2f\n", name, Lq_pad, H,
-         n_shards, shard_rows, shard_valid, ms[0], flops / ms[0] * 1e-9, ms[1], flops / ms[1] * 1e-9, ms[0] / ms[1]);
+  printf("  attn %-8s vs fp64 (%d rows) rel_l2/max_abs/nan:", name, nsample);
+  for (int v = 0; v < NV; ++v) printf("  v%d %.3e %.3e %zu", v + 1, dr[v].rel_l2(), dr[v].max_abs, dr[v].nan);
+  printf(" | vs v1 rel_l2/nan:");
+  for (int v = 1; v < NV; ++v) printf("  v%d %.3e %zu", v + 1, dv[v].rel_l2(), dv[v].nan);
+  printf("\nattn %-8s Lq=%d H=%d keys=%dx%d(valid %d) |", name, Lq_pad, H, n_shards, shard_rows, shard_valid);
+  for (int v = 0; v < NV; ++v) printf(" v%d %.3f ms %.0f TF |", v + 1, ms[v], flops / ms[v] * 1e-9);
+  printf("\n");
   fflush(stdout);
   MC(mc_set_option("attn_kernel", 0));
-  CK(hipFree(Q)); CK(hipFree(K)); CK(hipFree(V));
-  for (int v = 0; v < 2; ++v) CK(hipFree(O[v]));
+  CK(hipFree(Q)); CK(hipFree(K)); CK(hipFree(V)); CK(hipFree(O));
 }
 
 int main(int argc, char** argv) {
