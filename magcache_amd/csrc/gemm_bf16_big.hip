@@ -48,10 +48,10 @@ constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // Am0 | Am1 | Wn0 | Wn1
 constexpr int OFF_AM0 = 0, OFF_AM1 = HALF_BYTES, OFF_WN0 = 2 * HALF_BYTES, OFF_WN1 = 3 * HALF_BYTES;
 constexpr int GROUP_M = 8;
 
-// end-of-interval wait: at most n LDS-DMA instructions of this wave still in flight, and every
-// ds_read older than the r issued in this interval complete (their LDS region is re-filled two
-// barriers later; the count makes that formally safe, the reads are long done in practice)
-#define MC_WAIT(n, r) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(" #r ")" ::: "memory")
+// end-of-interval wait: at most n LDS-DMA instructions of this wave still in flight.  (ds_reads need
+// no wait here: a region is re-filled two barriers after its last read, and every read has been
+// consumed by an MFMA -- i.e. waited for -- one barrier earlier.)
+#define MC_WAIT(n, r) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // interval boundary: nothing (MFMAs included -- they are register-only and would otherwise drift
 // across the asm statements) is scheduled across it
 #define MC_BARRIER()                          \
@@ -59,6 +59,8 @@ constexpr int GROUP_M = 8;
     asm volatile("s_barrier" ::: "memory");   \
     __builtin_amdgcn_sched_barrier(0);        \
   } while (0)
+
+#define MC_PIN() __builtin_amdgcn_sched_barrier(0)
 
 struct Frag4 {  // one 32-row block x 64 k = 4 MFMA operands
   bf16x8 v[4];
@@ -130,45 +132,49 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   // that pass and ordered only by the counted waits below.  saddr form: 64-bit uniform base in
   // SGPRs + one 32-bit byte offset per lane.  M0 = LDS byte address of the piece (wave-uniform);
   // s_nop covers the SALU-write-M0 -> LDS-DMA hazard; M0 is restored for the compiler.
-  auto dma2 = [&](const bf16_t* base, uint32_t off0, uint32_t off1, uint32_t lds) {
+  // one 1 KiB piece: M0 = LDS byte address (wave-uniform), saddr form: 64-bit uniform base + 32-bit
+  // lane offset; s_nop covers the SALU-write-M0 -> LDS-DMA hazard; M0 is restored for the compiler.
+  auto dma1 = [&](const bf16_t* base, uint32_t off, uint32_t lds) {
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %5\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %5\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(off0), "v"(off1), "s"(lds), "s"(lds + 1024u), "s"(base)
+        : "v"(off), "s"(lds), "s"(base)
         : "memory");
   };
-  auto dma_a = [&](int kt, int st, int h) {  // issue A half h of K tile kt into stage st (= kt & 1)
-    dma2(p.A + (size_t)kt * BK, srcA[h][0], srcA[h][1], dma_lds + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0));
+  // piece j (0/1) of half h of K tile kt into stage st (= kt & 1)
+  auto dma_a1 = [&](int kt, int st, int h, int j) {
+    dma1(p.A + (size_t)kt * BK, srcA[h][j], dma_lds + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0) + j * 1024);
   };
-  auto dma_w = [&](int kt, int st, int h) {
-    dma2(p.W + (size_t)kt * BK, srcW[h][0], srcW[h][1], dma_lds + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0));
+  auto dma_w1 = [&](int kt, int st, int h, int j) {
+    dma1(p.W + (size_t)kt * BK, srcW[h][j], dma_lds + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0) + j * 1024);
   };
-  auto read_a = [&](int st, int h, Frag4 (&f)[2]) {  // both 32-row blocks of this wave's A half h
-    const char* src = smem + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0) + a_base;
+  auto dma_a = [&](int kt, int st, int h) { dma_a1(kt, st, h, 0); dma_a1(kt, st, h, 1); };  // prologue
+  auto dma_w = [&](int kt, int st, int h) { dma_w1(kt, st, h, 0); dma_w1(kt, st, h, 1); };
+  // fragment i = 4*ms + ks of this wave's A half h / fragment ks of its W half h
+  auto read_a1 = [&](int st, int h, int i, Frag4 (&f)[2]) {
+    f[i >> 2].v[i & 3] =
+        *(const bf16x8*)(smem + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0) + a_base + (i >> 2) * (32 * 128) + fo[i & 3]);
+  };
+  auto read_w1 = [&](int st, int h, int ks, Frag4& f) {
+    f.v[ks] = *(const bf16x8*)(smem + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0) + w_base + fo[ks]);
+  };
+  auto read_a = [&](int st, int h, Frag4 (&f)[2]) {  // prologue
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) f[ms].v[ks] = *(const bf16x8*)(src + ms * (32 * 128) + fo[ks]);
+    for (int i = 0; i < 8; ++i) read_a1(st, h, i, f);
   };
   auto read_w = [&](int st, int h, Frag4& f) {
-    const char* src = smem + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0) + w_base;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) f.v[ks] = *(const bf16x8*)(src + fo[ks]);
+    for (int ks = 0; ks < 4; ++ks) read_w1(st, h, ks, f);
   };
-  auto mma = [&](const Frag4& w, const Frag4 (&a)[2], f32x16 (&c0), f32x16 (&c1)) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[ks], a[0].v[ks], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[ks], a[1].v[ks], c1, 0, 0, 0);
-    }
+  // MFMA i (0..7) of an interval: k-substep i/2, 32-row block i%2 -> two rotating accumulators
+  auto mma1 = [&](int i, const Frag4& w, const Frag4 (&a)[2], f32x16 (&c0), f32x16 (&c1)) {
+    if (i & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i >> 1], a[1].v[i >> 1], c1, 0, 0, 0);
+    else c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i >> 1], a[0].v[i >> 1], c0, 0, 0, 0);
   };
 
   // ---- prologue: K tiles 0 and 1 in the steady-state issue order; Wn0(0), Am0(0), Wn1(0) landed
@@ -186,32 +192,116 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   // Wait counts: at the end of an interval the half that is read in the NEXT interval must have
   // landed.  Steady state: 6 halves (12 DMAs) issued since, the oldest must be done -> vmcnt(10).
   // Tile nk-2 issues nothing: 4,3,2,1 halves may stay in flight -> 8,6,4,2; tile nk-1: 0 once.
-#define MC_TILE(TAIL, kt, ST, W0, W2)                                        \
-  {                                                                           \
-    /* q0 */                                                                  \
-    if (TAIL == 0) dma_w((kt) + 2, ST, 0);                                    \
-    read_w(ST, 1, W1);                                                        \
-    mma(W0, A0, acc[0][0][0], acc[0][1][0]);                                  \
-    if (TAIL == 0) MC_WAIT(10, 4); else if (TAIL == 1) MC_WAIT(8, 4); else MC_WAIT(0, 4); \
-    MC_BARRIER();                                                             \
-    /* q1 */                                                                  \
-    if (TAIL == 0) dma_a((kt) + 2, ST, 0);                                    \
-    read_a(ST, 1, A1);                                                        \
-    mma(W1, A0, acc[0][0][1], acc[0][1][1]);                                  \
-    if (TAIL == 0) MC_WAIT(10, 8); else if (TAIL == 1) MC_WAIT(6, 8);           \
-    MC_BARRIER();                                                             \
-    /* q2 */                                                                  \
-    if (TAIL == 0) dma_w((kt) + 2, ST, 1);                                    \
-    if (TAIL != 2) read_w(1 - ST, 0, W2);                                     \
-    mma(W1, A1, acc[1][0][1], acc[1][1][1]);                                  \
-    if (TAIL == 0) MC_WAIT(10, 4); else if (TAIL == 1) MC_WAIT(4, 4);           \
-    MC_BARRIER();                                                             \
-    /* q3 */                                                                  \
-    if (TAIL == 0) dma_a((kt) + 2, ST, 1);                                    \
-    if (TAIL != 2) read_a(1 - ST, 0, A0);                                     \
-    mma(W0, A1, acc[1][0][0], acc[1][1][0]);                                  \
-    if (TAIL == 0) MC_WAIT(10, 8); else if (TAIL == 1) MC_WAIT(2, 8);           \
-    MC_BARRIER();                                                             \
+#define MC_TILE(TAIL, kt, ST, W0, W2) \
+  { \
+    /* q0: (m0,n0); reads Wn1(kt); DMA Wn0(kt+2) */ \
+    mma1(0, W0, A0, acc[0][0][0], acc[0][1][0]); \
+    if (true) read_w1(ST, 1, 0, W1); \
+    MC_PIN(); \
+    mma1(1, W0, A0, acc[0][0][0], acc[0][1][0]); \
+    MC_PIN(); \
+    mma1(2, W0, A0, acc[0][0][0], acc[0][1][0]); \
+    if (true) read_w1(ST, 1, 1, W1); \
+    if (TAIL == 0) dma_w1((kt) + 2, ST, 0, 0); \
+    MC_PIN(); \
+    mma1(3, W0, A0, acc[0][0][0], acc[0][1][0]); \
+    MC_PIN(); \
+    mma1(4, W0, A0, acc[0][0][0], acc[0][1][0]); \
+    if (true) read_w1(ST, 1, 2, W1); \
+    MC_PIN(); \
+    mma1(5, W0, A0, acc[0][0][0], acc[0][1][0]); \
+    if (TAIL == 0) dma_w1((kt) + 2, ST, 0, 1); \
+    MC_PIN(); \
+    mma1(6, W0, A0, acc[0][0][0], acc[0][1][0]); \
+    if (true) read_w1(ST, 1, 3, W1); \
+    MC_PIN(); \
+    mma1(7, W0, A0, acc[0][0][0], acc[0][1][0]); \
+    MC_PIN(); \
+    if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(8, 0); else MC_WAIT(0, 0); \
+    MC_BARRIER(); \
+    /* q1: (m0,n1); reads Am1(kt); DMA Am0(kt+2) */ \
+    mma1(0, W1, A0, acc[0][0][1], acc[0][1][1]); \
+    if (true) read_a1(ST, 1, 0, A1); \
+    MC_PIN(); \
+    mma1(1, W1, A0, acc[0][0][1], acc[0][1][1]); \
+    if (true) read_a1(ST, 1, 1, A1); \
+    MC_PIN(); \
+    mma1(2, W1, A0, acc[0][0][1], acc[0][1][1]); \
+    if (true) read_a1(ST, 1, 2, A1); \
+    if (TAIL == 0) dma_a1((kt) + 2, ST, 0, 0); \
+    MC_PIN(); \
+    mma1(3, W1, A0, acc[0][0][1], acc[0][1][1]); \
+    if (true) read_a1(ST, 1, 3, A1); \
+    MC_PIN(); \
+    mma1(4, W1, A0, acc[0][0][1], acc[0][1][1]); \
+    if (true) read_a1(ST, 1, 4, A1); \
+    MC_PIN(); \
+    mma1(5, W1, A0, acc[0][0][1], acc[0][1][1]); \
+    if (true) read_a1(ST, 1, 5, A1); \
+    if (TAIL == 0) dma_a1((kt) + 2, ST, 0, 1); \
+    MC_PIN(); \
+    mma1(6, W1, A0, acc[0][0][1], acc[0][1][1]); \
+    if (true) read_a1(ST, 1, 6, A1); \
+    MC_PIN(); \
+    mma1(7, W1, A0, acc[0][0][1], acc[0][1][1]); \
+    if (true) read_a1(ST, 1, 7, A1); \
+    MC_PIN(); \
+    if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(6, 0); \
+    MC_BARRIER(); \
+    /* q2: (m1,n1); reads Wn0(kt+1); DMA Wn1(kt+2) */ \
+    mma1(0, W1, A1, acc[1][0][1], acc[1][1][1]); \
+    if (TAIL != 2) read_w1(1 - ST, 0, 0, W2); \
+    MC_PIN(); \
+    mma1(1, W1, A1, acc[1][0][1], acc[1][1][1]); \
+    MC_PIN(); \
+    mma1(2, W1, A1, acc[1][0][1], acc[1][1][1]); \
+    if (TAIL != 2) read_w1(1 - ST, 0, 1, W2); \
+    if (TAIL == 0) dma_w1((kt) + 2, ST, 1, 0); \
+    MC_PIN(); \
+    mma1(3, W1, A1, acc[1][0][1], acc[1][1][1]); \
+    MC_PIN(); \
+    mma1(4, W1, A1, acc[1][0][1], acc[1][1][1]); \
+    if (TAIL != 2) read_w1(1 - ST, 0, 2, W2); \
+    MC_PIN(); \
+    mma1(5, W1, A1, acc[1][0][1], acc[1][1][1]); \
+    if (TAIL == 0) dma_w1((kt) + 2, ST, 1, 1); \
+    MC_PIN(); \
+    mma1(6, W1, A1, acc[1][0][1], acc[1][1][1]); \
+    if (TAIL != 2) read_w1(1 - ST, 0, 3, W2); \
+    MC_PIN(); \
+    mma1(7, W1, A1, acc[1][0][1], acc[1][1][1]); \
+    MC_PIN(); \
+    if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(4, 0); \
+    MC_BARRIER(); \
+    /* q3: (m1,n0); reads Am0(kt+1); DMA Am1(kt+2) */ \
+    mma1(0, W0, A1, acc[1][0][0], acc[1][1][0]); \
+    if (TAIL != 2) read_a1(1 - ST, 0, 0, A0); \
+    MC_PIN(); \
+    mma1(1, W0, A1, acc[1][0][0], acc[1][1][0]); \
+    if (TAIL != 2) read_a1(1 - ST, 0, 1, A0); \
+    MC_PIN(); \
+    mma1(2, W0, A1, acc[1][0][0], acc[1][1][0]); \
+    if (TAIL != 2) read_a1(1 - ST, 0, 2, A0); \
+    if (TAIL == 0) dma_a1((kt) + 2, ST, 1, 0); \
+    MC_PIN(); \
+    mma1(3, W0, A1, acc[1][0][0], acc[1][1][0]); \
+    if (TAIL != 2) read_a1(1 - ST, 0, 3, A0); \
+    MC_PIN(); \
+    mma1(4, W0, A1, acc[1][0][0], acc[1][1][0]); \
+    if (TAIL != 2) read_a1(1 - ST, 0, 4, A0); \
+    MC_PIN(); \
+    mma1(5, W0, A1, acc[1][0][0], acc[1][1][0]); \
+    if (TAIL != 2) read_a1(1 - ST, 0, 5, A0); \
+    if (TAIL == 0) dma_a1((kt) + 2, ST, 1, 1); \
+    MC_PIN(); \
+    mma1(6, W0, A1, acc[1][0][0], acc[1][1][0]); \
+    if (TAIL != 2) read_a1(1 - ST, 0, 6, A0); \
+    MC_PIN(); \
+    mma1(7, W0, A1, acc[1][0][0], acc[1][1][0]); \
+    if (TAIL != 2) read_a1(1 - ST, 0, 7, A0); \
+    MC_PIN(); \
+    if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(2, 0); \
+    MC_BARRIER(); \
   }
 
   // nk is even (checked by the launcher): steady pairs, then the two tail tiles
