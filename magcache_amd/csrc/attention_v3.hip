@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
   dma_v(0);
   dma_k(2);
   dma_v(1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // K(0) landed (this wave's pieces)
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K(0), K(1) landed (this wave's pieces)
   asm volatile("s_barrier" ::: "memory");
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 s[2], sn[2];
@@ -266,19 +266,31 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
   }
 
   int slot_k = 1, slot_v = 0;  // ring slots of K(t+1) and V(t)
+  // Fragments that cross a phase boundary (no LDS latency at the start of a phase): the K fragments of
+  // d-steps 0 and 1 of the NEXT iteration's phase 1 are read at the end of phase 2 (its K tile was
+  // published by this iteration's barrier: the wait below leaves only V pieces in flight), the V^T
+  // fragments of micro-steps 0 and 1 at the end of phase 1.
+  bf16x8 kx0, kx1, ky0, ky1, kz0, kz1, kw0, kw1, va_, vb_, vc_, vd_, ve_;
+  read_k(smem + slot_k * TILE_BYTES, 0, kx0, kx1);
+  read_k(smem + slot_k * TILE_BYTES, 1, ky0, ky1);
+  read_k(smem + slot_k * TILE_BYTES, 2, kz0, kz1);
 
-  // d-step ds of S_nxt = K Q^T: [K fragments of step ds+1] M P M (P), one K DMA piece at ds 2 and 5
-#define MC_QK_STEP(S_cur, S_nxt, ds)                                                                \
-  if ((ds) < 7) read_k(st_, (ds) + 1, n0_, n1_);                                                     \
-  S_nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0_, qf[ds], (ds) ? S_nxt[0] : c_init, 0, 0, 0); \
+  // d-step ds of S_nxt = K Q^T with fragments (KC0, KC1); [K fragments of step ds+2 -> (KN0, KN1)]
+  // M P M (P); one K DMA piece at ds 2 and 5; the first two V^T fragments of phase 2 at ds 6 and 7
+#define MC_QK_STEP(S_cur, S_nxt, ds, KC0, KC1, KN0, KN1)                                            \
+  if ((ds) < 5) read_k(st_, (ds) + 3, KN0, KN1);                                                     \
+  if ((ds) == 4) read_v(stv_, 0, va_);                                                               \
+  if ((ds) == 5) read_v(stv_, 1, vb_);                                                               \
+  if ((ds) == 6) read_v(stv_, 2, vc_);                                                               \
+  if ((ds) == 7) read_v(stv_, 3, vd_);                                                               \
+  S_nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KC0, qf[ds], (ds) ? S_nxt[0] : c_init, 0, 0, 0); \
   MC_FIN_N(S_cur, (ds));                                                                             \
   if ((ds) == 2) dma1(kptr_, srcK[0], kdst_);                                                        \
   if ((ds) == 5) dma1(kptr_, srcK[1], kdst_ + 1024);                                                 \
   MC_PIN();                                                                                          \
-  S_nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1_, qf[ds], (ds) ? S_nxt[1] : c_init, 0, 0, 0); \
+  S_nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KC1, qf[ds], (ds) ? S_nxt[1] : c_init, 0, 0, 0); \
   if ((ds) == 3) MC_FIN_N(S_cur, 8);                                                                 \
   if ((ds) == 6) MC_FIN_N(S_cur, 9);                                                                 \
-  k0_ = n0_; k1_ = n1_;                                                                              \
   MC_PIN();
 
   // row maximum of S in four parts (4 partial maxima over the 32 accumulator registers)
@@ -299,10 +311,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
     }                                                                                                \
   }
 
-  // PV micro-step i = 4*ks + db: [V^T fragment of step i+2] 1 MFMA + a slice of VALU work:
+  // PV micro-step i = 4*ks + db: [V^T fragment of step i+4] 1 MFMA + a slice of VALU work:
   //   i 0..5: P pair 10+i;  i 8..11: row maximum of S_nxt;  V DMA pieces at i = 6 and 12
 #define MC_PV_STEP(S_cur, S_nxt, i, VC, VN)                                                         \
-  if ((i) < 14) read_v(st_, (i) + 2, VN);                                                            \
+  if ((i) < 12) read_v(st_, (i) + 4, VN);                                                            \
+  if ((i) == 13) read_k(stk_, 0, kx0, kx1);                                                          \
+  if ((i) == 14) read_k(stk_, 1, ky0, ky1);                                                          \
+  if ((i) == 15) read_k(stk_, 2, kz0, kz1);                                                          \
   {                                                                                                  \
     const int ks_ = (i) >> 2;                                                                        \
     const u32x4 pw_ = {pk[4 * ks_], pk[4 * ks_ + 1], pk[4 * ks_ + 2], pk[4 * ks_ + 3]};               \
@@ -317,8 +332,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
   // One iteration: S_cur = S(t) (row maximum in mx) -> P(t), O += V(t)^T P(t); S_nxt = S(t+1).
 #define MC_ATTN_BODY(S_cur, S_nxt)                                                                  \
   {                                                                                                  \
-    /* K(t+1), V(t) were issued two iterations ago; only the last iteration's 4 DMAs may be pending */ \
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                 \
+    /* K(t+1), V(t) were issued two iterations ago, K(t+2) early in the last one: only the two V   */ \
+    /* pieces issued last may still be in flight                                                    */ \
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                 \
     asm volatile("s_barrier" ::: "memory");                                                          \
     /* the slots freed by iteration t-1 are refilled inside the phases: K(t) -> K(t+3), V(t-1) -> V(t+2) */ \
     const uint32_t kdst_ = dma_lds + ((slot_k == 0) ? NST - 1 : slot_k - 1) * TILE_BYTES;            \
@@ -330,28 +346,26 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
     mask_partial(S_cur);                                                                             \
     decide(S_cur);                                                                                   \
     MC_PIN();                                                                                        \
-    { /* ---- phase 1 */                                                                             \
+    { /* ---- phase 1: fragment sets rotate x, y, z, w; x, y, z arrive pre-read */                      \
       const char* st_ = smem + slot_k * TILE_BYTES;                                                  \
-      bf16x8 k0_, k1_, n0_, n1_;                                                                     \
-      read_k(st_, 0, k0_, k1_);                                                                      \
-      MC_QK_STEP(S_cur, S_nxt, 0) MC_QK_STEP(S_cur, S_nxt, 1) MC_QK_STEP(S_cur, S_nxt, 2)            \
-      MC_QK_STEP(S_cur, S_nxt, 3) MC_QK_STEP(S_cur, S_nxt, 4) MC_QK_STEP(S_cur, S_nxt, 5)            \
-      MC_QK_STEP(S_cur, S_nxt, 6) MC_QK_STEP(S_cur, S_nxt, 7)                                        \
+      const char* stv_ = smem + slot_v * TILE_BYTES;                                                 \
+      MC_QK_STEP(S_cur, S_nxt, 0, kx0, kx1, kw0, kw1) MC_QK_STEP(S_cur, S_nxt, 1, ky0, ky1, kx0, kx1)  \
+      MC_QK_STEP(S_cur, S_nxt, 2, kz0, kz1, ky0, ky1) MC_QK_STEP(S_cur, S_nxt, 3, kw0, kw1, kz0, kz1)  \
+      MC_QK_STEP(S_cur, S_nxt, 4, kx0, kx1, kw0, kw1) MC_QK_STEP(S_cur, S_nxt, 5, ky0, ky1, kx0, kx1)  \
+      MC_QK_STEP(S_cur, S_nxt, 6, kz0, kz1, ky0, ky1) MC_QK_STEP(S_cur, S_nxt, 7, kw0, kw1, kz0, kz1) \
     }                                                                                                \
     { /* ---- phase 2 */                                                                             \
       const char* st_ = smem + slot_v * TILE_BYTES;                                                  \
-      bf16x8 va_, vb_, vc_;                                                                          \
+      const char* stk_ = smem + ((slot_k + 1 == NST) ? 0 : slot_k + 1) * TILE_BYTES; /* K(t+2) */    \
       float rm_[4];                                                                                  \
-      read_v(st_, 0, va_);                                                                           \
-      read_v(st_, 1, vb_);                                                                           \
-      MC_PV_STEP(S_cur, S_nxt, 0, va_, vc_) MC_PV_STEP(S_cur, S_nxt, 1, vb_, va_)                    \
-      MC_PV_STEP(S_cur, S_nxt, 2, vc_, vb_) MC_PV_STEP(S_cur, S_nxt, 3, va_, vc_)                    \
-      MC_PV_STEP(S_cur, S_nxt, 4, vb_, va_) MC_PV_STEP(S_cur, S_nxt, 5, vc_, vb_)                    \
-      MC_PV_STEP(S_cur, S_nxt, 6, va_, vc_) MC_PV_STEP(S_cur, S_nxt, 7, vb_, va_)                    \
-      MC_PV_STEP(S_cur, S_nxt, 8, vc_, vb_) MC_PV_STEP(S_cur, S_nxt, 9, va_, vc_)                    \
-      MC_PV_STEP(S_cur, S_nxt, 10, vb_, va_) MC_PV_STEP(S_cur, S_nxt, 11, vc_, vb_)                  \
-      MC_PV_STEP(S_cur, S_nxt, 12, va_, vc_) MC_PV_STEP(S_cur, S_nxt, 13, vb_, va_)                  \
-      MC_PV_STEP(S_cur, S_nxt, 14, vc_, vb_) MC_PV_STEP(S_cur, S_nxt, 15, va_, vc_)                  \
+      MC_PV_STEP(S_cur, S_nxt, 0, va_, ve_) MC_PV_STEP(S_cur, S_nxt, 1, vb_, va_)  \
+      MC_PV_STEP(S_cur, S_nxt, 2, vc_, vb_) MC_PV_STEP(S_cur, S_nxt, 3, vd_, vc_)  \
+      MC_PV_STEP(S_cur, S_nxt, 4, ve_, vd_) MC_PV_STEP(S_cur, S_nxt, 5, va_, ve_)  \
+      MC_PV_STEP(S_cur, S_nxt, 6, vb_, va_) MC_PV_STEP(S_cur, S_nxt, 7, vc_, vb_)  \
+      MC_PV_STEP(S_cur, S_nxt, 8, vd_, vc_) MC_PV_STEP(S_cur, S_nxt, 9, ve_, vd_)  \
+      MC_PV_STEP(S_cur, S_nxt, 10, va_, ve_) MC_PV_STEP(S_cur, S_nxt, 11, vb_, va_)  \
+      MC_PV_STEP(S_cur, S_nxt, 12, vc_, vb_) MC_PV_STEP(S_cur, S_nxt, 13, vd_, vc_)  \
+      MC_PV_STEP(S_cur, S_nxt, 14, ve_, vd_) MC_PV_STEP(S_cur, S_nxt, 15, va_, ve_) \
     }                                                                                                \
     l_run += rs0 + rs1;                                                                              \
     /* uses the sums inside this block: otherwise the adds are sunk into the next block and the */   \
