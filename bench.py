@@ -37,6 +37,19 @@ def flops_forward(cfg, L, Lc=512):
     return n * per_layer + 2 * L * 64 * d * 2
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/rNN/pmc_traffic.json,
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collected by tools/gpu_round.sh; counters cannot be read from
+    inside this process).  None if no such file."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            return json.load(open(f))[kernel]["bytes_per_launch"]
+        except (KeyError, ValueError, OSError):
+            continue
+    return None
+
+
 def timed(fn, sync, barrier):
     barrier()
     sync()
@@ -72,7 +85,8 @@ def kernel_rooflines(cfg, device):
     t = ev_time(lambda: H.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, heads, Lp, SEQ, 1, 128 ** -0.5), 5)
     fl = 4.0 * SEQ * SEQ * d
     res["attention"] = dict(bound="mfma", achieved=fl / t / 1e12, peak=2500.0, unit="TFLOP/s",
-                            frac=fl / t / 2.5e15, traffic=None, ms=t * 1e3, shape=f"L={SEQ} heads={heads} hd=128")
+                            frac=fl / t / 2.5e15, traffic=pmc_traffic("attn_fwd_v3_kernel"), ms=t * 1e3,
+                            shape=f"L={SEQ} heads={heads} hd=128")
     for name, (N, K, epi) in dict(gemm_qkv=(3 * d, d, 0), gemm_ffn1=(ffn, d, 1), gemm_ffn2=(d, ffn, 2),
                                   gemm_o=(d, d, 2)).items():
         A = torch.randn(Lp, K, generator=g, device=device).bfloat16()
@@ -218,7 +232,7 @@ def main():
         if world == 1 and not args.no_kernels:
             k = kernel_rooflines(cfg, device)
             line["roofline"] = {kk: k["attention"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-            line["roofline"]["kernel"] = "attn_fwd_kernel (self-attention, 71% of forward FLOPs)"
+            line["roofline"]["kernel"] = "attn_fwd_v3_kernel (self-attention, 71% of forward FLOPs, 64% of forward time)"
             line["kernels"] = k
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
