@@ -70,6 +70,31 @@ def test_forward_vs_oracle(golden, hip_model):
         assert MR.psnr(got.cpu().numpy(), ref_32.numpy(), data_range=float(ref_32.abs().max())) > 35.0
 
 
+def test_wan14b_widths_forward_vs_oracle():
+    """BASELINE.json config 4 (Wan2.1-T2V-14B) at its real widths -- d = 5120, 40 heads, ffn 13824 --
+    on a small latent grid and 2 layers, so the CPU oracle finishes in seconds: same tolerance as the
+    1.3B forward test."""
+    from magcache_amd.engine import WAN_T2V_14B
+    cfg = dict(WAN_T2V_14B, num_layers=2, text_len=64, text_dim=256)
+    grid = (2, 16, 16)
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    oracle = W.init_synthetic_(W.WanModel(**cfg), seed=3, std=0.02)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(16, *grid, generator=g)
+    ctx = torch.randn(33, cfg["text_dim"], generator=g)
+    t = torch.tensor([731.0])
+    ref_ac = oracle.forward([lat], t, [ctx], L, autocast=True)[0]
+    oracle.set_fp32_attention(True)
+    ref_32 = oracle.forward([lat], t, [ctx], L, autocast=False)[0]
+    cls = type("WanModelHIP14BWidths", (M.WanModelHIP,), {})
+    m = cls(cfg, grid, device=DEV, calibration=False)
+    m.load_state_dict(oracle.state_dict())
+    got = m([lat.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L)[0]
+    e_hip, e_ac = rel_l2(got, ref_32), rel_l2(ref_ac, ref_32)
+    assert e_hip < 2 * e_ac + 1e-3, (e_hip, e_ac)
+    assert rel_l2(got, ref_ac) < 2e-2
+
+
 def test_host_scalar_t_equals_device_t(golden, hip_model):
     g, meta, _ = golden
     x, ctx = torch.from_numpy(g["latent0"]).to(DEV), torch.from_numpy(g["ctx"]).to(DEV)

@@ -185,6 +185,30 @@ def test_attention_full_shape_properties(kernel_variant):
     torch.testing.assert_close(o[idx, h * 128:(h + 1) * 128].float(), want, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("name,L,heads", [("HunyuanVideo 720p 129f: 118800 image + 256 text tokens, 24 heads", 119056, 24),
+                                          ("FLUX.1-dev 512x512: 1024 image + 512 text tokens, 24 heads", 1536, 24),
+                                          ("Wan2.1-14B 720p 81f: 75600 tokens, 40 heads", 75600, 40)])
+def test_attention_other_config_shapes(name, L, heads):
+    """The joint-attention shapes of the other BASELINE.json configs (parity-test cases, not bench
+    lines): softmax rows sum to one (V = 1 -> O = 1) and 48 sampled rows of one head match the fp32
+    reference over the full key range."""
+    Lp = (L + 255) // 256 * 256
+    d = heads * 128
+    q = rnd(Lp, d, seed=1, dtype=torch.bfloat16)
+    k = rnd(Lp, d, seed=2, dtype=torch.bfloat16)
+    v = torch.ones(Lp, d, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(Lp, d, dtype=torch.bfloat16, device=DEV)
+    H.attention(q, k, v, o, heads, Lp, L, 1, 1 / math.sqrt(128))
+    assert float((o[:L].float() - 1).abs().max()) < 1e-2
+    v = rnd(Lp, d, seed=3, dtype=torch.bfloat16)
+    H.attention(q, k, v, o, heads, Lp, L, 1, 1 / math.sqrt(128))
+    idx = torch.randint(0, L, (48,), device=DEV)
+    h = heads - 1
+    s = q[idx, h * 128:(h + 1) * 128].float() @ k[:L, h * 128:(h + 1) * 128].float().t() / math.sqrt(128)
+    want = torch.softmax(s, -1) @ v[:L, h * 128:(h + 1) * 128].float()
+    torch.testing.assert_close(o[idx, h * 128:(h + 1) * 128].float(), want, rtol=2e-2, atol=2e-2)
+
+
 def test_attention_rejects_bad_shapes():
     q = rnd(100, 128, dtype=torch.bfloat16)
     o = torch.zeros_like(q)
