@@ -164,6 +164,12 @@ mc_status mc_op_calib_stats(const float* r_dev, long ldr, const float* rp_dev, l
                             mc_stream stream);
 mc_status mc_op_cfg_euler(const float* cond_dev, const float* uncond_dev, float guide, float dt, float* x_dev,
                           float* eps_out_dev, size_t n, mc_stream stream);
+/* out[i] = sum_j coef[j] * xs[j][i]: xs = HOST array of k (1..6) device pointers, coef = host array of k
+ * floats; out may alias an operand.  The sampler's solver updates around the model call -- CFG combine and
+ * the UniPC / DPM++ / Euler flow steps of the upstream pipeline (wan_magcache.py:296-310) -- are one launch
+ * each. */
+mc_status mc_op_lincomb(const float* const* xs_dev, const float* coef, int k, float* out_dev, size_t n,
+                        mc_stream stream);
 mc_status mc_op_cast_bf16(const float* src_dev, void* dst_bf16_dev, size_t n, mc_stream stream);
 /* rope table the engine builds for a latent grid: fp32 [n_tok][64][2] (cos, sin), upstream
  * wan/modules/model.py rope_params + rope_apply split (d-4*(d//6), 2*(d//6), 2*(d//6)), d = 128 */

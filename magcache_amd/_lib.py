@@ -68,6 +68,7 @@ SIGNATURES = {
     "mc_op_calib_stats": (_i, [_vp, _l, _vp, _l, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mc_op_cfg_euler": (_i, [_vp, _vp, _f, _f, _vp, _vp, _sz, _vp]),
     "mc_op_cast_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "mc_op_lincomb": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "mc_op_rope_table": (_i, [_i, _i, _i, _i, _i, _vp]),
 }
 

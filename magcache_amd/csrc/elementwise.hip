@@ -293,6 +293,22 @@ __global__ void cfg_euler_kernel(const float* __restrict__ cond, const float* __
   }
 }
 
+// out = sum_i a[i] * x[i] over up to 6 fp32 operands (null operands skipped; out may alias an operand):
+// the multistep solver updates (UniPC / DPM++ predictor and corrector, CFG combine) in one pass
+struct LinComb {
+  const float* x[6];
+  float a[6];
+};
+__global__ void lincomb_kernel(LinComb lc, float* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (lc.x[k]) acc = __builtin_fmaf(lc.a[k], lc.x[k][i], acc);
+    out[i] = acc;
+  }
+}
+
 inline int grid_for(long total, int block, int cap = 2048) {
   long g = (total + block - 1) / block;
   if (g < 1) g = 1;
@@ -384,6 +400,17 @@ hipError_t launch_head_linear(const float* xn, long ldx, const float* W, const f
   if (N > 64 || (K % 32) != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(head_linear_kernel, dim3((M + 63) / 64), dim3(256), 0, stream, xn, ldx, W, b, out, ldo, M, N,
                      K);
+  return hipGetLastError();
+}
+
+hipError_t launch_lincomb(const float* const* xs, const float* coef, int k, float* out, size_t n, hipStream_t stream) {
+  if (k < 1 || k > 6 || !out || n == 0) return hipErrorInvalidValue;
+  LinComb lc;
+  for (int i = 0; i < 6; ++i) {
+    lc.x[i] = i < k ? xs[i] : nullptr;
+    lc.a[i] = i < k ? coef[i] : 0.f;
+  }
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, stream, lc, out, n);
   return hipGetLastError();
 }
 

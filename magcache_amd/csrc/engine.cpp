@@ -739,6 +739,14 @@ mc_status mc_op_cfg_euler(const float* cond, const float* uncond, float guide, f
   return MC_OK;
 }
 
+mc_status mc_op_lincomb(const float* const* xs_dev, const float* coef, int k, float* out_dev, size_t n, mc_stream s) {
+  if (!xs_dev || !coef) return fail(MC_EINVAL, "null argument");
+  hipError_t err = mc::launch_lincomb(xs_dev, coef, k, out_dev, n, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "lincomb: 1..6 operands, non-empty output");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
 mc_status mc_op_cast_bf16(const float* src, void* dst, size_t n, mc_stream s) {
   HIP_TRY(mc::launch_cast_bf16(src, (bf16_t*)dst, n, (hipStream_t)s));
   return MC_OK;

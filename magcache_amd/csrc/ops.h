@@ -97,6 +97,10 @@ hipError_t launch_head_linear(const float* xn, long ldx, const float* W, const f
 hipError_t launch_cfg_euler(const float* cond, const float* uncond, float g, float dt, float* x, float* eps_out,
                             size_t n, hipStream_t stream);
 
+// out[i] = sum_j coef[j] * xs[j][i], 1 <= k <= 6 fp32 operands (host arrays of k pointers / coefficients);
+// out may alias an operand.  The multistep flow solvers (sampler.py) are built from this.
+hipError_t launch_lincomb(const float* const* xs, const float* coef, int k, float* out, size_t n, hipStream_t stream);
+
 // ---------------------------------------------------------------- MagCache ops (magcache_ops.hip)
 // out = x0 (bf16) + r (fp32)     -- the skipped-step path (reference :294-295)
 hipError_t launch_skip_add(const bf16_t* x0, long ldx0, const float* r, long ldr, float* out, long ldo, int M,

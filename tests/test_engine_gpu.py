@@ -95,6 +95,23 @@ def test_wan14b_widths_forward_vs_oracle():
     assert rel_l2(got, ref_ac) < 2e-2
 
 
+@pytest.mark.parametrize("solver", ["unipc", "dpm++"])
+def test_sampler_multistep_solvers_run_on_engine(golden, hip_model, solver):
+    """the upstream default solvers around the MagCache-wrapped engine: finite result, same skip schedule
+    as Euler (the schedule depends on the call count only), and a final latent close to the Euler one
+    (same ODE, few steps: > 20 dB)"""
+    g, meta, _ = golden
+    x = torch.from_numpy(g["latent0"]).to(DEV)
+    ctx, ctxn = torch.from_numpy(g["ctx"]).to(DEV), torch.from_numpy(g["ctx_null"]).to(DEV)
+    finals = {}
+    for sv in ("euler", solver):
+        M.init_magcache(hip_model, meta["steps"], meta["thresh"], meta["K"], meta["R"], mag_ratios=TABLES[meta["table"]])
+        finals[sv] = sample(hip_model, x, ctx, ctxn, sampling_steps=meta["steps"], shift=meta["shift"],
+                            guide_scale=meta["guide"], solver=sv).cpu().numpy()
+        assert hip_model.cnt == 0 and np.isfinite(finals[sv]).all()
+    assert MR.psnr(finals[solver], finals["euler"], data_range=float(np.abs(finals["euler"]).max())) > 20.0
+
+
 def test_host_scalar_t_equals_device_t(golden, hip_model):
     g, meta, _ = golden
     x, ctx = torch.from_numpy(g["latent0"]).to(DEV), torch.from_numpy(g["ctx"]).to(DEV)

@@ -3,6 +3,7 @@ op (floating-point kernels; tolerances stated per test), plus size-independent p
 full Wan2.1-1.3B 480p shape (L = 32760, d = 1536, 12 heads)."""
 import math
 
+import numpy as np  # noqa: F401
 import pytest
 import torch
 import torch.nn.functional as F
@@ -309,3 +310,30 @@ def test_calib_stats_matches_torch_ops():
     # idempotence / edge: identical slabs -> ratio 1, std 0, cos distance 0
     stats, _ = H.calib_stats(rp, rp)
     assert abs(float(stats[0]) - 1) < 1e-6 and float(stats[1]) < 1e-6 and abs(float(stats[2])) < 1e-6
+
+
+# ----------------------------------------------------------------------------- sampler kernels
+def test_lincomb_and_flow_solver_on_device():
+    """mc_op_lincomb (the one kernel behind CFG + UniPC / DPM++ / Euler updates) vs torch, and the device
+    FlowSolver trajectory vs the numpy oracle on a cheap analytic velocity field."""
+    from magcache_amd.sampler import FlowSolver, lincomb_hip
+    from oracle import flow_solvers_ref as FR
+    xs = [rnd(16, 21, 60, 104, seed=i) for i in range(5)]
+    cf = [0.5, -1.25, 2.0, 1e-3, -7.0]
+    got = lincomb_hip(cf, xs)
+    want = sum(c * x.double() for c, x in zip(cf, xs)).float()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    out = xs[0].clone()
+    lincomb_hip([1.0, 0.25], [out, xs[1]], out=out)       # in place, aliasing an operand
+    torch.testing.assert_close(out, xs[0] + 0.25 * xs[1], rtol=1e-6, atol=1e-6)
+    model = lambda x, s: (0.3 * x + s)                     # linear in x: same formula for numpy and torch
+    sig = FR.shifted_sigmas(12, 5.0)
+    x0 = rnd(4096, seed=9)
+    for solver in ("euler", "unipc", "dpm++"):
+        fs = FlowSolver(sig, solver)
+        x = x0.clone()
+        for i in range(12):
+            x = fs.step(i, x, model(x, float(sig[i])).contiguous())
+        want = FR.solve(model, x0.double().cpu().numpy(), sig, solver)
+        np_got = x.double().cpu().numpy()
+        assert float(abs(np_got - want).max()) < 1e-4 * float(abs(want).max() + 1), solver
