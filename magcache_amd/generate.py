@@ -1,0 +1,189 @@
+"""`python -m magcache_amd.generate` -- the reference's `magcache_generate.py` entry point on the HIP engine.
+
+Same flags, defaults and argument validation as MagCache4Wan2.1/magcache_generate.py (`_parse_args`
+:598-775, `_validate_args` :563-595) for everything that reaches the denoising hot path:
+
+    --task --size --frame_num --ckpt_dir --base_seed --sample_solver --sample_steps --sample_shift
+    --sample_guide_scale --use_magcache --magcache_thresh --magcache_K --retention_ratio
+    --magcache_calibration --save_file --prompt
+
+What is outside the hot path and absent offline is declared, not faked: there is no T5 text encoder and
+no VAE in this repository (out of scope).  So
+  * the text context is read from `--context_file` / `--context_null_file` (torch tensors [len<=512, 4096],
+    e.g. dumped from the upstream pipeline), or, without them, is a seeded synthetic stand-in;
+  * DiT weights are loaded from `--ckpt_dir` if it holds the upstream `*.safetensors`, otherwise they are
+    seeded random-init weights of the named architecture (a warning says so);
+  * the result saved to `--save_file` is the final LATENT ([16, F, H/8, W/8] fp32, torch.save), which the
+    upstream pipeline would hand to its VAE decoder.
+The flags that only concern those parts (--t5_cpu, --offload_model, prompt extension, FSDP, ...) are accepted
+and ignored so that existing command lines keep working.  Multi-GPU: launch with torchrun; the token
+sequence is sharded over the ranks (magcache_amd/parallel.py) instead of the reference's xfuser USP.
+"""
+import argparse
+import glob
+import hashlib
+import logging
+import os
+import random
+import sys
+import time
+
+# upstream wan/configs: SIZE_CONFIGS / SUPPORTED_SIZES for the tasks this engine implements
+SIZE_CONFIGS = {"720*1280": (720, 1280), "1280*720": (1280, 720), "480*832": (480, 832), "832*480": (832, 480),
+                "1024*1024": (1024, 1024)}
+SUPPORTED_SIZES = {"t2v-14B": ("720*1280", "1280*720", "480*832", "832*480"), "t2v-1.3B": ("480*832", "832*480"),
+                   "t2i-14B": tuple(SIZE_CONFIGS.keys())}
+EXAMPLE_PROMPT = "Two anthropomorphic cats in comfy boxing gear and bright gloves fight intensely on a spotlighted stage."
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected (True/False)")
+
+
+def _validate_args(args):
+    """magcache_generate.py:563-595"""
+    assert args.task in SUPPORTED_SIZES, f"Unsupport task: {args.task} (this engine: {', '.join(SUPPORTED_SIZES)})"
+    if args.sample_steps is None:
+        args.sample_steps = 50
+    if args.sample_shift is None:
+        args.sample_shift = 5.0
+    if args.frame_num is None:
+        args.frame_num = 1 if "t2i" in args.task else 81
+    if "t2i" in args.task:
+        assert args.frame_num == 1, f"Unsupport frame_num {args.frame_num} for task {args.task}"
+    args.base_seed = args.base_seed if args.base_seed >= 0 else random.randint(0, sys.maxsize)
+    assert args.size in SUPPORTED_SIZES[args.task], \
+        f"Unsupport size {args.size} for task {args.task}, supported sizes are: {', '.join(SUPPORTED_SIZES[args.task])}"
+    assert (args.frame_num - 1) % 4 == 0, "frame_num must be 4n+1 (VAE temporal stride 4)"
+
+
+def _parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Denoise a Wan2.1 latent with MagCache on the MI355X HIP engine")
+    p.add_argument("--task", type=str, default="t2v-14B", choices=list(SUPPORTED_SIZES.keys()))
+    p.add_argument("--size", type=str, default="1280*720", choices=list(SIZE_CONFIGS.keys()))
+    p.add_argument("--frame_num", type=int, default=None)
+    p.add_argument("--ckpt_dir", type=str, default=None)
+    p.add_argument("--save_file", type=str, default=None)
+    p.add_argument("--prompt", type=str, default=None)
+    p.add_argument("--base_seed", type=int, default=-1)
+    p.add_argument("--sample_solver", type=str, default="unipc", choices=["unipc", "dpm++", "euler"])
+    p.add_argument("--sample_steps", type=int, default=None)
+    p.add_argument("--sample_shift", type=float, default=None)
+    p.add_argument("--sample_guide_scale", type=float, default=5.0)
+    p.add_argument("--magcache_thresh", type=float, default=0.12)
+    p.add_argument("--retention_ratio", type=float, default=0.2)
+    p.add_argument("--magcache_K", type=int, default=2)
+    p.add_argument("--use_magcache", action="store_true", default=False)
+    p.add_argument("--magcache_calibration", action="store_true", default=False)
+    # inputs that replace the absent text encoder
+    p.add_argument("--context_file", type=str, default=None, help="torch tensor [len<=512, 4096]: T5 embedding of the prompt")
+    p.add_argument("--context_null_file", type=str, default=None, help="the same for the negative prompt")
+    # accepted for command-line compatibility; they configure parts that are not in this repository
+    for flag, kw in (("--offload_model", dict(type=str2bool, default=None)), ("--ulysses_size", dict(type=int, default=1)),
+                     ("--ring_size", dict(type=int, default=1)), ("--t5_fsdp", dict(action="store_true")),
+                     ("--t5_cpu", dict(action="store_true")), ("--dit_fsdp", dict(action="store_true")),
+                     ("--use_prompt_extend", dict(action="store_true")),
+                     ("--prompt_extend_method", dict(type=str, default="local_qwen")),
+                     ("--prompt_extend_model", dict(type=str, default=None)),
+                     ("--prompt_extend_target_lang", dict(type=str, default="zh")),
+                     ("--image", dict(type=str, default=None)), ("--src_video", dict(type=str, default=None)),
+                     ("--src_mask", dict(type=str, default=None)), ("--src_ref_images", dict(type=str, default=None)),
+                     ("--first_frame", dict(type=str, default=None)), ("--last_frame", dict(type=str, default=None))):
+        p.add_argument(flag, **kw)
+    args = p.parse_args(argv)
+    _validate_args(args)
+    return args
+
+
+def _context(path, prompt, seed, text_dim, device):
+    import torch
+    if path:
+        c = torch.load(path, map_location="cpu")
+        c = c[0] if isinstance(c, (list, tuple)) else c
+        assert c.dim() == 2 and c.shape[0] <= 512 and c.shape[1] == text_dim, f"context {tuple(c.shape)}"
+        return c.float().to(device)
+    h = int(hashlib.sha256((prompt or "").encode()).hexdigest()[:8], 16)
+    g = torch.Generator(device="cpu").manual_seed(seed ^ h)
+    n = max(8, min(512, len((prompt or "").split()) * 2 + 2))   # a stand-in of plausible length, zero padded by the engine
+    return torch.randn(n, text_dim, generator=g).to(device)
+
+
+def generate(args):
+    import torch
+    import torch.distributed as dist
+    import magcache_amd as mca
+    from magcache_amd import model as M
+    from magcache_amd.engine import WAN_T2V_1_3B, WAN_T2V_14B, synthetic_weights
+
+    rank, world = int(os.getenv("RANK", 0)), int(os.getenv("WORLD_SIZE", 1))
+    local = int(os.getenv("LOCAL_RANK", 0))
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.ERROR,
+                        format="[%(asctime)s] %(levelname)s: %(message)s", handlers=[logging.StreamHandler(sys.stdout)])
+    device = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(device))
+        seed = [args.base_seed] if rank == 0 else [None]
+        dist.broadcast_object_list(seed, src=0)      # magcache_generate.py:852-855
+        args.base_seed = seed[0]
+    if args.ulysses_size > 1 or args.ring_size > 1:
+        logging.info("--ulysses_size/--ring_size are ignored: the token sequence is sharded over WORLD_SIZE ranks")
+
+    cfg = WAN_T2V_1_3B if "1.3B" in args.task else WAN_T2V_14B
+    H, W = SIZE_CONFIGS[args.size][1], SIZE_CONFIGS[args.size][0]
+    grid = ((args.frame_num - 1) // 4 + 1, H // 8, W // 8)
+    logging.info(f"Generation job args: {args}")
+    logging.info(f"latent grid {grid}, {grid[0] * (grid[1] // 2) * (grid[2] // 2)} tokens, {cfg['num_layers']} layers d={cfg['dim']}")
+    model = M.WanModelHIP(cfg, grid, device=device, calibration=args.magcache_calibration, sp_rank=rank, sp_size=world)
+
+    files = sorted(glob.glob(os.path.join(args.ckpt_dir or "", "*.safetensors")))
+    if files:
+        from safetensors.torch import load_file
+        sd = {}
+        for f in files:
+            sd.update(load_file(f, device="cpu"))
+        model.load_state_dict(sd)
+        logging.info(f"loaded {len(sd)} tensors from {args.ckpt_dir}")
+    else:
+        logging.warning("no *.safetensors under --ckpt_dir: using seeded RANDOM-INIT weights of the architecture")
+        model.engine.load_weights(synthetic_weights(cfg, seed=0, device=device))
+
+    if args.use_magcache:
+        name = args.ckpt_dir or ("Wan2.1-T2V-1.3B" if "1.3B" in args.task else "Wan2.1-T2V-14B")
+        if "T2V-1.3B" not in name and "T2V-14B" not in name:
+            name = "Wan2.1-T2V-1.3B" if "1.3B" in args.task else "Wan2.1-T2V-14B"
+        mca.init_magcache(model, args.sample_steps, args.magcache_thresh, args.magcache_K, args.retention_ratio,
+                          ckpt_dir=name)                                         # :896-919
+    if args.magcache_calibration:
+        mca.init_magcache_calibration(model, args.sample_steps)                   # :921-928
+
+    prompt = args.prompt or EXAMPLE_PROMPT
+    ctx = _context(args.context_file, prompt, args.base_seed, cfg["text_dim"], device)
+    ctx_null = _context(args.context_null_file, "", args.base_seed + 1, cfg["text_dim"], device)
+    g = torch.Generator(device=device).manual_seed(args.base_seed)
+    noise = torch.randn(16, *grid, dtype=torch.float32, device=device, generator=g)      # wan_magcache.py:243-251
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    latent = mca.sample(model, noise, ctx, ctx_null, sampling_steps=args.sample_steps, shift=args.sample_shift,
+                        guide_scale=args.sample_guide_scale, solver=args.sample_solver)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    logging.info(f"denoising: {dt:.2f} s, {args.sample_steps / dt:.3f} steps/s")
+    if rank == 0:
+        out = args.save_file or f"{args.task}_{args.size.replace('*', 'x')}_{args.base_seed}_latent.pt"
+        torch.save(latent.cpu(), out)
+        logging.info(f"Saving the final latent to {out} (no VAE decoder in this repository)")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return latent
+
+
+if __name__ == "__main__":
+    generate(_parse_args())

@@ -226,3 +226,20 @@ def test_sequence_parallel_two_ranks_one_gpu(tmp_path):
     assert res["rel_full"] < 1e-3, res          # same kernels, different tiling of the key loop only
     assert res["rel_skip"] < 1e-3, res
     assert res["rel_calib"] < 1e-4, res
+
+
+def test_generate_entry_point_short_run(tmp_path):
+    """python -m magcache_amd.generate with the reference's flags (5 frames, 6 steps so it stays a test):
+    MagCache schedule active, UniPC solver, latent of the right shape written to --save_file"""
+    from magcache_amd import generate as G
+    out = tmp_path / "latent.pt"
+    args = G._parse_args(["--task", "t2v-1.3B", "--size", "832*480", "--frame_num", "5", "--sample_steps", "6",
+                          "--base_seed", "42", "--use_magcache", "--magcache_K", "2", "--retention_ratio", "0.2",
+                          "--save_file", str(out), "--prompt", "a cat boxing"])
+    try:
+        lat = G.generate(args)
+    finally:
+        M.WanModelHIP.forward = M.plain_forward      # generate() patches the class, like the reference does
+    got = torch.load(out)
+    assert tuple(got.shape) == (16, 2, 60, 104) and bool(torch.isfinite(got).all())
+    assert torch.equal(got, lat.cpu())

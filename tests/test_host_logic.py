@@ -198,3 +198,23 @@ def test_skip_before_any_residual_is_an_error():
     m.engine.residual = lambda p: None
     with pytest.raises(RuntimeError):
         m(["x"], t=0, context=["c"], seq_len=4)
+
+
+# ----------------------------------------------------------------------------- generate.py CLI
+def test_generate_cli_defaults_and_validation():
+    """the flags, defaults and checks of the reference's _parse_args / _validate_args
+    (MagCache4Wan2.1/magcache_generate.py:563-595, :598-775) for the hot-path arguments"""
+    from magcache_amd import generate as G
+    a = G._parse_args(["--task", "t2v-1.3B", "--size", "832*480", "--ckpt_dir", "./Wan2.1-T2V-1.3B", "--base_seed", "42",
+                       "--use_magcache", "--magcache_K", "4", "--offload_model", "True", "--t5_cpu"])
+    assert (a.sample_steps, a.sample_shift, a.frame_num, a.sample_guide_scale) == (50, 5.0, 81, 5.0)
+    assert (a.magcache_thresh, a.retention_ratio, a.magcache_K, a.use_magcache, a.magcache_calibration) == \
+        (0.12, 0.2, 4, True, False)
+    assert a.sample_solver == "unipc" and a.base_seed == 42
+    d = G._parse_args(["--task", "t2v-14B"])
+    assert d.size == "1280*720" and d.magcache_K == 2 and d.base_seed >= 0
+    with pytest.raises(AssertionError):
+        G._parse_args(["--task", "t2v-1.3B", "--size", "1280*720"])          # unsupported size for the task
+    with pytest.raises(AssertionError):
+        G._parse_args(["--task", "t2i-14B", "--size", "1024*1024", "--frame_num", "5"])
+    assert G._parse_args(["--task", "t2i-14B", "--size", "1024*1024"]).frame_num == 1
