@@ -151,16 +151,26 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernels", action="store_true")
     ap.add_argument("--no_nocache", action="store_true", help="skip the second (cache off) timed region")
+    ap.add_argument("--no_cfg_parallel", action="store_true",
+                    help="N > 1: shard the sequence over all N ranks instead of CFG branches x N/2")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    backend = os.environ.get("MC_BENCH_BACKEND", "nccl")   # tests: "gloo" runs N ranks on ONE GPU
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
+    layout = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
+        from magcache_amd.parallel import ParallelLayout
+        layout = ParallelLayout(cfg_parallel=not args.no_cfg_parallel)
 
     from magcache_amd import model as M
     from magcache_amd.engine import WAN_T2V_1_3B, synthetic_weights
@@ -168,7 +178,9 @@ def main():
     from magcache_amd.sampler import sample
 
     cfg = WAN_T2V_1_3B
-    model = M.WanModelHIP(cfg, GRID, device=device, calibration=False, sp_rank=rank, sp_size=world)
+    model = M.WanModelHIP(cfg, GRID, device=device, calibration=False,
+                          sp_rank=layout.sp_rank if layout else 0, sp_size=layout.sp_size if layout else 1,
+                          sp_group=layout.sp_group if layout else None)
     model.engine.load_weights(synthetic_weights(cfg, seed=0, device=device))
     g = torch.Generator(device=device).manual_seed(42)
     noise = torch.randn(16, *GRID, generator=g, device=device)
@@ -180,7 +192,7 @@ def main():
 
     def run(steps):
         return sample(model, noise, ctx, ctx_null, sampling_steps=steps, shift=args.shift,
-                      guide_scale=args.guide_scale)
+                      guide_scale=args.guide_scale, layout=layout)
 
     M.disable_magcache(model)
     if args.warmup > 0:
@@ -194,6 +206,11 @@ def main():
     t_mc, lat_mc = timed(lambda: run(args.steps), sync, barrier)
     model._run = fwd
     skipped = int(sum(1 for m in modes if m == 1))
+    if world > 1:
+        # one count per CFG branch / per job: the first rank of every sequence-parallel group reports
+        cnt = torch.tensor([skipped if layout.sp_rank == 0 else 0], device=device, dtype=torch.int64)
+        dist.all_reduce(cnt)
+        skipped = int(cnt[0])
     # ---- timed region 2: the same K steps with the cache off
     t_nc, psnr = None, None
     if not args.no_nocache:
@@ -220,7 +237,7 @@ def main():
                                    "synthetic latents/contexts, random-init weights",
                        "magcache_thresh": args.magcache_thresh, "magcache_K": args.magcache_K,
                        "retention_ratio": args.retention_ratio, "sampling_steps": args.steps,
-                       "parallelism": "single GPU" if world == 1 else f"sequence-parallel sp{world} (K/V all-gather)"},
+                       "parallelism": "single GPU" if world == 1 else layout.describe()},
             "forwards_skipped": skipped, "forwards_total": 2 * args.steps,
             "speedup_bound": (2 * args.steps) / max(ran, 1),
             "nocache_steps_per_s": (args.steps / t_nc) if t_nc else None,

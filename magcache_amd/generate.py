@@ -16,8 +16,9 @@ no VAE in this repository (out of scope).  So
   * the result saved to `--save_file` is the final LATENT ([16, F, H/8, W/8] fp32, torch.save), which the
     upstream pipeline would hand to its VAE decoder.
 The flags that only concern those parts (--t5_cpu, --offload_model, prompt extension, FSDP, ...) are accepted
-and ignored so that existing command lines keep working.  Multi-GPU: launch with torchrun; the token
-sequence is sharded over the ranks (magcache_amd/parallel.py) instead of the reference's xfuser USP.
+and ignored so that existing command lines keep working.  Multi-GPU: launch with torchrun; the two CFG
+branches run on two halves of the node and the token sequence is sharded inside each half
+(magcache_amd/parallel.py) instead of the reference's xfuser USP.
 """
 import argparse
 import glob
@@ -132,6 +133,11 @@ def generate(args):
         seed = [args.base_seed] if rank == 0 else [None]
         dist.broadcast_object_list(seed, src=0)      # magcache_generate.py:852-855
         args.base_seed = seed[0]
+    layout = None
+    if world > 1:
+        from magcache_amd.parallel import ParallelLayout
+        layout = ParallelLayout(cfg_parallel=not args.magcache_calibration)   # calibration needs both branches per rank
+        logging.info(f"parallel layout: {layout.describe()}")
     if args.ulysses_size > 1 or args.ring_size > 1:
         logging.info("--ulysses_size/--ring_size are ignored: the token sequence is sharded over WORLD_SIZE ranks")
 
@@ -140,7 +146,9 @@ def generate(args):
     grid = ((args.frame_num - 1) // 4 + 1, H // 8, W // 8)
     logging.info(f"Generation job args: {args}")
     logging.info(f"latent grid {grid}, {grid[0] * (grid[1] // 2) * (grid[2] // 2)} tokens, {cfg['num_layers']} layers d={cfg['dim']}")
-    model = M.WanModelHIP(cfg, grid, device=device, calibration=args.magcache_calibration, sp_rank=rank, sp_size=world)
+    model = M.WanModelHIP(cfg, grid, device=device, calibration=args.magcache_calibration,
+                          sp_rank=layout.sp_rank if layout else 0, sp_size=layout.sp_size if layout else 1,
+                          sp_group=layout.sp_group if layout else None)
 
     files = sorted(glob.glob(os.path.join(args.ckpt_dir or "", "*.safetensors")))
     if files:
@@ -171,7 +179,7 @@ def generate(args):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     latent = mca.sample(model, noise, ctx, ctx_null, sampling_steps=args.sample_steps, shift=args.sample_shift,
-                        guide_scale=args.sample_guide_scale, solver=args.sample_solver)
+                        guide_scale=args.sample_guide_scale, solver=args.sample_solver, layout=layout)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     logging.info(f"denoising: {dt:.2f} s, {args.sample_steps / dt:.3f} steps/s")

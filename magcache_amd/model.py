@@ -61,7 +61,8 @@ class WanModelHIP:
     model_type = "t2v"
     patch_size = (1, 2, 2)
 
-    def __init__(self, cfg, latent_grid, device="cuda:0", calibration=True, engine=None, sp_rank=0, sp_size=1):
+    def __init__(self, cfg, latent_grid, device="cuda:0", calibration=True, engine=None, sp_rank=0, sp_size=1,
+                 sp_group=None):
         self.cfg = dict(cfg)
         for k in ("dim", "ffn_dim", "freq_dim", "text_len", "text_dim", "in_dim", "out_dim", "num_heads",
                   "num_layers"):
@@ -70,6 +71,7 @@ class WanModelHIP:
         self.engine = engine or Engine(cfg, latent_grid, device=device, n_branches=2, calibration=calibration,
                                        sp_rank=sp_rank, sp_size=sp_size)
         self.device = self.engine.device
+        self.sp_group = sp_group      # torch.distributed group of the ranks that share this token sequence
 
     def load_state_dict(self, state_dict):
         self.engine.load_weights(state_dict)
@@ -93,7 +95,7 @@ class WanModelHIP:
         if self.engine.sp_size > 1:
             if getattr(self, "_sp", None) is None:
                 from .parallel import SequenceParallelForward
-                self._sp = SequenceParallelForward(self.engine)
+                self._sp = SequenceParallelForward(self.engine, group=self.sp_group)
             out = self._sp.forward(lat, t, ctx, branch, mode)
         else:
             out = self.engine.forward(lat, t, ctx, branch=branch, mode=mode)
@@ -178,6 +180,21 @@ def magcache_calibration(self, x, t, context, seq_len, clip_fea=None, y=None):
                       ("wan2_1_cos_dis", self.cos_dis)):
             with open(fn + ".json", "w") as f:
                 json.dump(v, f)
+    return out
+
+
+def call_branch(model, step, branch, x, t, context, seq_len):
+    """One forward of ONE CFG branch at sampler step `step` (CFG-parallel layouts: this rank never sees the
+    other branch's call).  The reference's counter runs over both branches (cnt = 2*step + branch selects
+    mag_ratios[cnt] and the state slot cnt % 2, :279-292); it is positioned before the call, and the skipped
+    sibling call is accounted for afterwards so that the end-of-video reset (:306-311) happens as usual."""
+    cls = type(model)
+    has_state = getattr(cls, "forward", None) in (magcache_forward, magcache_calibration)
+    if has_state:
+        model.cnt = 2 * step + branch
+    out = model(x, t=t, context=context, seq_len=seq_len)
+    if has_state and branch == 0:
+        _advance(model)                    # the uncond call made by the other half of the node
     return out
 
 

@@ -20,13 +20,68 @@ import torch.distributed as dist
 from ._lib import MC_MODE_CALIB, MC_MODE_SKIP
 
 
+class ParallelLayout:
+    """How the ranks of one node split one denoising job.
+
+    cfg x sp:  with an even world size the two classifier-free-guidance branches run on two halves of
+    the node (cfg_size = 2; the in-tree precedent is videosys/models/transformers/
+    open_sora_transformer_3d.py:443-451) and the token sequence is sharded inside each half
+    (sp_size = world / 2).  The branches are independent forwards with independent MagCache slots
+    (reference state is indexed by cnt % 2, magcache_generate.py:281-301), so the only traffic between
+    the halves is the 8 MB prediction of each step, exchanged inside rank pairs {r, r + sp_size}; the
+    per-layer K/V all-gather stays inside a half and moves half the bytes over half the peers.  With an
+    odd world size (or cfg_parallel=False) everything is sequence parallel.
+
+    branch : the CFG branch this rank evaluates (0 cond, 1 uncond) or None (both, sequentially)
+    sp_group / pair_group : torch.distributed groups (None = the default group / no pair)."""
+
+    def __init__(self, world=None, rank=None, cfg_parallel=True):
+        self.world = dist.get_world_size() if world is None else world
+        self.rank = dist.get_rank() if rank is None else rank
+        self.cfg_size = 2 if (cfg_parallel and self.world % 2 == 0) else 1
+        self.sp_size = self.world // self.cfg_size
+        self.branch = self.rank // self.sp_size if self.cfg_size == 2 else None
+        self.sp_rank = self.rank % self.sp_size
+        self.sp_group = None
+        self.pair_group = None
+        if self.cfg_size == 2 and dist.is_initialized():
+            # every rank must create every group, in the same order
+            for b in range(2):
+                ranks = list(range(b * self.sp_size, (b + 1) * self.sp_size))
+                g = dist.new_group(ranks) if self.sp_size > 1 else None
+                if b == self.branch:
+                    self.sp_group = g
+            for r in range(self.sp_size):
+                g = dist.new_group([r, r + self.sp_size])
+                if r == self.sp_rank:
+                    self.pair_group = g
+
+    def describe(self):
+        if self.world == 1:
+            return "single GPU"
+        if self.cfg_size == 2:
+            return f"cfg2 x sp{self.sp_size} (CFG branches on two halves, K/V all-gather inside a half)"
+        return f"sequence-parallel sp{self.sp_size} (K/V all-gather)"
+
+    def exchange(self, eps):
+        """(eps_cond, eps_uncond) from this rank's prediction and its pair's."""
+        buf = torch.empty((2,) + tuple(eps.shape), dtype=eps.dtype, device=eps.device)
+        if dist.get_backend(self.pair_group) == "nccl":
+            dist.all_gather_into_tensor(buf, eps.contiguous(), group=self.pair_group)
+        else:
+            parts = [torch.empty_like(eps) for _ in range(2)]
+            dist.all_gather(parts, eps.contiguous(), group=self.pair_group)
+            buf[0], buf[1] = parts[0], parts[1]
+        return buf[0], buf[1]
+
+
 class SequenceParallelForward:
     def __init__(self, engine, group=None):
         self.e = engine
         self.group = group
         self.P = engine.sp_size
         self.rank = engine.sp_rank
-        assert dist.is_initialized() and dist.get_world_size(group) == self.P
+        assert dist.is_initialized() and dist.get_world_size(group) == self.P, (dist.get_world_size(group), self.P)
         self.inplace = dist.get_backend(group) == "nccl"
         cfg = engine.cfg
         self.d, self.NL = cfg["dim"], cfg["num_layers"]

@@ -148,23 +148,37 @@ class FlowSolver:
 
 
 def sample(model, noise, context, context_null, sampling_steps=50, shift=5.0, guide_scale=5.0, seq_len=None,
-           callback=None, solver="euler"):
+           callback=None, solver="euler", layout=None, lincomb=None):
     """Run the denoising loop; returns the final latent (fp32 [C,F,H,W]).  `model` is called like the
-    upstream model: model([latent], t=timestep, context=[ctx], seq_len=seq_len)[0]."""
+    upstream model: model([latent], t=timestep, context=[ctx], seq_len=seq_len)[0].  `layout`
+    (parallel.ParallelLayout) with cfg_size == 2: this rank runs one CFG branch per step and swaps the
+    prediction with its pair rank; every rank then applies the same update to its replica of the latent."""
     sig, ts = flow_timesteps(sampling_steps, shift)
     device = noise.device
     t_dev = torch.tensor(ts, dtype=torch.float32, device=device)
     latent = noise.clone().float().contiguous()
     seq_len = seq_len or model.engine.seq_len
-    fs = FlowSolver(sig, solver) if solver != "euler" else None
+    lc = lincomb or lincomb_hip      # tests of the orchestration inject a host implementation
+    fs = FlowSolver(sig, solver, lincomb=lc) if solver != "euler" else None
+    cfg_par = layout is not None and layout.cfg_size == 2
     for i in range(sampling_steps):
         timestep = t_dev[i:i + 1]
-        eps_c = model([latent], t=timestep, context=[context], seq_len=seq_len)[0]
-        eps_u = model([latent], t=timestep, context=[context_null], seq_len=seq_len)[0]
-        if fs is None:
-            cfg_euler_(latent, eps_c, eps_u, guide_scale, float(sig[i + 1] - sig[i]))
+        if cfg_par:
+            # this rank evaluates one CFG branch; the pair {cond rank, uncond rank} swaps predictions
+            from .model import call_branch
+            mine = call_branch(model, i, layout.branch, [latent], timestep,
+                               [context if layout.branch == 0 else context_null], seq_len)[0]
+            eps_c, eps_u = layout.exchange(mine.contiguous())
         else:
-            v = lincomb_hip([1.0 - guide_scale, guide_scale], [eps_u.contiguous(), eps_c.contiguous()])  # CFG
+            eps_c = model([latent], t=timestep, context=[context], seq_len=seq_len)[0]
+            eps_u = model([latent], t=timestep, context=[context_null], seq_len=seq_len)[0]
+        if fs is None and lincomb is None:
+            cfg_euler_(latent, eps_c, eps_u, guide_scale, float(sig[i + 1] - sig[i]))
+        elif fs is None:
+            dt = float(sig[i + 1] - sig[i])
+            latent = lc([1.0, dt * (1.0 - guide_scale), dt * guide_scale], [latent, eps_u, eps_c])
+        else:
+            v = lc([1.0 - guide_scale, guide_scale], [eps_u.contiguous(), eps_c.contiguous()])  # CFG
             latent = fs.step(i, latent, v)
         if callback is not None:
             callback(i, latent)

@@ -21,3 +21,28 @@ def test_sequence_parallel_orchestration_gloo(tmp_path):
         assert x["rel_full"] < 1e-2, x
         assert x["rel_skip"] < 1e-2, x
         assert x["calib_err"] < 1e-3, x
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world,port", [(2, 29541), (4, 29543)])
+def test_cfg_parallel_sampler_gloo(tmp_path, world, port):
+    """cfg2 x sp(world/2): every rank runs ONE CFG branch per step with the reference's counter placed at
+    2*step + branch, pairs swap predictions; the final latent, the per-branch call/skip sequence and the
+    end-of-video counter state must equal the sequential two-calls-per-step loop."""
+    out = tmp_path / "cfg.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "gloo_cfg_worker.py"), str(out)]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert len(res) == world
+    for x in res:
+        assert x["cfg_size"] == 2 and x["sp_size"] == world // 2 and x["branch"] == x["rank"] // (world // 2)
+        for solver in ("euler", "unipc"):
+            assert x[solver]["equal"], x
+            assert x[solver]["calls_match"], x
+            assert x[solver]["skipped"] > 0, x
+            assert x[solver]["state_par"][0] == 0 == x[solver]["state_seq"][0]   # cnt reset at the end (:306-311)
