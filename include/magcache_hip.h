@@ -112,6 +112,11 @@ mc_status mc_unpatchify(mc_engine* e, const float* tokens_dev, int tok0, int n_t
 mc_status mc_calib_ready(const mc_engine* e, int branch, int* has_stats);
 mc_status mc_calib_finalize(mc_engine* e, int branch, mc_stream stream);
 mc_status mc_state_reset(mc_engine* e); /* forget cached residuals (new video) */
+/* residual_cache[branch] = src (fp32 [tokens of this rank, dim], device).  The reference keeps the cache
+ * on the model CLASS, so Wan2.2's two experts (two model instances = two engines) read each other's
+ * entries (MagCache4Wan2.2/magcache_generate.py:340-352 and the shared residual_cache[cnt%2] of :309-322);
+ * the Python shim forwards an entry that lives in another engine through this call before a skip. */
+mc_status mc_import_residual(mc_engine* e, int branch, const float* src_dev, mc_stream stream);
 
 /* ---- host-side MagCache decision rule (reference :277-292, :306-311 and its per-model twins) --
  * Pure host arithmetic, never touches the device.  variant: see MC_RULE_*. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mc_calib_ready": (_i, [_vp, _i, C.POINTER(_i)]),
     "mc_calib_finalize": (_i, [_vp, _i, _vp]),
     "mc_state_reset": (_i, [_vp]),
+    "mc_import_residual": (_i, [_vp, _i, _vp, _vp]),
     "mc_rule_create": (_vp, [_i, _i, _d, _i, _d, C.POINTER(_d), _i, _i]),
     "mc_rule_destroy": (None, [_vp]),
     "mc_rule_step": (_i, [_vp, C.POINTER(_i)]),

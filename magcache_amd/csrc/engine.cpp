@@ -655,6 +655,17 @@ mc_status mc_calib_finalize(mc_engine* e, int branch, mc_stream stream) {
   return MC_OK;
 }
 
+mc_status mc_import_residual(mc_engine* e, int branch, const float* src_dev, mc_stream stream) {
+  if (!e || !e->ws || !src_dev) return fail(MC_EINVAL, "null argument / no workspace");
+  if (branch < 0 || branch >= e->cfg.n_branches) return fail(MC_EINVAL, "branch %d out of range", branch);
+  float* dst = e->residual(e->res_slot[branch]);
+  if (dst != src_dev)
+    HIP_TRY(hipMemcpyAsync(dst, src_dev, (size_t)e->Lr * e->d * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+  e->have_res[branch] = true;
+  return MC_OK;
+}
+
 mc_status mc_state_reset(mc_engine* e) {
   if (!e) return fail(MC_EINVAL, "null engine");
   e->have_res[0] = e->have_res[1] = false;

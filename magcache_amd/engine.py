@@ -196,6 +196,13 @@ class Engine:
         s = self.buffer("calib_stats", torch.float32)[3 * branch:3 * branch + 3].cpu()
         return float(s[0]), float(s[1]), float(s[2])
 
+    def import_residual(self, branch, tensor):
+        """make `tensor` (fp32 [tokens_per_rank, dim] on this device) this engine's residual_cache[branch]"""
+        t = tensor.float().contiguous()
+        assert tuple(t.shape) == (self.tokens_per_rank, self.cfg["dim"]), tuple(t.shape)
+        check(self.lib.mc_import_residual(self.h, branch, _ptr(t), _stream()))
+        self._keep_res = t
+
     def reset(self):
         check(self.lib.mc_state_reset(self.h))
 

@@ -1,0 +1,156 @@
+"""Wan2.2 (A14B two-expert models) on the HIP engine: the reference's MagCache4Wan2.2/magcache_generate.py.
+
+What differs from Wan2.1 on the hot path:
+  * two DiT experts -- high-noise and low-noise -- of the Wan2.1-14B architecture; the sampler picks one per
+    step by `t >= boundary * 1000` (upstream wan/text2video.py / image2video.py, boundary 0.875 t2v, 0.9 i2v);
+    here each expert is one `WanModelHIP` (one engine, one set of weights);
+  * the MagCache state lives on the model CLASS and both experts are instances of that class, so cnt,
+    the accumulators and residual_cache are shared (:340-352); this module keeps exactly that: both experts
+    must be instances of the same Python class, and a cached residual that lives in the other expert's
+    engine is forwarded with mc_import_residual before a skip;
+  * the retention gate depends on the expert split (:294-303): t2v skips nothing in the first
+    `retention_ratio` of EACH expert's steps, i2v nothing until `split + (n - split) * R`;
+  * I2V-A14B conditions by channel concatenation only (`x = cat([x, y])`, :245-246; in_dim 36, no CLIP
+    branch), which the engine's patch embedding takes as a 36-channel latent;
+  * the time embedding is evaluated per token (`t.expand(B, seq_len)`, :261-270).  For the A14B models all
+    tokens carry the same t, which makes it the Wan2.1 computation -- what the engine runs.  (TI2V-5B gives
+    the first-frame tokens their own t: not implemented.)
+"""
+import numpy as np
+import torch
+
+from .engine import MC_MODE_FULL, MC_MODE_SKIP, WAN_T2V_14B
+from .mag_ratios import TABLES
+from .model import WanModelHIP, nearest_interp
+
+# upstream wan/configs/wan_t2v_A14B.py / wan_i2v_A14B.py [UPSTREAM, not in the reference tree]
+WAN22_T2V_A14B = dict(WAN_T2V_14B)
+WAN22_I2V_A14B = dict(WAN_T2V_14B, in_dim=36)
+WAN22_DEFAULTS = {"t2v-A14B": dict(boundary=0.875, sample_steps=40, sample_shift=12.0, guide_scale=(3.0, 4.0)),
+                  "i2v-A14B": dict(boundary=0.900, sample_steps=40, sample_shift=5.0, guide_scale=(3.5, 3.5))}
+
+
+def get_timesteps(shift, num_inference_steps, num_train_timesteps=1000, sigma_max=1.0, sigma_min=0.01):
+    """MagCache4Wan2.2/magcache_generate.py:43-95 with its defaults (final_sigmas_type "zero"): int64 timesteps."""
+    sigmas = np.linspace(sigma_max, sigma_min, num_inference_steps + 1)[:-1]
+    sigmas = shift * sigmas / (1 + (shift - 1) * sigmas)
+    sigmas = np.concatenate([sigmas, [0.0]]).astype(np.float32)
+    return (sigmas[:-1] * num_train_timesteps).astype(np.int64), sigmas
+
+
+def high_noise_steps(shift, sample_steps, boundary, num_train_timesteps=1000):
+    """:697-698 -- number of sampler steps the high-noise expert serves"""
+    ts, _ = get_timesteps(shift, sample_steps, num_train_timesteps)
+    return int((ts >= num_train_timesteps * boundary).sum())
+
+
+def _use_magcache(self):
+    """retention gate, :294-303"""
+    if self.split_step is not None:
+        if self.mode == "i2v":
+            return not (self.cnt < int(self.split_step + (self.num_steps - self.split_step) * self.retention_ratio))
+        return not (self.cnt < int(self.split_step * self.retention_ratio) or
+                    (self.cnt <= ((self.num_steps - self.split_step) * self.retention_ratio + self.split_step) and
+                     self.cnt >= self.split_step))
+    return not (self.cnt < int(self.num_steps * self.retention_ratio))
+
+
+def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
+    """Drop-in for MagCache4Wan2.2/magcache_generate.py magcache_forward (:198-338)."""
+    if self.model_type == "i2v":
+        assert y is not None
+    if y is not None:
+        x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]          # :245-246
+    self._check_inputs(x, context, seq_len, None, None)
+    cls = type(self)
+    p = int(self.cnt) % 2
+    skip_forward = False
+    if _use_magcache(self):
+        self.accumulated_ratio[p] = self.accumulated_ratio[p] * self.mag_ratios[int(self.cnt)]
+        self.accumulated_steps[p] += 1
+        self.accumulated_err[p] += np.abs(1 - self.accumulated_ratio[p])
+        if self.accumulated_err[p] < self.magcache_thresh and self.accumulated_steps[p] <= self.K:
+            skip_forward = True
+        else:
+            self.accumulated_err[p] = 0
+            self.accumulated_steps[p] = 0
+            self.accumulated_ratio[p] = 1.0
+    if skip_forward:
+        cached = self.residual_cache[p]
+        if cached is None:
+            raise RuntimeError("MagCache asked to skip before any residual was cached")
+        mine = self.engine.residual(p)
+        if cached.data_ptr() != mine.data_ptr():       # cached by the other expert (class-shared cache)
+            self.engine.import_residual(p, cached)
+    out = self._run(x, t, context, p, MC_MODE_SKIP if skip_forward else MC_MODE_FULL)
+    cls.residual_cache[p] = self.engine.residual(p)
+    cls.cnt = int(self.cnt) + 1
+    if cls.cnt >= self.num_steps:                        # :333-337
+        cls.cnt = 0
+        cls.accumulated_ratio = [1.0, 1.0]
+        cls.accumulated_err = [0.0, 0.0]
+        cls.accumulated_steps = [0, 0]
+    return out
+
+
+def init_magcache(model, mag_ratios, sample_steps, magcache_thresh=0.12, magcache_K=2, retention_ratio=0.2,
+                  split_steps=None, mode="t2v"):
+    """:340-362.  `model` is either expert: the state goes to their common class.  (The reference multiplies
+    split_steps by two unconditionally and therefore fails for split_steps=None, the TI2V path; None is
+    kept as None here.)"""
+    cls = model.__class__
+    cls.forward = magcache_forward
+    cls.cnt = 0
+    cls.num_steps = sample_steps * 2
+    cls.split_step = None if split_steps is None else split_steps * 2
+    cls.mode = mode
+    cls.magcache_thresh = magcache_thresh
+    cls.K = magcache_K
+    cls.accumulated_err = [0.0, 0.0]
+    cls.accumulated_steps = [0, 0]
+    cls.accumulated_ratio = [1.0, 1.0]
+    cls.retention_ratio = retention_ratio
+    cls.residual_cache = [None, None]
+    table = np.array([1.0] * 2 + list(mag_ratios), dtype=np.float64)          # :356, pad of the first step
+    if len(table) != sample_steps * 2:
+        con, ucon = nearest_interp(table[0::2], sample_steps), nearest_interp(table[1::2], sample_steps)
+        table = np.concatenate([con.reshape(-1, 1), ucon.reshape(-1, 1)], axis=1).reshape(-1)
+    cls.mag_ratios = table
+    return model
+
+
+def table_without_pad(name):
+    """the tables of mag_ratios.py are stored padded ([1.0]*2 + ...) like the Wan2.1 ones; init_magcache above
+    pads itself, as the Wan2.2 script does"""
+    t = np.asarray(TABLES[name], dtype=np.float64)
+    return t[2:] if (len(t) >= 2 and t[0] == 1.0 and t[1] == 1.0) else t
+
+
+def make_experts(cfg, latent_grid, device="cuda:0", name="WanModelHIP22", **kw):
+    """two engines (high-noise, low-noise) whose shims are instances of ONE fresh class"""
+    cls = type(name, (WanModelHIP,), {"model_type": "i2v" if cfg["in_dim"] == 36 else "t2v"})
+    hi = cls(cfg, latent_grid, device=device, calibration=False, **kw)
+    lo = cls(cfg, latent_grid, device=device, calibration=False, **kw)
+    return hi, lo
+
+
+def sample(high, low, noise, context, context_null, boundary, sampling_steps=40, shift=12.0, guide_scale=(3.0, 4.0),
+           y=None, seq_len=None, solver="euler"):
+    """The two-expert denoising loop (upstream wan/text2video.py generate(): expert by timestep, guidance
+    scale per expert (low, high), cond call first, uncond second)."""
+    from .sampler import FlowSolver, lincomb_hip
+    ts, sig = get_timesteps(shift, sampling_steps)
+    device = noise.device
+    t_dev = torch.tensor(ts, dtype=torch.float32, device=device)
+    latent = noise.clone().float().contiguous()
+    seq_len = seq_len or high.engine.seq_len
+    fs = FlowSolver(sig, solver)
+    kw = {} if y is None else {"y": [y]}
+    for i in range(sampling_steps):
+        hi = ts[i] >= boundary * 1000
+        model, g = (high, guide_scale[1]) if hi else (low, guide_scale[0])
+        eps_c = model([latent], t=t_dev[i:i + 1], context=[context], seq_len=seq_len, **kw)[0]
+        eps_u = model([latent], t=t_dev[i:i + 1], context=[context_null], seq_len=seq_len, **kw)[0]
+        v = lincomb_hip([1.0 - g, g], [eps_u.contiguous(), eps_c.contiguous()])
+        latent = fs.step(i, latent, v)
+    return latent

@@ -191,3 +191,41 @@ def psnr(a, b, data_range=None):
         return 100.0
     rng = 1.0 if data_range is None else data_range
     return float(20 * np.log10(rng / np.sqrt(mse)))
+
+
+class MagCacheWan22:
+    """MagCache4Wan2.2/magcache_generate.py magcache_forward (:198-338) around TWO oracle WanModels (the
+    high- and low-noise experts): y is concatenated to x (:245-246), the state machine and the residual
+    cache are shared by both experts (class attributes, :340-352), the expert is the caller's choice.
+    The per-token time embedding (:261-270) equals the Wan2.1 embedding when all tokens carry the same t,
+    which is what the oracle model's embed() evaluates."""
+
+    def __init__(self, high, low, num_steps, thresh, K, retention_ratio, mag_ratios, split_step, mode, autocast=True):
+        self.models = {"high": high, "low": low}
+        self.autocast = autocast
+        self.rule = RuleState("wan22_i2v" if mode == "i2v" else "wan22_t2v", num_steps, thresh, K, retention_ratio,
+                              mag_ratios, split_step=split_step)
+        self.residual_cache = [None, None]
+        self.trace = []
+
+    def forward(self, expert, x, t, context, seq_len, y=None):
+        m = self.models[expert]
+        if y is not None:
+            x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
+        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if self.autocast else torch.autocast("cpu", enabled=False)
+        with torch.no_grad(), ctx:
+            x, e, kwargs = m.embed(x, t, context, seq_len)
+            ori_x = x
+            cnt = self.rule.cnt
+            skip, p = self.rule.step()
+            if skip:
+                residual = self.residual_cache[p]
+                x = x + residual
+            else:
+                for block in m.blocks:
+                    x = block(x, **kwargs)
+                residual = x - ori_x
+            self.residual_cache[p] = residual
+            self.trace.append((cnt, expert, skip))
+            x = m.unpatchify(m.head(x, e), kwargs["grid_sizes"])
+        return [u.float() for u in x]

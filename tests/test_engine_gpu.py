@@ -265,3 +265,52 @@ def test_bench_two_ranks_one_gpu(extra, par):
     assert got["n_gpus"] == 2 and got["config"]["parallelism"].startswith(par)
     assert got["forwards_skipped"] == ref["forwards_skipped"] and got["forwards_total"] == 20
     assert abs(got["psnr_vs_nocache_db"] - ref["psnr_vs_nocache_db"]) < 0.5
+
+
+def test_wan22_two_experts_i2v_vs_oracle():
+    """Wan2.2 I2V-A14B structure at test size: 36-channel input (x ++ y), two experts with different
+    weights switched at a timestep boundary, MagCache state shared by both (i2v retention gate).  The
+    HIP loop must take the oracle loop's skip decisions, match every call within 3e-2 and end > 30 dB."""
+    from magcache_amd import wan22
+    cfg = W.tiny_config(num_layers=2, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64)
+    cfg = dict(cfg, in_dim=36)
+    grid = (3, 16, 16)
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    o_hi = W.init_synthetic_(W.WanModel(**cfg), seed=11, std=0.05)
+    o_lo = W.init_synthetic_(W.WanModel(**cfg), seed=12, std=0.05)
+    g = torch.Generator().manual_seed(4)
+    noise = torch.randn(16, *grid, generator=g)
+    y = torch.randn(20, *grid, generator=g)
+    ctx, ctxn = torch.randn(21, cfg["text_dim"], generator=g), torch.randn(9, cfg["text_dim"], generator=g)
+    steps, shift, boundary, guide = 12, 5.0, 0.9, (3.5, 3.5)
+    ts, sig = wan22.get_timesteps(shift, steps)
+    split = wan22.high_noise_steps(shift, steps, boundary)
+    assert 0 < split < steps
+    table = wan22.table_without_pad("wan2.2_i2v_A14B")
+
+    hi, lo = wan22.make_experts(cfg, grid, device=DEV, name="WanModelHIP22UnderTest")
+    hi.load_state_dict(o_hi.state_dict())
+    lo.load_state_dict(o_lo.state_dict())
+    wan22.init_magcache(hi, table, steps, 0.12, 2, 0.2, split_steps=split, mode="i2v")
+    ref = MR.MagCacheWan22(o_hi, o_lo, 2 * steps, 0.12, 2, 0.2, type(hi).mag_ratios, 2 * split, "i2v")
+
+    x_hip, x_ref = noise.to(DEV).clone(), noise.clone()
+    yd, cd, cnd = y.to(DEV), ctx.to(DEV), ctxn.to(DEV)
+    modes = []
+    for e in (hi, lo):
+        orig = e.engine.forward
+        e.engine.forward = (lambda orig: lambda *a, **k: (modes.append(k["mode"]), orig(*a, **k))[1])(orig)
+    for i in range(steps):
+        expert = "high" if ts[i] >= boundary * 1000 else "low"
+        m = hi if expert == "high" else lo
+        t = torch.tensor([float(ts[i])])
+        outs_ref = [ref.forward(expert, [x_ref], t, [c], L, y=[y])[0] for c in (ctx, ctxn)]
+        outs = [m([x_hip], t=t.to(DEV), context=[c], seq_len=L, y=[yd])[0] for c in (cd, cnd)]
+        for a, b in zip(outs, outs_ref):
+            assert tuple(a.shape) == (16,) + grid and rel_l2(a, b) < 3e-2, i
+        dt = float(sig[i + 1] - sig[i])
+        x_ref = x_ref + dt * (outs_ref[1] + guide[0] * (outs_ref[0] - outs_ref[1]))
+        cfg_euler_(x_hip, outs[0].contiguous(), outs[1].contiguous(), guide[0], dt)
+    assert [int(m == MC_MODE_SKIP) for m in modes] == [int(s) for _, _, s in ref.trace]
+    assert any(s for _, _, s in ref.trace) and type(hi).cnt == 0
+    assert MR.psnr(x_hip.cpu().numpy(), x_ref.numpy(), data_range=float(x_ref.abs().max())) > 30.0

@@ -218,3 +218,83 @@ def test_generate_cli_defaults_and_validation():
     with pytest.raises(AssertionError):
         G._parse_args(["--task", "t2i-14B", "--size", "1024*1024", "--frame_num", "5"])
     assert G._parse_args(["--task", "t2i-14B", "--size", "1024*1024"]).frame_num == 1
+
+
+# ----------------------------------------------------------------------------- Wan2.2 two-expert shim
+class FakeEngine22(FakeEngine):
+    def __init__(self, tag):
+        super().__init__()
+        self.tag, self.imported = tag, []
+
+    def residual(self, p):
+        return FakeRes(self.tag, p)
+
+    def import_residual(self, p, t):
+        self.imported.append((p, t.tag))
+
+
+class FakeRes:
+    def __init__(self, tag, p):
+        self.tag, self.p = tag, p
+
+    def data_ptr(self):
+        return hash((self.tag, self.p))
+
+
+def make_experts22():
+    from magcache_amd import wan22
+    cls = type("PatchedModel22", (M.WanModelHIP,), {"model_type": "t2v"})
+    out = []
+    for tag in ("hi", "lo"):
+        m = cls.__new__(cls)
+        m.engine = FakeEngine22(tag)
+        out.append(m)
+    cls.trace = []
+    cls._check_inputs = lambda self, *a: None
+    cls._run = lambda self, x, t, ctx, branch, mode: (cls.trace.append((self.engine.tag, branch, mode)) or ["out"])
+    return wan22, cls, out[0], out[1]
+
+
+def test_wan22_two_expert_shim_schedule_and_shared_state(golden_dir):
+    """MagCache4Wan2.2: state on the CLASS shared by both experts, split-step retention gates (:294-303);
+    skip schedule = the golden one produced by the reference's own rule lines"""
+    g = json.load(open(os.path.join(golden_dir, "rule_schedules.json")))
+    for key, want in g.items():
+        d = parse_key(key)
+        if d["variant"] not in ("wan22_t2v", "wan22_i2v"):
+            continue
+        wan22, cls, hi, lo = make_experts22()
+        wan22.init_magcache(hi, wan22.table_without_pad(d["table"]), d["steps"], d["thresh"], d["K"], d["R"],
+                            split_steps=d["split"], mode="i2v" if d["variant"] == "wan22_i2v" else "t2v")
+        assert cls.split_step == 2 * d["split"] and len(cls.mag_ratios) == 2 * d["steps"]
+        for step in range(d["steps"]):
+            m = hi if step < d["split"] else lo
+            for _ in range(2):
+                assert m(["x"], t=0, context=["c"], seq_len=4) == ["out"]
+        assert [int(mode == _lib.MC_MODE_SKIP) for _, _, mode in cls.trace] == want, key
+        assert [b for _, b, _ in cls.trace] == [i % 2 for i in range(2 * d["steps"])]
+        assert [e for e, _, _ in cls.trace] == ["hi"] * (2 * d["split"]) + ["lo"] * (2 * (d["steps"] - d["split"]))
+        assert cls.cnt == 0 and cls.accumulated_steps == [0, 0]
+        assert hi.engine.imported == [] and lo.engine.imported == []   # each expert recomputes before it skips
+
+
+def test_wan22_skip_uses_the_other_experts_residual():
+    """class-shared residual_cache: a skip right after the expert switch replays the residual cached by
+    the other expert (forwarded to this expert's engine)"""
+    wan22, cls, hi, lo = make_experts22()
+    wan22.init_magcache(hi, [1.0] * 78, 40, magcache_thresh=10.0, magcache_K=100, retention_ratio=0.0,
+                        split_steps=0, mode="i2v")
+    cls.residual_cache = [hi.engine.residual(0), hi.engine.residual(1)]
+    lo(["x"], t=0, context=["c"], seq_len=4)
+    assert cls.trace[-1] == ("lo", 0, _lib.MC_MODE_SKIP) and lo.engine.imported == [(0, "hi")]
+    lo(["x"], t=0, context=["c"], seq_len=4)
+    lo(["x"], t=0, context=["c"], seq_len=4)      # branch 0 again: now its own slot, nothing to import
+    assert lo.engine.imported == [(0, "hi"), (1, "hi")]
+
+
+def test_wan22_timesteps_and_split():
+    from magcache_amd import wan22
+    ts, sig = wan22.get_timesteps(12.0, 40)
+    assert ts.dtype == np.int64 and len(ts) == 40 and len(sig) == 41 and sig[-1] == 0.0 and ts[0] == 1000
+    assert wan22.high_noise_steps(12.0, 40, 0.875) == int((ts >= 875).sum())
+    assert wan22.WAN22_I2V_A14B["in_dim"] == 36 and wan22.WAN22_T2V_A14B["dim"] == 5120
