@@ -61,7 +61,9 @@ def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
         assert y is not None
     if y is not None:
         x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]          # :245-246
-    self._check_inputs(x, context, seq_len, None, None)
+    # Wan2.2's i2v takes y only (no CLIP branch): the shared input checks run in t2v mode on the
+    # concatenated latent
+    type(self)._check_inputs(_T2VChecks(self), x, context, seq_len, None, None)
     cls = type(self)
     p = int(self.cnt) % 2
     skip_forward = False
@@ -91,6 +93,17 @@ def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
         cls.accumulated_err = [0.0, 0.0]
         cls.accumulated_steps = [0, 0]
     return out
+
+
+class _T2VChecks:
+    """view of a model whose input checks are the t2v ones (Wan2.1's i2v check asks for clip_fea)"""
+    model_type = "t2v"
+
+    def __init__(self, m):
+        self.__dict__["_m"] = m
+
+    def __getattr__(self, k):
+        return getattr(self._m, k)
 
 
 def init_magcache(model, mag_ratios, sample_steps, magcache_thresh=0.12, magcache_K=2, retention_ratio=0.2,
