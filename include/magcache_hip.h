@@ -58,6 +58,9 @@ typedef struct {
   int sp_rank, sp_size; /* sequence-parallel shard of the token axis; 0,1 for one GPU */
   int n_branches;       /* residual-cache slots: 2 for CFG models (cond/uncond), 1 otherwise */
   int calibration;      /* reserve the extra residual slot calibration mode needs */
+  int clip_dim;         /* 0: t2v.  > 0: Wan2.1 I2V -- width of the CLIP image features (1280); the model then
+                           has img_emb (MLPProj) and the k_img / v_img cross-attention branch over 257 image
+                           tokens (upstream WanI2VCrossAttention), and in_dim counts the y channels (36) */
 } mc_config;
 
 const char* mc_last_error(void);
@@ -94,6 +97,10 @@ int mc_weights_missing(const mc_engine* e, char* buf, size_t buflen); /* count; 
 mc_status mc_forward(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
                      const void* context_dev, mc_dtype ctx_dtype, int ctx_len, int branch, mc_mode mode,
                      float* out_dev, mc_stream stream);
+
+/* Wan2.1 I2V: clip_fea (upstream `clip_fea`, magcache_generate.py:203,264-266) = [n_tokens (257), clip_dim]
+ * fp32 or bf16.  Runs img_emb on it and keeps the image-token context for the following forwards. */
+mc_status mc_set_clip_fea(mc_engine* e, const void* clip_dev, mc_dtype dtype, int n_tokens, mc_stream stream);
 
 /* ---- the same forward in phases (sequence parallel: the caller runs the K/V all-gather between
  * pre_attn and post_attn of every layer with its own communicator, e.g. torch.distributed/RCCL) */

@@ -293,6 +293,19 @@ __global__ void cfg_euler_kernel(const float* __restrict__ cond, const float* __
   }
 }
 
+__global__ void add_bf16_kernel(bf16_t* __restrict__ a, const bf16_t* __restrict__ b, size_t n8) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    u32x4 x = ((const u32x4*)a)[i], y = ((const u32x4*)b)[i], o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float lo = __uint_as_float(x[k] << 16) + __uint_as_float(y[k] << 16);
+      const float hi = __uint_as_float(x[k] & 0xffff0000u) + __uint_as_float(y[k] & 0xffff0000u);
+      o[k] = pack_bf16x2(lo, hi);
+    }
+    ((u32x4*)a)[i] = o;
+  }
+}
+
 // out = sum_i a[i] * x[i] over up to 6 fp32 operands (null operands skipped; out may alias an operand):
 // the multistep solver updates (UniPC / DPM++ predictor and corrector, CFG combine) in one pass
 struct LinComb {
@@ -331,6 +344,7 @@ hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long l
     MC_LN_CASE(1)
     MC_LN_CASE(2)
     MC_LN_CASE(4)
+    MC_LN_CASE(5)
     MC_LN_CASE(6)
     MC_LN_CASE(8)
     MC_LN_CASE(12)
@@ -400,6 +414,12 @@ hipError_t launch_head_linear(const float* xn, long ldx, const float* W, const f
   if (N > 64 || (K % 32) != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(head_linear_kernel, dim3((M + 63) / 64), dim3(256), 0, stream, xn, ldx, W, b, out, ldo, M, N,
                      K);
+  return hipGetLastError();
+}
+
+hipError_t launch_add_bf16(bf16_t* a, const bf16_t* b, size_t n, hipStream_t stream) {
+  if (n % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for((long)(n / 8), 256)), dim3(256), 0, stream, a, b, n / 8);
   return hipGetLastError();
 }
 

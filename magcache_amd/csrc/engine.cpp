@@ -52,6 +52,8 @@ struct Layer {
   bf16_t *wqkv, *wo, *wcq, *wckv, *wco, *w1, *w2;
   float *bqkv, *bo, *bcq, *bckv, *bco, *b1, *b2;
   float *nq, *nk, *cnq, *cnk, *n3w, *n3b, *mod;
+  bf16_t* wckv_img = nullptr;  // I2V: [k_img ; v_img]
+  float *bckv_img = nullptr, *cnk_img = nullptr;
 };
 
 struct Buf {
@@ -70,6 +72,12 @@ struct mc_engine {
   float *b_patch, *b_text0, *b_text1;
   float *w_time0, *b_time0, *w_time1, *b_time1, *w_tproj, *b_tproj;
   float *w_head, *b_head, *head_mod;
+  // I2V img_emb = MLPProj(clip_dim -> dim): LayerNorm, Linear, GELU, Linear, LayerNorm
+  bf16_t *w_img1 = nullptr, *w_img3 = nullptr;
+  float *ln_img0_w = nullptr, *ln_img0_b = nullptr, *b_img1 = nullptr, *b_img3 = nullptr, *ln_img4_w = nullptr,
+        *ln_img4_b = nullptr;
+  int img_rows = 0;     // 257 image tokens padded to a multiple of 64
+  bool have_clip = false;
   float* cs_table = nullptr;  // rope (cos,sin) [Lp][64][2]
   std::map<std::string, Slot> slots;
   std::vector<void*> owned;
@@ -182,6 +190,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (c.sp_size < 1 || c.sp_rank < 0 || c.sp_rank >= c.sp_size) return fail(MC_EINVAL, "bad sp rank/size");
   if (c.n_branches != 1 && c.n_branches != 2) return fail(MC_EINVAL, "n_branches must be 1 or 2");
   if (c.out_dim * 4 > 64) return fail(MC_EINVAL, "out_dim*4 > 64 unsupported by the head kernel");
+  if (c.clip_dim < 0 || (c.clip_dim % 256) != 0) return fail(MC_EINVAL, "clip_dim %d must be 0 or a multiple of 256", c.clip_dim);
 
   mc_engine* e = new mc_engine();
   e->cfg = c;
@@ -240,6 +249,28 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_slot(e, p + "ffn.2.weight", l.w2, MC_BF16, d * ffn);
     add_slot(e, p + "ffn.2.bias", l.b2, MC_F32, d);
     add_slot(e, p + "modulation", l.mod, MC_F32, 6 * d);
+    if (c.clip_dim > 0) {
+      ALLOC(l.wckv_img, 2 * d * d); ALLOC(l.bckv_img, 2 * d); ALLOC(l.cnk_img, d);
+      add_slot(e, p + "cross_attn.k_img.weight", l.wckv_img, MC_BF16, d * d, 0);
+      add_slot(e, p + "cross_attn.v_img.weight", l.wckv_img, MC_BF16, d * d, d * d);
+      add_slot(e, p + "cross_attn.k_img.bias", l.bckv_img, MC_F32, d, 0);
+      add_slot(e, p + "cross_attn.v_img.bias", l.bckv_img, MC_F32, d, d);
+      add_slot(e, p + "cross_attn.norm_k_img.weight", l.cnk_img, MC_F32, d);
+    }
+  }
+  if (c.clip_dim > 0) {
+    const size_t cd = c.clip_dim;
+    e->img_rows = (int)align_up(257, 64);
+    ALLOC(e->ln_img0_w, cd); ALLOC(e->ln_img0_b, cd); ALLOC(e->w_img1, cd * cd); ALLOC(e->b_img1, cd);
+    ALLOC(e->w_img3, d * cd); ALLOC(e->b_img3, d); ALLOC(e->ln_img4_w, d); ALLOC(e->ln_img4_b, d);
+    add_slot(e, "img_emb.proj.0.weight", e->ln_img0_w, MC_F32, cd);
+    add_slot(e, "img_emb.proj.0.bias", e->ln_img0_b, MC_F32, cd);
+    add_slot(e, "img_emb.proj.1.weight", e->w_img1, MC_BF16, cd * cd);
+    add_slot(e, "img_emb.proj.1.bias", e->b_img1, MC_F32, cd);
+    add_slot(e, "img_emb.proj.3.weight", e->w_img3, MC_BF16, d * cd);
+    add_slot(e, "img_emb.proj.3.bias", e->b_img3, MC_F32, d);
+    add_slot(e, "img_emb.proj.4.weight", e->ln_img4_w, MC_F32, d);
+    add_slot(e, "img_emb.proj.4.bias", e->ln_img4_b, MC_F32, d);
   }
   const size_t kin = (size_t)c.in_dim * 4;
   ALLOC(e->w_patch, d * e->Kp); ALLOC(e->b_patch, d);
@@ -299,6 +330,17 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   add_buf(e, cur, "residual0", Lp * d * 4);
   add_buf(e, cur, "residual1", c.n_branches > 1 ? Lp * d * 4 : 256);
   add_buf(e, cur, "residual2", c.calibration ? Lp * d * 4 : 256);
+  if (c.clip_dim > 0) {
+    const size_t ir = e->img_rows, cd = c.clip_dim;
+    add_buf(e, cur, "clip_in", ir * cd * 4);
+    add_buf(e, cur, "clip_n", ir * cd * 2);
+    add_buf(e, cur, "clip_h", ir * cd * 2);
+    add_buf(e, cur, "clip_o", ir * d * 4);
+    add_buf(e, cur, "clip_h2", ir * d * 2);
+    add_buf(e, cur, "ctx_img", ir * d * 2);
+    add_buf(e, cur, "ckv_img", ir * 2 * d * 2);
+    add_buf(e, cur, "ao2", Lp * d * 2);
+  }
   add_buf(e, cur, "calib_partial", 1024 * 4 * 8);
   add_buf(e, cur, "calib_sums", 4 * 8);
   add_buf(e, cur, "calib_stats", 2 * 3 * 4);
@@ -398,6 +440,41 @@ int mc_weights_missing(const mc_engine* e, char* buf, size_t buflen) {
   return n;
 }
 
+// I2V: context_clip = img_emb(clip_fea)   (reference :264-266; upstream MLPProj: LayerNorm, Linear, GELU(erf),
+// Linear, LayerNorm).  257 tokens; rows up to img_rows are padding (finite, masked in the attention).
+mc_status mc_set_clip_fea(mc_engine* e, const void* clip_dev, mc_dtype dtype, int n_tokens, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  mc_status st = check_ready(e);
+  if (st != MC_OK) return st;
+  const mc_config& c = e->cfg;
+  if (c.clip_dim <= 0) return fail(MC_EINVAL, "engine was created without clip_dim (t2v model)");
+  if (!clip_dev || n_tokens != 257) return fail(MC_EINVAL, "clip_fea must be [257, %d]", c.clip_dim);
+  const int cd = c.clip_dim, ir = e->img_rows, d = e->d;
+  float* in = e->buf<float>("clip_in");
+  HIP_TRY(hipMemsetAsync(in, 0, (size_t)ir * cd * 4, s));
+  if (dtype == MC_F32) {
+    HIP_TRY(hipMemcpyAsync(in, clip_dev, (size_t)n_tokens * cd * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    return fail(MC_EINVAL, "clip_fea must be given as fp32");
+  }
+  bf16_t* n0 = e->buf<bf16_t>("clip_n");
+  HIP_TRY(mc::launch_ln_modulate(in, cd, nullptr, 0, e->ln_img0_w, e->ln_img0_b, 1, 1e-5f, n0, cd, nullptr, 0, ir, cd, s));
+  {
+    mc::GemmParams p = gp(n0, cd, e->w_img1, cd, e->b_img1, ir, cd, cd);
+    p.Cb = e->buf<bf16_t>("clip_h"); p.ldc = cd;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_ERF_BF16, s));
+    mc::GemmParams q = gp(e->buf<bf16_t>("clip_h"), cd, e->w_img3, cd, e->b_img3, ir, d, cd);
+    q.Cb = e->buf<bf16_t>("clip_h2"); q.ldc = d;   // autocast: the Linear's output is bf16 before the LayerNorm
+    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+  }
+  // LayerNorm of the bf16 rows: the kernel's (fp32 x) + (bf16 x0) form with x = 0
+  HIP_TRY(hipMemsetAsync(e->buf<float>("clip_o"), 0, (size_t)ir * d * 4, s));
+  HIP_TRY(mc::launch_ln_modulate(e->buf<float>("clip_o"), d, e->buf<bf16_t>("clip_h2"), d, e->ln_img4_w,
+                                 e->ln_img4_b, 1, 1e-5f, e->buf<bf16_t>("ctx_img"), d, nullptr, 0, ir, d, s));
+  e->have_clip = true;
+  return MC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // embeds: patch embedding, time embedding + projection, text embedding   (reference :236-262)
 mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
@@ -409,6 +486,8 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
   const mc_config& c = e->cfg;
   if (ctx_len <= 0 || ctx_len > c.text_len)
     return fail(MC_EINVAL, "context length %d exceeds text_len %d", ctx_len, c.text_len);
+  if (c.clip_dim > 0 && !e->have_clip)
+    return fail(MC_ESTATE, "i2v model: mc_set_clip_fea must run before the forward (reference assert :226-227)");
   const int d = e->d;
   // x = patch_embedding(latent): im2col -> GEMM, x (fp32) and ori_x (bf16), zero rows past seq_len
   bf16_t* tokens = e->buf<bf16_t>("tokens");
@@ -549,6 +628,20 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
     a.O = ao; a.ldo = d; a.Lq_pad = Lp; a.n_heads = e->H; a.scale = scale;
     a.shard_rows = e->ctx_rows; a.shard_valid = e->cfg.text_len; a.n_shards = 1;
     HIP_TRY(mc::launch_attention(a, s));
+    if (e->cfg.clip_dim > 0) {
+      // I2V (upstream WanI2VCrossAttention): + attention over the 257 CLIP image tokens with their own k/v
+      bf16_t* ckvi = e->buf<bf16_t>("ckv_img");
+      bf16_t* ao2 = e->buf<bf16_t>("ao2");
+      mc::GemmParams qi = gp(e->buf<bf16_t>("ctx_img"), d, l.wckv_img, d, l.bckv_img, e->img_rows, 2 * d, d);
+      qi.Cb = ckvi; qi.ldc = 2 * d;
+      HIP_TRY(mc::launch_gemm_bf16(qi, mc::EPI_BF16, s));
+      HIP_TRY(mc::launch_rmsnorm_rope(ckvi, 2 * d, l.cnk_img, e->cfg.eps, nullptr, 0, e->img_rows, d, s));
+      mc::AttnParams ai = a;
+      ai.K = ckvi; ai.V = ckvi + d; ai.O = ao2;
+      ai.shard_rows = e->img_rows; ai.shard_valid = 257;
+      HIP_TRY(mc::launch_attention(ai, s));
+      HIP_TRY(mc::launch_add_bf16(ao, ao2, (size_t)Lp * d, s));
+    }
     mc::GemmParams o = gp(ao, d, l.wco, d, l.bco, Lp, d, d);
     o.X = x; o.ldx = d; o.gate = nullptr;
     HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));

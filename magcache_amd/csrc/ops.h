@@ -17,6 +17,7 @@ enum GemmEpi {
   EPI_RESID_CAPTURE = 3, // as 2, then R = X_new - X0               (MagCache residual capture)
   EPI_EMBED = 4,         // X = bf16(acc + bias) (as fp32), X0out = same (bf16)
   EPI_F32 = 5,           // X = acc + bias (fp32 store)
+  EPI_GELU_ERF_BF16 = 6, // Cb = bf16(gelu_erf(bf16(acc + bias)))   (128x128 kernel only)
 };
 
 struct GemmParams {
@@ -90,6 +91,8 @@ hipError_t launch_add_bcast(const float* a, int na, const float* b, float* out, 
 hipError_t launch_cast_pad_bf16(const float* src, long lds, int rows_valid, int rows, int cols, bf16_t* dst,
                                 long ldd, hipStream_t stream);
 hipError_t launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
+// a[i] = bf16(float(a[i]) + float(b[i]))   (sum of two attention outputs, Wan I2V cross-attention)
+hipError_t launch_add_bf16(bf16_t* a, const bf16_t* b, size_t n, hipStream_t stream);
 // head: out[m, n] = dot(xn[m,:], W[n,:]) + b[n], fp32, N small (<= 64)
 hipError_t launch_head_linear(const float* xn, long ldx, const float* W, const float* b, float* out, long ldo,
                               int M, int N, int K, hipStream_t stream);

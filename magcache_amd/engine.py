@@ -11,6 +11,9 @@ WAN_T2V_1_3B = dict(dim=1536, ffn_dim=8960, freq_dim=256, num_heads=12, num_laye
                     out_dim=16, text_dim=4096, eps=1e-6)
 WAN_T2V_14B = dict(dim=5120, ffn_dim=13824, freq_dim=256, num_heads=40, num_layers=40, text_len=512, in_dim=16,
                    out_dim=16, text_dim=4096, eps=1e-6)
+# Wan2.1 I2V-14B (480P and 720P share the architecture): x ++ y = 16 + 20 channels, CLIP ViT-H features 1280 wide
+WAN_I2V_14B = dict(WAN_T2V_14B, model_type="i2v", in_dim=36, clip_dim=1280)
+N_CLIP_TOKENS = 257
 
 
 def _stream():
@@ -32,12 +35,22 @@ def weight_names(cfg):
            ("time_projection.1.weight", (6 * d, d)), ("time_projection.1.bias", (6 * d,)),
            ("head.head.weight", (4 * cfg["out_dim"], d)), ("head.head.bias", (4 * cfg["out_dim"],)),
            ("head.modulation", (1, 2, d))]
+    cd = cfg.get("clip_dim", 0)
+    if cd:
+        out += [("img_emb.proj.0.weight", (cd,)), ("img_emb.proj.0.bias", (cd,)),
+                ("img_emb.proj.1.weight", (cd, cd)), ("img_emb.proj.1.bias", (cd,)),
+                ("img_emb.proj.3.weight", (d, cd)), ("img_emb.proj.3.bias", (d,)),
+                ("img_emb.proj.4.weight", (d,)), ("img_emb.proj.4.bias", (d,))]
     for i in range(cfg["num_layers"]):
         p = f"blocks.{i}."
         for a in ("self_attn", "cross_attn"):
             for w in ("q", "k", "v", "o"):
                 out += [(p + f"{a}.{w}.weight", (d, d)), (p + f"{a}.{w}.bias", (d,))]
             out += [(p + f"{a}.norm_q.weight", (d,)), (p + f"{a}.norm_k.weight", (d,))]
+        if cd:
+            out += [(p + "cross_attn.k_img.weight", (d, d)), (p + "cross_attn.k_img.bias", (d,)),
+                    (p + "cross_attn.v_img.weight", (d, d)), (p + "cross_attn.v_img.bias", (d,)),
+                    (p + "cross_attn.norm_k_img.weight", (d,))]
         out += [(p + "norm3.weight", (d,)), (p + "norm3.bias", (d,)),
                 (p + "ffn.0.weight", (ffn, d)), (p + "ffn.0.bias", (ffn,)),
                 (p + "ffn.2.weight", (d, ffn)), (p + "ffn.2.bias", (d,)),
@@ -50,11 +63,12 @@ def synthetic_weights(cfg, seed=0, std=0.02, device="cuda"):
     time (no checkpoint exists offline).  Same distribution family as oracle.init_synthetic_."""
     g = torch.Generator(device=device).manual_seed(seed)
     for name, shape in weight_names(cfg):
+        kind = name.replace("img_emb.proj.0.", "img_emb.norm0.").replace("img_emb.proj.4.", "img_emb.norm4.")
         if name.endswith("modulation"):
             t = torch.randn(shape, generator=g, device=device) / cfg["dim"] ** 0.5
-        elif "norm" in name and name.endswith("weight"):
+        elif "norm" in kind and name.endswith("weight"):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
-        elif "norm" in name and name.endswith("bias"):
+        elif "norm" in kind and name.endswith("bias"):
             t = 0.1 * torch.randn(shape, generator=g, device=device)
         else:
             t = std * torch.randn(shape, generator=g, device=device)
@@ -77,7 +91,8 @@ class Engine:
         c = McConfig(dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"], num_layers=cfg["num_layers"],
                      in_dim=cfg["in_dim"], out_dim=cfg["out_dim"], freq_dim=cfg["freq_dim"], text_dim=cfg["text_dim"],
                      text_len=cfg["text_len"], latent_f=F_, latent_h=H_, latent_w=W_, eps=cfg.get("eps", 1e-6),
-                     sp_rank=sp_rank, sp_size=sp_size, n_branches=n_branches, calibration=int(calibration))
+                     sp_rank=sp_rank, sp_size=sp_size, n_branches=n_branches, calibration=int(calibration),
+                     clip_dim=cfg.get("clip_dim", 0))
         self.sp_rank, self.sp_size, self.n_branches = sp_rank, sp_size, n_branches
         h = C.c_void_p()
         check(self.lib.mc_create(C.byref(c), C.byref(h)))
@@ -130,6 +145,13 @@ class Engine:
         """fp32 [seq_len/sp, dim] view of residual_cache[branch] (rows past the valid tokens cut off)."""
         d = self.cfg["dim"]
         return self.buffer(f"residual_branch{branch}", torch.float32).view(-1, d)[:self.tokens_per_rank]
+
+    def set_clip_fea(self, clip_fea):
+        """Wan2.1 I2V: clip_fea [257, clip_dim] (or [1, 257, clip_dim]); runs img_emb once, the image-token context
+        stays resident for the following forwards (the reference recomputes it every call, :264-266)."""
+        c = clip_fea.detach().to(self.device, torch.float32).reshape(-1, clip_fea.shape[-1]).contiguous()
+        check(self.lib.mc_set_clip_fea(self.h, _ptr(c), MC_F32, c.shape[0], _stream()))
+        torch.cuda.current_stream().synchronize()
 
     # ---- forward
     def _ctx(self, context):

@@ -56,7 +56,8 @@ def select_table(ckpt_dir, task="t2v"):
 
 
 class WanModelHIP:
-    """Wan2.1 T2V DiT whose forward runs on the HIP engine.  One latent grid per instance."""
+    """Wan2.1 DiT (T2V, or I2V when cfg has model_type='i2v' / clip_dim) whose forward runs on the HIP engine.
+    One latent grid per instance."""
 
     model_type = "t2v"
     patch_size = (1, 2, 2)
@@ -68,6 +69,9 @@ class WanModelHIP:
                   "num_layers"):
             setattr(self, k, cfg[k])
         self.latent_grid = tuple(latent_grid)
+        if cfg.get("model_type", "t2v") != "t2v":
+            self.model_type = cfg["model_type"]          # instance attribute, like upstream's self.model_type
+        self._clip_key = None
         self.engine = engine or Engine(cfg, latent_grid, device=device, n_branches=2, calibration=calibration,
                                        sp_rank=sp_rank, sp_size=sp_size)
         self.device = self.engine.device
@@ -83,13 +87,24 @@ class WanModelHIP:
             assert clip_fea is not None and y is not None
         assert len(x) == 1 and len(context) == 1, "the engine evaluates one sample per call, as the Wan sampler does"
         u = x[0]
-        assert tuple(u.shape[1:]) == self.latent_grid and u.shape[0] == self.in_dim, \
-            f"latent {tuple(u.shape)} does not match the engine grid {(self.in_dim,) + self.latent_grid}"
+        c_in = u.shape[0] + (y[0].shape[0] if y is not None else 0)   # x ++ y along channels (:233-234)
+        assert tuple(u.shape[1:]) == self.latent_grid and c_in == self.in_dim, \
+            f"latent {tuple(u.shape)} (+y) does not match the engine grid {(self.in_dim,) + self.latent_grid}"
+        if y is not None:
+            assert len(y) == 1 and tuple(y[0].shape[1:]) == self.latent_grid
         assert self.engine.seq_len <= seq_len  # seq_lens.max() <= seq_len (:242)
         assert context[0].shape[0] <= self.text_len and context[0].shape[1] == self.text_dim
 
-    def _run(self, x, t, context, branch, mode):
+    def _run(self, x, t, context, branch, mode, clip_fea=None, y=None):
         lat = x[0].to(self.device)
+        if y is not None:
+            lat = torch.cat([lat, y[0].to(self.device)], dim=0)
+        if clip_fea is not None:
+            # img_emb(clip_fea) is constant over a video: run it when the tensor changes, not every call
+            key = (clip_fea.data_ptr(), clip_fea._version, tuple(clip_fea.shape))
+            if key != self._clip_key:
+                self.engine.set_clip_fea(clip_fea)
+                self._clip_key = key
         t = t if not torch.is_tensor(t) else t.to(self.device)
         ctx = context[0].to(self.device)
         if self.engine.sp_size > 1:
@@ -107,10 +122,14 @@ class WanModelHIP:
         return type(self).forward(self, *args, **kwargs)
 
 
+def _i2v_inputs(clip_fea, y):
+    return {} if clip_fea is None and y is None else dict(clip_fea=clip_fea, y=y)
+
+
 def plain_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
     """Plain (no-cache) forward: upstream WanModel.forward."""
     self._check_inputs(x, context, seq_len, clip_fea, y)
-    return self._run(x, t, context, 0, MC_MODE_FULL)
+    return self._run(x, t, context, 0, MC_MODE_FULL, **_i2v_inputs(clip_fea, y))
 
 
 WanModelHIP.forward = plain_forward
@@ -144,7 +163,7 @@ def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
             self.accumulated_ratio[p] = 1.0
     if skip_forward and self.residual_cache[p] is None:
         raise RuntimeError("MagCache asked to skip before any residual was cached (retention_ratio too small?)")
-    out = self._run(x, t, context, p, MC_MODE_SKIP if skip_forward else MC_MODE_FULL)
+    out = self._run(x, t, context, p, MC_MODE_SKIP if skip_forward else MC_MODE_FULL, **_i2v_inputs(clip_fea, y))
     self.residual_cache[p] = self.engine.residual(p)  # a view of the engine's HBM slot
     _advance(self)
     return out
@@ -156,7 +175,7 @@ def magcache_calibration(self, x, t, context, seq_len, clip_fea=None, y=None):
     three JSON files when the video is finished."""
     self._check_inputs(x, context, seq_len, clip_fea, y)
     p = self.cnt % 2
-    out = self._run(x, t, context, p, MC_MODE_CALIB)
+    out = self._run(x, t, context, p, MC_MODE_CALIB, **_i2v_inputs(clip_fea, y))
     if self.cnt >= 2:
         norm_ratio, norm_std, cos_dis = self.engine.calib_stats(p)
         self.norm_ratio.append(round(norm_ratio, 5))

@@ -238,7 +238,49 @@ def main():
                                              guide=5.0, shift=5.0, weight_seed=7, weight_std=0.05, input_seed=42,
                                              ctx_len=37, table="wan2.1_t2v_1.3B")))
 
+    # ---------------------------------------------------------------- I2V wrapper forward golden
+    # the reference's magcache_forward with clip_fea / y (:226-234, :264-266) around the tiny oracle i2v model
+    cfg_i = W.tiny_config(num_layers=2, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64, i2v=True,
+                          clip_dim=256)
+    Fi, Hi, Wi, steps_i = 2, 16, 20, 8
+    seq_i = Fi * (Hi // 2) * (Wi // 2)
+    gi = torch.Generator().manual_seed(77)
+    lat_i = torch.randn(16, Fi, Hi, Wi, generator=gi)
+    y_i = torch.randn(20, Fi, Hi, Wi, generator=gi)
+    clip_i = torch.randn(1, 257, cfg_i["clip_dim"], generator=gi)
+    ctx_i = torch.randn(29, cfg_i["text_dim"], generator=gi)
+    ctxn_i = torch.randn(11, cfg_i["text_dim"], generator=gi)
+    sig_i, ts_i = flow_timesteps(steps_i, shift=3.0)
+    cls = fresh_model_class()
+    model = W.init_synthetic_(cls(**cfg_i), seed=11, std=0.05)
+    patch_like_reference(cls, ref, steps_i * 2, 0.12, 2, 0.2, TABLES["wan2.1_i2v_480P"], steps_i)
+    outs_i, ran = [], []
+    hook = model.blocks[0].register_forward_hook(lambda *a: ran.append(True))
+    x = lat_i.clone()
+    sk_i = []
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(steps_i):
+            t = torch.tensor([float(ts_i[i])])
+            pred = []
+            for c in (ctx_i, ctxn_i):
+                n0 = len(ran)
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    pred.append(model([x], t=t, context=[c], seq_len=seq_i, clip_fea=clip_i, y=[y_i])[0])
+                sk_i.append(len(ran) == n0)
+            outs_i += [pred[0].numpy().copy(), pred[1].numpy().copy()]
+            x = x + float(sig_i[i + 1] - sig_i[i]) * (pred[1] + 5.0 * (pred[0] - pred[1]))
+    hook.remove()
+    np.savez_compressed(os.path.join(GOLD, "wan_i2v_forward_golden.npz"),
+                        outs=np.stack(outs_i).astype(np.float32), final_latent=x.numpy(), latent0=lat_i.numpy(),
+                        y=y_i.numpy(), clip_fea=clip_i.numpy(), ctx=ctx_i.numpy(), ctx_null=ctxn_i.numpy(),
+                        timesteps=ts_i, sigmas=sig_i, skipped=np.array(sk_i, dtype=np.int8),
+                        meta=json.dumps(dict(cfg=cfg_i, F=Fi, H=Hi, W=Wi, steps=steps_i, thresh=0.12, K=2, R=0.2,
+                                             guide=5.0, shift=3.0, weight_seed=11, weight_std=0.05,
+                                             table="wan2.1_i2v_480P")))
+
     # ---------------------------------------------------------------- calibration goldens
+    cfg = W.tiny_config(num_layers=2, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64)
     cls = fresh_model_class()
     model = W.init_synthetic_(cls(**cfg), seed=7, std=0.05)
     cls.forward = ref.magcache_calibration           # :921-928

@@ -120,11 +120,11 @@ class MagCacheWan:
     def _ctx(self):
         return torch.autocast("cpu", dtype=torch.bfloat16) if self.autocast else torch.autocast("cpu", enabled=False)
 
-    def forward(self, x, t, context, seq_len, use_cache=True):
+    def forward(self, x, t, context, seq_len, use_cache=True, clip_fea=None, y=None):
         m = self.model
         cnt = self.rule.cnt
         with torch.no_grad(), self._ctx():
-            x, e, kwargs = m.embed(x, t, context, seq_len)
+            x, e, kwargs = m.embed(x, t, context, seq_len, clip_fea, y)
             ori_x = x
             skip, p = self.rule.step() if use_cache else (False, cnt % 2)
             if not use_cache:
@@ -142,12 +142,12 @@ class MagCacheWan:
             x = m.unpatchify(x, kwargs["grid_sizes"])
         return [u.float() for u in x]
 
-    def calibrate(self, x, t, context, seq_len):
+    def calibrate(self, x, t, context, seq_len, clip_fea=None, y=None):
         m = self.model
         cnt = self.rule.cnt
         p = cnt % 2
         with torch.no_grad(), self._ctx():
-            x, e, kwargs = m.embed(x, t, context, seq_len)
+            x, e, kwargs = m.embed(x, t, context, seq_len, clip_fea, y)
             ori_x = x
             for block in m.blocks:
                 x = block(x, **kwargs)

@@ -36,7 +36,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 __all__ = ["WanModel", "sinusoidal_embedding_1d", "rope_params", "rope_apply", "WAN_T2V_1_3B", "WAN_T2V_14B",
-           "tiny_config", "init_synthetic_"]
+           "WAN_I2V_14B", "tiny_config", "init_synthetic_"]
 
 
 def sinusoidal_embedding_1d(dim, position):
@@ -158,13 +158,53 @@ class WanT2VCrossAttention(WanSelfAttention):
         return self.o(x.flatten(2))
 
 
+class WanI2VCrossAttention(WanSelfAttention):
+    """Upstream wan/modules/model.py WanI2VCrossAttention: the first 257 context rows are the CLIP image
+    tokens (the wrapper concatenates them in front of the text rows, magcache_generate.py:264-266); they
+    get their own k_img / v_img / norm_k_img, a second attention with the same q, and the two attention
+    outputs are summed before the output projection."""
+    N_IMG = 257
+
+    def __init__(self, dim, num_heads, qk_norm=True, eps=1e-6):
+        super().__init__(dim, num_heads, qk_norm, eps)
+        self.k_img, self.v_img = nn.Linear(dim, dim), nn.Linear(dim, dim)
+        self.norm_k_img = WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()
+
+    def forward(self, x, context, context_lens):
+        img, text = context[:, :self.N_IMG], context[:, self.N_IMG:]
+        b, n, d = x.size(0), self.num_heads, self.head_dim
+        q = self.norm_q(self.q(x)).view(b, -1, n, d)
+        k = self.norm_k(self.k(text)).view(b, -1, n, d)
+        v = self.v(text).view(b, -1, n, d)
+        k_img = self.norm_k_img(self.k_img(img)).view(b, -1, n, d)
+        v_img = self.v_img(img).view(b, -1, n, d)
+        img_x = self._attn(q, k_img, v_img, None)
+        x = self._attn(q, k, v, context_lens)
+        return self.o(x.flatten(2) + img_x.flatten(2))
+
+
+class MLPProj(nn.Module):
+    """Upstream img_emb: LayerNorm(in) -> Linear(in,in) -> GELU (exact) -> Linear(in,out) -> LayerNorm(out)
+    (torch LayerNorm defaults: affine, eps 1e-5)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.proj = nn.Sequential(nn.LayerNorm(in_dim), nn.Linear(in_dim, in_dim), nn.GELU(),
+                                  nn.Linear(in_dim, out_dim), nn.LayerNorm(out_dim))
+
+    def forward(self, image_embeds):
+        return self.proj(image_embeds)
+
+
 class WanAttentionBlock(nn.Module):
-    def __init__(self, dim, ffn_dim, num_heads, qk_norm=True, cross_attn_norm=False, eps=1e-6):
+    def __init__(self, dim, ffn_dim, num_heads, qk_norm=True, cross_attn_norm=False, eps=1e-6,
+                 cross_attn_type="t2v_cross_attn"):
         super().__init__()
         self.norm1 = WanLayerNorm(dim, eps)
         self.self_attn = WanSelfAttention(dim, num_heads, qk_norm, eps)
         self.norm3 = WanLayerNorm(dim, eps, elementwise_affine=True) if cross_attn_norm else nn.Identity()
-        self.cross_attn = WanT2VCrossAttention(dim, num_heads, qk_norm, eps)
+        self.cross_attn = (WanI2VCrossAttention if cross_attn_type == "i2v_cross_attn" else WanT2VCrossAttention)(
+            dim, num_heads, qk_norm, eps)
         self.norm2 = WanLayerNorm(dim, eps)
         self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
@@ -199,13 +239,15 @@ class Head(nn.Module):
 
 
 class WanModel(nn.Module):
-    """T2V Wan DiT (model_type 't2v'): same member names the reference wrapper dereferences."""
+    """Wan2.1 DiT (model_type 't2v' or 'i2v'): same member names the reference wrapper dereferences.
+    i2v: in_dim counts the y channels (36 = 16 + 4 mask + 16 image latent), img_emb maps the CLIP features
+    (clip_dim, upstream constant 1280) to 257 extra context rows and the blocks use WanI2VCrossAttention."""
 
     def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
                  freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, qk_norm=True,
-                 cross_attn_norm=True, eps=1e-6):
+                 cross_attn_norm=True, eps=1e-6, clip_dim=1280):
         super().__init__()
-        assert model_type == "t2v"
+        assert model_type in ("t2v", "i2v")
         self.model_type, self.patch_size, self.text_len = model_type, patch_size, text_len
         self.in_dim, self.dim, self.ffn_dim, self.freq_dim = in_dim, dim, ffn_dim, freq_dim
         self.text_dim, self.out_dim, self.num_heads, self.num_layers, self.eps = text_dim, out_dim, num_heads, num_layers, eps
@@ -214,8 +256,12 @@ class WanModel(nn.Module):
         self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
         self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
         self.blocks = nn.ModuleList(
-            [WanAttentionBlock(dim, ffn_dim, num_heads, qk_norm, cross_attn_norm, eps) for _ in range(num_layers)])
+            [WanAttentionBlock(dim, ffn_dim, num_heads, qk_norm, cross_attn_norm, eps,
+                               "i2v_cross_attn" if model_type == "i2v" else "t2v_cross_attn") for _ in range(num_layers)])
         self.head = Head(dim, out_dim, patch_size, eps)
+        if model_type == "i2v":
+            self.clip_dim = clip_dim
+            self.img_emb = MLPProj(clip_dim, dim)
         d = dim // num_heads
         assert d % 2 == 0
         self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
@@ -231,7 +277,11 @@ class WanModel(nn.Module):
         return out
 
     # ---- the op sequence of the reference wrapper, without any MagCache logic (no-cache forward)
-    def embed(self, x, t, context, seq_len):
+    def embed(self, x, t, context, seq_len, clip_fea=None, y=None):
+        if self.model_type == "i2v":
+            assert clip_fea is not None and y is not None                       # :226-227
+        if y is not None:
+            x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]                # :233-234
         x = [self.patch_embedding(u.unsqueeze(0)) for u in x]
         grid_sizes = torch.stack([torch.tensor(u.shape[2:], dtype=torch.long) for u in x])
         x = [u.flatten(2).transpose(1, 2) for u in x]
@@ -244,14 +294,16 @@ class WanModel(nn.Module):
             assert e.dtype == torch.float32 and e0.dtype == torch.float32
         context = self.text_embedding(torch.stack(
             [torch.cat([u, u.new_zeros(self.text_len - u.size(0), u.size(1))]) for u in context]))
+        if clip_fea is not None:
+            context = torch.concat([self.img_emb(clip_fea), context], dim=1)    # :264-266
         kwargs = dict(e=e0, seq_lens=seq_lens, grid_sizes=grid_sizes, freqs=self.freqs, context=context,
                       context_lens=None)
         return x, e, kwargs
 
-    def forward(self, x, t, context, seq_len, autocast=True):
+    def forward(self, x, t, context, seq_len, clip_fea=None, y=None, autocast=True):
         ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else nullcontext()
         with torch.no_grad(), ctx:
-            x, e, kwargs = self.embed(x, t, context, seq_len)
+            x, e, kwargs = self.embed(x, t, context, seq_len, clip_fea, y)
             for block in self.blocks:
                 x = block(x, **kwargs)
             x = self.head(x, e)
@@ -268,12 +320,16 @@ WAN_T2V_1_3B = dict(dim=1536, ffn_dim=8960, freq_dim=256, num_heads=12, num_laye
                     out_dim=16, text_dim=4096, eps=1e-6)
 WAN_T2V_14B = dict(dim=5120, ffn_dim=13824, freq_dim=256, num_heads=40, num_layers=40, text_len=512, in_dim=16,
                    out_dim=16, text_dim=4096, eps=1e-6)
+WAN_I2V_14B = dict(WAN_T2V_14B, model_type="i2v", in_dim=36, clip_dim=1280)
 
 
-def tiny_config(num_layers=2, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64):
+def tiny_config(num_layers=2, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64, i2v=False, clip_dim=256):
     """A small geometry with the real head_dim (128) for CPU-sized parity runs."""
-    return dict(dim=128 * num_heads, ffn_dim=ffn_dim, freq_dim=freq_dim, num_heads=num_heads, num_layers=num_layers,
-                text_len=text_len, in_dim=16, out_dim=16, text_dim=text_dim, eps=1e-6)
+    cfg = dict(dim=128 * num_heads, ffn_dim=ffn_dim, freq_dim=freq_dim, num_heads=num_heads, num_layers=num_layers,
+               text_len=text_len, in_dim=16, out_dim=16, text_dim=text_dim, eps=1e-6)
+    if i2v:
+        cfg.update(model_type="i2v", in_dim=36, clip_dim=clip_dim)
+    return cfg
 
 
 def init_synthetic_(model, seed=0, std=0.02):
@@ -283,6 +339,7 @@ def init_synthetic_(model, seed=0, std=0.02):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
+            name = name.replace("img_emb.proj.0.", "img_emb.norm0.").replace("img_emb.proj.4.", "img_emb.norm4.")
             if name.endswith("modulation"):
                 p.copy_(torch.randn(p.shape, generator=g) / model.dim ** 0.5)
             elif "norm" in name and name.endswith("weight"):

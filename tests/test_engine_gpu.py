@@ -95,6 +95,57 @@ def test_wan14b_widths_forward_vs_oracle():
     assert rel_l2(got, ref_ac) < 2e-2
 
 
+def test_wan21_i2v_forward_and_magcache_run_vs_reference_golden(golden_dir):
+    """Wan2.1 I2V (CLIP image-token branch: img_emb MLPProj, k_img / v_img second cross-attention, x ++ y patch
+    embedding).  (1) one forward vs the oracle, same tolerance as the T2V forward; (2) the MagCache CFG loop through
+    the shim with clip_fea / y vs the golden produced by the reference's own magcache_forward: identical skip
+    schedule, per-call outputs within the bf16-mode tolerance."""
+    g = np.load(os.path.join(golden_dir, "wan_i2v_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = meta["cfg"]
+    oracle = W.init_synthetic_(W.WanModel(**cfg), seed=meta["weight_seed"], std=meta["weight_std"])
+    grid = (meta["F"], meta["H"], meta["W"])
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    cls = type("WanI2VHIPUnderTest", (M.WanModelHIP,), {})
+    m = cls(cfg, grid, device=DEV, calibration=False)
+    assert m.model_type == "i2v"
+    m.load_state_dict(oracle.state_dict())
+    lat, y = torch.from_numpy(g["latent0"]), torch.from_numpy(g["y"])
+    clip = torch.from_numpy(g["clip_fea"])
+    ctx, ctxn = torch.from_numpy(g["ctx"]), torch.from_numpy(g["ctx_null"])
+    t = torch.tensor([float(g["timesteps"][0])])
+    with pytest.raises(AssertionError):      # the reference's assert (:226-227)
+        m([lat.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L)
+    ref_ac = oracle.forward([lat], t, [ctx], L, clip_fea=clip, y=[y], autocast=True)[0]
+    oracle.set_fp32_attention(True)
+    ref_32 = oracle.forward([lat], t, [ctx], L, clip_fea=clip, y=[y], autocast=False)[0]
+    oracle.set_fp32_attention(False)
+    clip_d, y_d = clip.to(DEV), y.to(DEV)
+    got = m([lat.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L, clip_fea=clip_d, y=[y_d])[0]
+    e_hip, e_ac = rel_l2(got, ref_32), rel_l2(ref_ac, ref_32)
+    assert e_hip < 2 * e_ac + 1e-3, (e_hip, e_ac)
+    assert rel_l2(got, ref_ac) < 2e-2
+    # the image tokens matter: a different clip_fea changes the prediction
+    other = m([lat.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L, clip_fea=(clip_d * -1.0).contiguous(),
+              y=[y_d])[0]
+    assert rel_l2(other, got) > 1e-2
+    # (2) MagCache loop
+    steps = meta["steps"]
+    M.init_magcache(m, steps, meta["thresh"], meta["K"], meta["R"], mag_ratios=TABLES[meta["table"]])
+    x = lat.to(DEV).clone()
+    sig = g["sigmas"]
+    errs = []
+    for i in range(steps):
+        tt = torch.tensor([float(g["timesteps"][i])], device=DEV)
+        ec = m([x], t=tt, context=[ctx.to(DEV)], seq_len=L, clip_fea=clip_d, y=[y_d])[0]
+        eu = m([x], t=tt, context=[ctxn.to(DEV)], seq_len=L, clip_fea=clip_d, y=[y_d])[0]
+        errs += [rel_l2(ec, g["outs"][2 * i]), rel_l2(eu, g["outs"][2 * i + 1])]
+        x = x + float(sig[i + 1] - sig[i]) * (eu + meta["guide"] * (ec - eu))
+    assert max(errs) < 3e-2, errs
+    assert rel_l2(x, g["final_latent"]) < 2e-2
+    assert cls.cnt == 0
+
+
 @pytest.mark.parametrize("solver", ["unipc", "dpm++"])
 def test_sampler_multistep_solvers_run_on_engine(golden, hip_model, solver):
     """the upstream default solvers around the MagCache-wrapped engine: finite result, same skip schedule
