@@ -107,6 +107,10 @@ mc_status mc_set_clip_fea(mc_engine* e, const void* clip_dev, mc_dtype dtype, in
 mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
                    const void* context_dev, mc_dtype ctx_dtype, int ctx_len, mc_stream stream);
 mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream);  /* LN+mod, QKV, qk-norm, RoPE */
+/* optional, sp_size > 1 only: self-attention over THIS rank's K/V shard (already in place after pre_attn), to be
+ * launched while the all-gather of the other shards is in flight; the following mc_block_post_attn of the same
+ * layer then attends the remaining shards only and merges both parts (log-sum-exp weights) */
+mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream);
 mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream);
 mc_status mc_head(mc_engine* e, int branch, mc_mode mode, mc_stream stream); /* -> "head_tokens" */
 /* tokens_dev: fp32 [n_tok, 4*out_dim] for tokens tok0..tok0+n_tok-1 -> out_dev [out_dim,F,H,W] */
@@ -161,6 +165,14 @@ mc_status mc_op_attention(const void* Q_dev, long ldq, const void* K_dev, long l
                           const void* V_dev, long ldv, long v_shard_stride, void* O_dev, long ldo, int Lq_pad,
                           int n_heads, int shard_rows, int shard_valid, int n_shards, float scale,
                           mc_stream stream);
+/* two-phase form (sequence parallel): skip_shard >= 0 leaves that shard out; lse_out [n_heads][Lq_pad] fp32 receives
+ * the log2-sum-exp of the keys visited; lse_in != NULL merges with the result already in O_dev (see
+ * mc_block_attn_local) */
+mc_status mc_op_attention_partial(const void* Q_dev, long ldq, const void* K_dev, long ldk, long k_shard_stride,
+                                  const void* V_dev, long ldv, long v_shard_stride, void* O_dev, long ldo,
+                                  int Lq_pad, int n_heads, int shard_rows, int shard_valid, int n_shards,
+                                  float scale, int skip_shard, float* lse_out_dev, const float* lse_in_dev,
+                                  mc_stream stream);
 mc_status mc_op_ln_modulate(const float* x_dev, long ldx, const void* x0_dev, long ldx0, const float* sc_dev,
                             const float* sh_dev, int mode, float eps, void* out_bf16_dev, long ldo,
                             float* out_f32_dev, long ldof, int M, int D, mc_stream stream);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mc_set_clip_fea": (_i, [_vp, _vp, _i, _i, _vp]),
     "mc_embed": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _vp]),
     "mc_block_pre_attn": (_i, [_vp, _i, _vp]),
+    "mc_block_attn_local": (_i, [_vp, _i, _vp]),
     "mc_block_post_attn": (_i, [_vp, _i, _i, _i, _vp]),
     "mc_head": (_i, [_vp, _i, _i, _vp]),
     "mc_unpatchify": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "mc_op_gemm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l,
                              _i, _vp]),
     "mc_op_attention": (_i, [_vp, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
+    "mc_op_attention_partial": (_i, [_vp, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "mc_op_ln_modulate": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _f, _vp, _l, _vp, _l, _i, _i, _vp]),
     "mc_op_rmsnorm_rope": (_i, [_vp, _l, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mc_op_skip_add": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp]),

@@ -229,6 +229,12 @@ hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream) {
 int g_attn_kernel = 0;
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+  const bool two_phase = p.skip_shard_p1 != 0 || p.lse_out || p.lse_in;  // only attention_v3.hip implements it
+  if (two_phase) {
+    if (p.skip_shard_p1 < 0 || p.skip_shard_p1 > p.n_shards || (p.skip_shard_p1 && p.n_shards < 2))
+      return hipErrorInvalidValue;
+    return launch_attention_v3(p, stream);
+  }
   switch (g_attn_kernel) {
     case 1: return launch_attention_v1(p, stream);
     case 2: return launch_attention_v2(p, stream);

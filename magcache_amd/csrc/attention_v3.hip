@@ -102,7 +102,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
   const uint32_t lds0 = (uint32_t)(uintptr_t)MC_LDS_PTR(smem);
   const uint32_t dma_lds = lds0 + wv * 2048;  // this wave's 2 pieces inside a tile image
 
-  const int ntiles = p.n_shards * tiles_per_shard;
+  const int skip_sh = p.skip_shard_p1 - 1;  // -1: none
+  const int ntiles = (p.n_shards - (skip_sh >= 0 ? 1 : 0)) * tiles_per_shard;
 
   // one 1 KiB piece.  saddr form: uniform 64-bit base + 32-bit lane offset; M0 = LDS byte address of
   // the piece; s_nop covers the SALU-write-M0 -> LDS-DMA hazard; M0 is restored for the compiler.
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
   // keeps the number of DMA instructions per iteration constant (the vmcnt counts rely on that).
   struct Cursor {
     const bf16_t* ptr;  // first row of the tile
-    int t, tin;         // global tile index, tile index inside its shard
+    int t, tin, sh;     // tile index in the walk, tile index inside its shard, shard index
   };
   auto advance = [&](Cursor& cu, long ld, long shard_stride) {
     if (cu.t < ntiles - 1) {  // uniform; false only for the last iterations
@@ -132,10 +133,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
       if (__builtin_expect(++cu.tin == tiles_per_shard, 0)) {  // next shard (rare)
         cu.tin = 0;
         cu.ptr += shard_stride - (long)tiles_per_shard * KT * ld;
+        if (++cu.sh == skip_sh) {
+          ++cu.sh;
+          cu.ptr += shard_stride;
+        }
       }
     }
   };
-  Cursor ck = {p.K, 0, 0}, cv = {p.V, 0, 0};
+  Cursor ck = {p.K, 0, 0, 0}, cv = {p.V, 0, 0, 0};
+  if (skip_sh == 0) {
+    ck.sh = cv.sh = 1;
+    ck.ptr += p.k_shard_stride;
+    cv.ptr += p.v_shard_stride;
+  }
   auto dma_k = [&](int slot) {  // whole next K tile (this wave's pieces) -> ring slot; prologue only
     dma1(ck.ptr, srcK[0], dma_lds + slot * TILE_BYTES);
     dma1(ck.ptr, srcK[1], dma_lds + slot * TILE_BYTES + 1024);
@@ -417,8 +427,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
 #undef MC_FIN_PAIR
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = db*32 + 8*g + 4*half + 0..3
-  const float inv = 1.0f / half_swap_sum(l_run);
+  const float l_tot = half_swap_sum(l_run);
+  float inv = 1.0f / l_tot;
   bf16_t* op = p.O + (size_t)qrow * p.ldo + head * HD + 4 * half;
+  if (p.lse_in || p.lse_out) {  // two-phase attention (uniform, off on the single-GPU path)
+    float lse = m_run + __builtin_amdgcn_logf(l_tot);  // v_log_f32 is log2; scores are in log2 units
+    if (p.lse_in) {
+      // O holds the normalised result over the keys of the earlier launch: combine with weights
+      // 2^(lse_prev - M) and 2^(lse - M)
+      const float lse_prev = p.lse_in[(size_t)head * p.Lq_pad + qrow];
+      const float mm = fmaxf(lse, lse_prev);
+      const float wa = __builtin_amdgcn_exp2f(lse_prev - mm), wb = __builtin_amdgcn_exp2f(lse - mm);
+      const float rden = 1.0f / (wa + wb);
+      const float ca = wa * rden, cb = wb * rden * inv;
+      inv = 1.0f;
+      lse = mm + __builtin_amdgcn_logf(wa + wb);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x2 pv = *(const u32x2*)(op + db * 32 + 8 * g);
+          o[db][4 * g] = o[db][4 * g] * cb + __uint_as_float(pv[0] << 16) * ca;
+          o[db][4 * g + 1] = o[db][4 * g + 1] * cb + __uint_as_float(pv[0] & 0xffff0000u) * ca;
+          o[db][4 * g + 2] = o[db][4 * g + 2] * cb + __uint_as_float(pv[1] << 16) * ca;
+          o[db][4 * g + 3] = o[db][4 * g + 3] * cb + __uint_as_float(pv[1] & 0xffff0000u) * ca;
+        }
+      }
+    }
+    if (p.lse_out && half == 0) p.lse_out[(size_t)head * p.Lq_pad + qrow] = lse;
+  }
 #pragma unroll
   for (int db = 0; db < 4; ++db) {
 #pragma unroll

@@ -78,6 +78,7 @@ struct mc_engine {
         *ln_img4_b = nullptr;
   int img_rows = 0;     // 257 image tokens padded to a multiple of 64
   bool have_clip = false;
+  int local_attn_layer = -1;  // layer whose local-shard attention already ran (two-phase SP attention)
   float* cs_table = nullptr;  // rope (cos,sin) [Lp][64][2]
   std::map<std::string, Slot> slots;
   std::vector<void*> owned;
@@ -341,6 +342,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_buf(e, cur, "ckv_img", ir * 2 * d * 2);
     add_buf(e, cur, "ao2", Lp * d * 2);
   }
+  if (e->P > 1) add_buf(e, cur, "attn_lse", (size_t)e->H * Lp * 4);
   add_buf(e, cur, "calib_partial", 1024 * 4 * 8);
   add_buf(e, cur, "calib_sums", 4 * 8);
   add_buf(e, cur, "calib_stats", 2 * 3 * 4);
@@ -570,6 +572,27 @@ mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream_) {
   return MC_OK;
 }
 
+// Self-attention over this rank's own K/V shard (slot `rank` of "kv_gather"): normalised partial result -> "ao",
+// log2-sum-exp -> "attn_lse".  Needs nothing from the other ranks, so the caller overlaps it with the all-gather.
+mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
+  if (e->P < 2) return fail(MC_ESTATE, "mc_block_attn_local needs sp_size > 1");
+  const int d = e->d, Lp = e->Lp;
+  bf16_t* kvl = e->buf<bf16_t>("kv_local");
+  mc::AttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.O = e->buf<bf16_t>("ao"); a.ldo = d; a.Lq_pad = Lp; a.n_heads = e->H; a.scale = 1.0f / std::sqrt(128.0f);
+  a.Q = e->buf<bf16_t>("qkv"); a.ldq = d;
+  a.K = kvl; a.ldk = 2 * d; a.V = kvl + d; a.ldv = 2 * d;
+  a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
+  a.lse_out = e->buf<float>("attn_lse");
+  HIP_TRY(mc::launch_attention(a, s));
+  e->local_attn_layer = layer;
+  return MC_OK;
+}
+
 // attention -> o (+gated residual) -> norm3 -> cross-attn (+residual) -> LN+mod -> FFN (+gated residual)
 mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
@@ -601,6 +624,11 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
       a.K = kvg; a.ldk = 2 * d; a.k_shard_stride = (long)Lp * 2 * d;
       a.V = kvg + d; a.ldv = 2 * d; a.v_shard_stride = (long)Lp * 2 * d;
       a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = e->P;
+      if (e->local_attn_layer == layer) {  // the local shard is done: the others only, merged into ao
+        a.skip_shard_p1 = e->rank + 1;
+        a.lse_in = e->buf<float>("attn_lse");
+      }
+      e->local_attn_layer = -1;
     }
     HIP_TRY(mc::launch_attention(a, s));
   }
@@ -791,6 +819,23 @@ mc_status mc_op_attention(const void* Q, long ldq, const void* K, long ldk, long
   a.n_shards = n_shards; a.scale = scale;
   hipError_t err = mc::launch_attention(a, (hipStream_t)s);
   if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "attention: unsupported shape");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_attention_partial(const void* Q, long ldq, const void* K, long ldk, long kss, const void* V, long ldv,
+                                  long vss, void* O, long ldo, int Lq_pad, int n_heads, int shard_rows,
+                                  int shard_valid, int n_shards, float scale, int skip_shard, float* lse_out,
+                                  const float* lse_in, mc_stream s) {
+  mc::AttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.k_shard_stride = kss;
+  a.V = (const bf16_t*)V; a.ldv = ldv; a.v_shard_stride = vss; a.O = (bf16_t*)O; a.ldo = ldo;
+  a.Lq_pad = Lq_pad; a.n_heads = n_heads; a.shard_rows = shard_rows; a.shard_valid = shard_valid;
+  a.n_shards = n_shards; a.scale = scale;
+  a.skip_shard_p1 = skip_shard >= 0 ? skip_shard + 1 : 0; a.lse_out = lse_out; a.lse_in = lse_in;
+  hipError_t err = mc::launch_attention(a, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "attention: unsupported shape / shard selection");
   HIP_TRY(err);
   return MC_OK;
 }

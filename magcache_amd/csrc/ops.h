@@ -52,6 +52,12 @@ struct AttnParams {
   int shard_valid;  // valid keys at the start of every shard
   int n_shards;
   float scale;      // softmax scale (1/sqrt(128))
+  // Two-phase attention (sequence parallel: the local K/V shard is attended while the other shards are still in
+  // flight over xGMI, the rest afterwards).  All three default to "off" when the struct is zero-filled.
+  int skip_shard_p1;    // k + 1: shard k is left out of the key sequence; 0: none
+  float* lse_out;       // [n_heads][Lq_pad] log2-sum-exp of the scaled scores of the keys visited, or null
+  const float* lse_in;  // not null: O already holds the normalised result over OTHER keys whose log2-sum-exp is
+                        // lse_in; the kernel merges both and writes the combined O (and lse_out if given)
 };
 // K/V rows in [shard_valid, shard_rows) are read (and masked) but must hold finite values.
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);     // picks a kernel

@@ -191,6 +191,9 @@ class Engine:
     def block_pre_attn(self, layer):
         check(self.lib.mc_block_pre_attn(self.h, layer, _stream()))
 
+    def block_attn_local(self, layer):
+        check(self.lib.mc_block_attn_local(self.h, layer, _stream()))
+
     def block_post_attn(self, layer, branch, mode):
         check(self.lib.mc_block_post_attn(self.h, layer, branch, mode, _stream()))
 

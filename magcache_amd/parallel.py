@@ -13,6 +13,13 @@ forward is bound on the instance and shadows the class-level MagCache patch), so
 Gather layout: "kv_gather" = [P][Lp][2*dim] bf16; rank r's pre_attn writes rows [k | v] of its own
 tokens into slot r; after the all-gather the attention kernel walks P shards of Lp rows of which
 the first L/P are valid.
+
+Overlap: the all-gather is issued asynchronously (RCCL runs it on its own stream) and, while the other
+shards cross xGMI, the attention kernel already runs over the LOCAL shard (engine.block_attn_local:
+1/P of the layer's attention, which is about what one peer's shard needs on its link); block_post_attn
+then attends the P-1 remote shards and merges the two partial softmaxes by their log-sum-exp in the
+kernel epilogue.  Nothing else in a layer is independent of the gathered K/V, so this is the overlap
+the data flow allows.
 """
 import torch
 import torch.distributed as dist
@@ -91,12 +98,13 @@ class SequenceParallelForward:
         self.tokens_full = torch.empty(self.L, 64, dtype=torch.float32, device=self.kv.device)
 
     def _all_gather_kv(self):
+        """Start the K/V all-gather; returns a work handle to wait on (None: already complete)."""
         mine = self.kv[self.rank]
         if self.inplace:
             # RCCL in-place all-gather: the send chunk is this rank's slot of the receive buffer
-            dist.all_gather_into_tensor(self.kv.view(-1), mine.reshape(-1), group=self.group)
-        else:
-            dist.all_gather([self.kv[r] for r in range(self.P)], mine.clone(), group=self.group)
+            return dist.all_gather_into_tensor(self.kv.view(-1), mine.reshape(-1), group=self.group, async_op=True)
+        dist.all_gather([self.kv[r] for r in range(self.P)], mine.clone(), group=self.group)
+        return None
 
     def forward(self, latent, t, context, branch, mode, out=None):
         e = self.e
@@ -106,7 +114,10 @@ class SequenceParallelForward:
         if mode != MC_MODE_SKIP:
             for layer in range(self.NL):
                 e.block_pre_attn(layer)
-                self._all_gather_kv()
+                work = self._all_gather_kv()
+                e.block_attn_local(layer)          # overlaps the gather: needs only this rank's shard
+                if work is not None:
+                    work.wait()                    # stream dependency, no host sync
                 e.block_post_attn(layer, branch, mode)
             if mode == MC_MODE_CALIB:
                 has = e.calib_has_stats(branch)

@@ -63,6 +63,9 @@ class CpuShardEngine:
             kv[self.sp_rank, :self.Lr] = torch.cat([k, v], dim=-1).to(torch.bfloat16)
             self._kv_exact = torch.cat([k, v], dim=-1)
 
+    def block_attn_local(self, layer):
+        self.local_calls = getattr(self, "local_calls", 0) + 1   # the stand-in attends all shards in post_attn
+
     def block_post_attn(self, layer, branch, mode):
         b = self.o.blocks[layer]
         o = self.o

@@ -38,6 +38,14 @@ def attention(Q, K, V, O, n_heads, shard_rows, shard_valid, n_shards, scale, k_s
                               n_shards, scale, S()))
 
 
+def attention_partial(Q, K, V, O, n_heads, shard_rows, shard_valid, n_shards, scale, shard_stride, skip_shard=-1,
+                      lse_out=None, lse_in=None):
+    lib = _lib.load()
+    check(lib.mc_op_attention_partial(P(Q), Q.stride(0), P(K), K.stride(0), shard_stride, P(V), V.stride(0),
+                                      shard_stride, P(O), O.stride(0), Q.shape[0], n_heads, shard_rows, shard_valid,
+                                      n_shards, scale, skip_shard, P(lse_out), P(lse_in), S()))
+
+
 def ln_modulate(x, sc, sh, mode, eps, out_bf16=None, out_f32=None, x0=None):
     lib = _lib.load()
     M, D = x.shape

@@ -148,6 +148,54 @@ def test_attention_vs_fp32_reference(Lq, heads, shard_rows, valid, n_shards, ker
     assert rel_l2(o, want) < 1e-2
 
 
+@pytest.mark.parametrize("Lq,heads,shard_rows,valid,n_shards,local", [(256, 2, 256, 193, 2, 0), (256, 2, 256, 193, 2, 1),
+                                                                      (512, 1, 128, 77, 4, 2), (256, 3, 192, 192, 3, 2),
+                                                                      (256, 1, 64, 1, 8, 5)])
+def test_attention_two_phase_local_then_remote(Lq, heads, shard_rows, valid, n_shards, local):
+    """Sequence-parallel overlap: the local shard first (writes O and the log2-sum-exp), then all shards but the
+    local one merged in the kernel epilogue == one pass over all shards == the fp32 reference."""
+    d = heads * 128
+    q = rnd(Lq, d, seed=1, dtype=torch.bfloat16)
+    k = rnd(n_shards * shard_rows, d, seed=2, dtype=torch.bfloat16)
+    v = rnd(n_shards * shard_rows, d, seed=3, dtype=torch.bfloat16)
+    k[local * shard_rows + 3] = q[5] * 4.0      # one dominant local key, so the two parts carry very different weights
+    rows = torch.arange(n_shards * shard_rows, device=DEV)
+    invalid = (rows % shard_rows) >= valid
+    k[invalid] = 50.0
+    v[invalid] = 1000.0
+    sc, ss = 1 / math.sqrt(128), shard_rows * d
+    one = torch.zeros(Lq, d, dtype=torch.bfloat16, device=DEV)
+    H.attention(q, k, v, one, heads, shard_rows, valid, n_shards, sc, k_shard_stride=ss, v_shard_stride=ss)
+    o = torch.zeros(Lq, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((heads, Lq), float("nan"), device=DEV)
+    kl, vl = k[local * shard_rows:(local + 1) * shard_rows], v[local * shard_rows:(local + 1) * shard_rows]
+    H.attention_partial(q, kl, vl, o, heads, shard_rows, valid, 1, sc, 0, lse_out=lse)
+    # the partial result is itself a correct attention over the local keys, and lse is their log2-sum-exp
+    loc_rows = rows[local * shard_rows:local * shard_rows + valid]
+    torch.testing.assert_close(o.float(), attn_ref(q, k, v, heads, loc_rows), rtol=2e-2, atol=2e-2)
+    s_loc = (q.float().view(Lq, heads, 128).transpose(0, 1) @ k.float()[loc_rows].view(-1, heads, 128).transpose(0, 1)
+             .transpose(1, 2)) * sc
+    torch.testing.assert_close(lse, torch.logsumexp(s_loc, -1) / math.log(2), rtol=1e-2, atol=5e-2)
+    lse2 = torch.empty_like(lse)
+    H.attention_partial(q, k, v, o, heads, shard_rows, valid, n_shards, sc, ss, skip_shard=local, lse_out=lse2, lse_in=lse)
+    want = attn_ref(q, k, v, heads, rows[~invalid])
+    torch.testing.assert_close(o.float(), want, rtol=2e-2, atol=2e-2)
+    assert rel_l2(o, want) < 1e-2
+    assert rel_l2(o, one) < 1e-2          # two roundings to bf16 instead of one
+    s_all = (q.float().view(Lq, heads, 128).transpose(0, 1) @ k.float()[rows[~invalid]].view(-1, heads, 128)
+             .transpose(0, 1).transpose(1, 2)) * sc
+    torch.testing.assert_close(lse2, torch.logsumexp(s_all, -1) / math.log(2), rtol=1e-2, atol=5e-2)
+
+
+def test_attention_two_phase_rejects_bad_selection():
+    q = rnd(256, 128, dtype=torch.bfloat16)
+    o = torch.zeros_like(q)
+    with pytest.raises(RuntimeError):          # cannot skip the only shard
+        H.attention_partial(q, q, q, o, 1, 256, 256, 1, 0.1, 0, skip_shard=0)
+    with pytest.raises(RuntimeError):
+        H.attention_partial(q, q, q, o, 1, 64, 64, 4, 0.1, 64 * 128, skip_shard=4)
+
+
 def test_attention_strided_qkv_and_online_softmax_rescale(kernel_variant):
     """q/k/v interleaved in one [L, 3d] buffer (the engine's layout) and a key whose score dwarfs all
     earlier tiles, forcing the running-max rescale late in the loop"""
