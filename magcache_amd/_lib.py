@@ -74,7 +74,28 @@ SIGNATURES = {
     "mc_op_cast_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "mc_op_lincomb": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "mc_op_rope_table": (_i, [_i, _i, _i, _i, _i, _vp]),
+    # include/magcache_mmdit.h
+    "mc_mmdit_create": (_i, [_vp, C.POINTER(_vp)]),
+    "mc_mmdit_destroy": (None, [_vp]),
+    "mc_mmdit_workspace_bytes": (_sz, [_vp]),
+    "mc_mmdit_set_workspace": (_i, [_vp, _vp, _sz]),
+    "mc_mmdit_buffer_info": (_i, [_vp, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mc_mmdit_set_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i, _vp]),
+    "mc_mmdit_weights_missing": (_i, [_vp, C.c_char_p, _sz]),
+    "mc_mmdit_set_rope": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "mc_mmdit_forward": (_i, [_vp, _vp, _d, _d, _vp, _i, _vp, _i, _vp, _vp]),
+    "mc_mmdit_calib_stats": (_i, [_vp, C.POINTER(C.c_float), _vp]),
+    "mc_mmdit_state_reset": (_i, [_vp]),
 }
+
+
+class McMmditConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("family", "dim", "num_heads", "n_double", "n_single", "in_channels", "out_channels",
+                                       "txt_dim", "txt_len", "vec_dim", "img_tokens", "latent_f", "latent_h", "latent_w",
+                                       "refiner_depth", "calibration")]
+
+
+MC_FAMILY_FLUX, MC_FAMILY_HUNYUAN = 0, 1
 
 _lib = None
 

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagcache_hip.so")
 SOURCES = ["gemm_bf16.hip", "gemm_bf16_big.hip", "attention.hip", "attention_v2.hip", "attention_v3.hip", "elementwise.hip",
-           "magcache_ops.hip", "engine.cpp", "rule.cpp"]
+           "magcache_ops.hip", "engine.cpp", "mmdit_engine.cpp", "rule.cpp"]
 # attention_v2's hand-interleaved VALU stream must stay scalar: the SLP vectoriser packs the row-sum
 # adds into v_pk_add_f32 and moves them out of the MFMA shadow
 EXTRA_FLAGS = {"attention_v2.hip": ["-fno-slp-vectorize"], "attention_v3.hip": ["-fno-slp-vectorize"]}
@@ -29,6 +29,7 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, h) for h in ("common.h", "ops.h", "gemm_epilogue.h")]
     headers.append(os.path.join(HERE, "..", "include", "magcache_hip.h"))
+    headers.append(os.path.join(HERE, "..", "include", "magcache_mmdit.h"))
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []

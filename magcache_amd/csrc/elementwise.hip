@@ -127,6 +127,98 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ MM-DiT per-head RMSNorm + RoPE (q and k)
+// One wave per row; a head is 128 channels = 64 lanes x one (2i, 2i+1) pair, i.e. exactly one RoPE pair per lane.
+__global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__ x, long ldx, long k_col0,
+                                                            const float* __restrict__ wq,
+                                                            const float* __restrict__ wk, float eps,
+                                                            const float* __restrict__ cs, int cs_row0, int M,
+                                                            int n_heads) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float cc = 1.f, sn = 0.f;
+  if (cs) {
+    const f32x2 t = *(const f32x2*)(cs + (size_t)(cs_row0 + row) * 128 + 2 * lane);
+    cc = t[0];
+    sn = t[1];
+  }
+#pragma unroll 1
+  for (int part = 0; part < 2; ++part) {
+    uint32_t* xr = (uint32_t*)(x + (size_t)row * ldx + (part ? k_col0 : 0)) + lane;
+    const float* w = part ? wk : wq;
+    f32x2 wv = {1.f, 1.f};
+    if (w) wv = *(const f32x2*)(w + 2 * lane);
+    for (int h = 0; h < n_heads; ++h) {
+      const uint32_t b = xr[h * 64];
+      float re = __uint_as_float(b << 16), im = __uint_as_float(b & 0xffff0000u);
+      if (w) {
+        // upstream RMSNorm (diffusers / hyvideo): norm in fp32, cast to the activation dtype, then * weight
+        const float rstd = rsqrtf(wave_sum(re * re + im * im) * (1.0f / 128.0f) + eps);
+        re = bf16_round(re * rstd) * wv[0];
+        im = bf16_round(im * rstd) * wv[1];
+        if (cs) {  // the weighted value is a bf16 tensor upstream before RoPE is applied in fp32
+          re = bf16_round(re);
+          im = bf16_round(im);
+        }
+      }
+      const float r2 = re * cc - im * sn, i2 = re * sn + im * cc;
+      xr[h * 64] = pack_bf16x2(r2, i2);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemv_bf16w_kernel(const bf16_t* __restrict__ Wt, const float* __restrict__ x,
+                                                         const float* __restrict__ b, float* __restrict__ y, int N,
+                                                         int K, int act_in, int act_out, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const bf16_t* wr = Wt + (size_t)n * K;
+  float acc = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const u32x4 wv = *(const u32x4*)(wr + k);
+    f32x4 x0 = *(const f32x4*)(x + k), x1 = *(const f32x4*)(x + k + 4);
+    if (act_in == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x0[j] = silu(x0[j]);
+        x1[j] = silu(x1[j]);
+      }
+    }
+    acc += (__uint_as_float(wv[0] << 16) * x0[0] + __uint_as_float(wv[0] & 0xffff0000u) * x0[1]) +
+           (__uint_as_float(wv[1] << 16) * x0[2] + __uint_as_float(wv[1] & 0xffff0000u) * x0[3]) +
+           (__uint_as_float(wv[2] << 16) * x1[0] + __uint_as_float(wv[2] & 0xffff0000u) * x1[1]) +
+           (__uint_as_float(wv[3] << 16) * x1[2] + __uint_as_float(wv[3] & 0xffff0000u) * x1[3]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float r = acc + (b ? b[n] : 0.f);
+    if (act_out == 1) r = silu(r);
+    y[n] = accumulate ? y[n] + r : r;
+  }
+}
+
+// column mean over the first n_rows rows (fp32 in, fp32 out); one thread per column, rows strided over blockIdx.y
+__global__ void colmean_kernel(const float* __restrict__ x, long ldx, int n_rows, int D, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float s = 0.f;
+  for (int r = 0; r < n_rows; ++r) s += x[(size_t)r * ldx + c];
+  out[c] = s / (float)n_rows;
+}
+
+// (cos, sin) tables [n, 128] with every frequency repeated twice (diffusers / hyvideo use_real layout) -> the
+// engine's [n][64][(cos,sin)] table
+__global__ void rope_table_from_cos_sin_kernel(const float* __restrict__ cosv, const float* __restrict__ sinv, long ld,
+                                               int n_rows, float* __restrict__ cs) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)n_rows * 64) return;
+  const int r = (int)(i >> 6), p = (int)(i & 63);
+  cs[2 * i] = cosv[(size_t)r * ld + 2 * p];
+  cs[2 * i + 1] = sinv[(size_t)r * ld + 2 * p];
+}
+
 // ------------------------------------------------------------------ patch im2col / unpatchify, patch (1,2,2)
 __global__ void patchify_kernel(const float* __restrict__ lat, int C, int F, int H, int W, int tok0, int n_tok,
                                 int n_rows, bf16_t* __restrict__ out, long ldo) {
@@ -361,6 +453,36 @@ hipError_t launch_rmsnorm_rope(bf16_t* x, long ldx, const float* w, float eps, c
   if (M <= 0 || D <= 0 || (D % 128) != 0 || (ldx % 8) != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, ldx, w, eps, cs, cs_row0, M,
                      D);
+  return hipGetLastError();
+}
+
+hipError_t launch_headnorm_rope(bf16_t* x, long ldx, long k_col0, const float* wq, const float* wk, float eps,
+                                const float* cs, int cs_row0, int M, int n_heads, hipStream_t stream) {
+  if (M <= 0 || n_heads <= 0 || (ldx % 2) != 0 || (k_col0 % 2) != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(headnorm_rope_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, ldx, k_col0, wq, wk, eps, cs,
+                     cs_row0, M, n_heads);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemv_bf16w(const bf16_t* W, const float* x, const float* b, float* y, int N, int K, int act_in,
+                             int act_out, int accumulate, hipStream_t stream) {
+  if ((K % 8) != 0 || N <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gemv_bf16w_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, x, b, y, N, K, act_in, act_out,
+                     accumulate);
+  return hipGetLastError();
+}
+
+hipError_t launch_colmean(const float* x, long ldx, int n_rows, int D, float* out, hipStream_t stream) {
+  if (n_rows <= 0 || D <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(colmean_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, x, ldx, n_rows, D, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_rope_table_from_cos_sin(const float* cosv, const float* sinv, long ld, int n_rows, float* cs,
+                                          hipStream_t stream) {
+  if (n_rows <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rope_table_from_cos_sin_kernel, dim3(((long)n_rows * 64 + 255) / 256), dim3(256), 0, stream, cosv,
+                     sinv, ld, n_rows, cs);
   return hipGetLastError();
 }
 

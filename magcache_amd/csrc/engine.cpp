@@ -174,6 +174,14 @@ mc::GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, const fl
 
 }  // namespace
 
+namespace mc {
+// error text shared with the other engines of this library (mmdit_engine.cpp): mc_last_error() reports it
+mc_status set_error_v(mc_status s, const char* fmt, va_list ap) {
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  return s;
+}
+}  // namespace mc
+
 extern "C" {
 
 const char* mc_last_error(void) { return g_err; }

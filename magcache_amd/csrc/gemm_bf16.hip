@@ -184,6 +184,7 @@ hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stre
     case EPI_EMBED: return launch_t<EPI_EMBED>(p, stream);
     case EPI_F32: return launch_t<EPI_F32>(p, stream);
     case EPI_GELU_ERF_BF16: return launch_t<EPI_GELU_ERF_BF16>(p, stream);
+    case EPI_SILU_BF16: return launch_t<EPI_SILU_BF16>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -197,8 +198,9 @@ int g_gemm_kernel = 0;
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
   bool big = false;
-  if (g_gemm_kernel != 1 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && gemm_bf16_big_supported(p)) {
-    const long tiles = (long)(p.M / 256) * (p.N / 256);
+  if (g_gemm_kernel != 1 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
+      gemm_bf16_big_supported(p)) {
+    const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
     big = (g_gemm_kernel == 2) || (p.K >= 1024 && tiles >= 256);
   }
   return big ? launch_gemm_bf16_big(p, epi, stream) : launch_gemm_bf16_small(p, epi, stream);

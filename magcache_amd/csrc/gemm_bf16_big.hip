@@ -1,5 +1,6 @@
 // 256x256x64 bf16 MFMA GEMM for gfx950 with a counted-vmcnt LDS-DMA pipeline:
-//   C[M,N] = A[M,K] * W[N,K]^T  (+ the fused epilogues of gemm_epilogue.h),  M % 256 == N % 256 == 0.
+//   C[M,N] = A[M,K] * W[N,K]^T  (+ the fused epilogues of gemm_epilogue.h),  N % 256 == 0; a partial last M
+//   tile re-reads row M-1 for its missing rows and does not write them.
 //
 // This is the kernel behind the large Linears of the Wan DiT block (QKV, cross-Q, FFN-1, FFN-2 at
 // M = 32768 tokens; reference call site MagCache4Wan2.1/magcache_generate.py:297-298, the Linear
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
     for (int j = 0; j < 2; ++j) {
       const int r = (wv * 2 + j) * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-      const int ra = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      const int ra = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
       const int rw = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
       srcA[h][j] = ((uint32_t)ra * (uint32_t)p.lda + chunk * 8) * 2u;
       srcW[h][j] = ((uint32_t)rw * (uint32_t)p.ldw + chunk * 8) * 2u;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
       const int m = m0 + wr * 128 + mh * 64 + ms * 32 + l31;
+      if (m >= p.M) continue;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
 #pragma unroll
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
 
 template <int EPI>
 hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
-  const int tilesM = p.M / TB, tilesN = p.N / TB;
+  const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<EPI>,
@@ -356,8 +358,8 @@ hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 bool gemm_bf16_big_supported(const GemmParams& p) {
-  // 32-bit byte offsets for the DMA sources; 256-multiples; an even number (>= 4) of K tiles
-  return p.M > 0 && p.N > 0 && (p.M % TB) == 0 && (p.N % TB) == 0 && (p.K % (2 * BK)) == 0 && p.K >= 4 * BK &&
+  // 32-bit byte offsets for the DMA sources; N a 256-multiple; an even number (>= 4) of K tiles
+  return p.M > 0 && p.N > 0 && (p.N % TB) == 0 && (p.K % (2 * BK)) == 0 && p.K >= 4 * BK &&
          (p.lda % 8) == 0 && (p.ldw % 8) == 0 && (size_t)p.M * (size_t)p.lda < (1ull << 31) &&
          (size_t)p.N * (size_t)p.ldw < (1ull << 31);
 }

@@ -25,7 +25,7 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
 // val = acc + bias for columns n..n+3 of row m.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_quad(const GemmParams& p, int m, int n, f32x4 val) {
-  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_GELU_ERF_BF16) {
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_SILU_BF16) {
     if constexpr (EPI == EPI_GELU_BF16) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) val[i] = gelu_tanh_fast(bf16_round(val[i]));
@@ -36,6 +36,10 @@ __device__ __forceinline__ void gemm_epilogue_quad(const GemmParams& p, int m, i
         const float x = bf16_round(val[i]);
         val[i] = 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
       }
+    }
+    if constexpr (EPI == EPI_SILU_BF16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) val[i] = silu(bf16_round(val[i]));
     }
     u32x2 o = {pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
     *(u32x2*)(p.Cb + (size_t)m * p.ldc + n) = o;

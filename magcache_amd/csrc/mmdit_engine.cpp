@@ -1,0 +1,706 @@
+// MM-DiT engine behind include/magcache_mmdit.h: FLUX.1 (diffusers FluxTransformer2DModel) and HunyuanVideo
+// (hyvideo HYVideoDiffusionTransformer) forward with the MagCache skip path, on the kernels of this library.
+//
+// Reference boundary: the body of magcache_forward in MagCache4FLUX/magcache_flux.py:301-432 and
+// MagCache4HunyuanVideo/magcache_sample_video.py:40-146; the blocks are upstream code (see oracle/flux_ref.py and
+// oracle/hunyuan_ref.py for the restatement this engine is tested against).
+//
+// Data layout in HBM (one caller-owned workspace; d = dim, S = txt_len + img_tokens, S_pad = S up to 256):
+//   x    fp32 [S_pad, d]    joint residual stream.  Row order = the family's attention order: FLUX [text ; image],
+//                           HunyuanVideo [image ; text] -- the two streams of a double block are row ranges of it,
+//                           so the single blocks need no concatenation (reference cat: flux :389, hunyuan :122)
+//   x0   bf16 [img, d]      ori_hidden_states / ori_img (flux :351, hunyuan :104) for the residual and the skip path
+//   xn   bf16 [S_pad, d]    LayerNorm + modulation output (GEMM operand)
+//   qkv  bf16 [S_pad, 3d]   q | k | v of the joint sequence (attention reads it in place, strided)
+//   am   bf16 [S_pad, 5d]   columns [0,d): attention output; [d,5d): GELU(MLP-in) -- exactly the operand of the
+//                           single block's fused output projection (cat([attn, mlp]) upstream) with K = 5d
+//   emod fp32               every block's modulation vector, produced by ONE bf16-weight GEMV over silu(vec)
+//   residual0/1 fp32 [img, d]   MagCache residual cache (+ the previous one in calibration mode)
+// GEMMs over one stream use the exact row count (the 256^2 kernel guards a partial last tile), so neighbouring
+// rows of the other stream are never touched.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/magcache_mmdit.h"
+#include "ops.h"
+
+using mc::bf16_t;
+
+namespace mc {
+mc_status set_error_v(mc_status s, const char* fmt, va_list ap);  // engine.cpp
+}
+
+namespace {
+
+mc_status fail(mc_status s, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  mc_status r = mc::set_error_v(s, fmt, ap);
+  va_end(ap);
+  return r;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(MC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define MC_TRY(expr)                 \
+  do {                               \
+    mc_status _s = (expr);           \
+    if (_s != MC_OK) return _s;      \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Slot {
+  void* dst = nullptr;
+  mc_dtype dst_dtype = MC_F32;
+  size_t numel = 0, off = 0;
+  int perm_c = 0;  // > 0: rows are (c, pq) channel-major upstream and are stored (pq, c) -- HunyuanVideo final linear
+  bool loaded = false;
+};
+struct Buf {
+  size_t off = 0, bytes = 0;
+};
+
+struct Stream {  // one stream (image or text) of a double block
+  bf16_t *wqkv, *wo, *w1, *w2;
+  float *bqkv, *bo, *b1, *b2, *qn, *kn;
+};
+struct Single {
+  bf16_t *w_in, *w_out;  // w_in = [q;k;v;mlp] rows [7d, d]; w_out [d, 5d]
+  float *b_in, *b_out, *qn, *kn;
+};
+struct Mlp2 {  // Linear, SiLU, Linear on a vector
+  bf16_t *w1, *w2;
+  float *b1, *b2;
+  int k_in;
+};
+struct Refiner {
+  bf16_t *wqkv, *wo, *w1, *w2, *wada;
+  float *bqkv, *bo, *b1, *b2, *bada, *n1w, *n1b, *n2w, *n2b;
+};
+
+mc::GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, const float* bias, int M, int N, int K) {
+  mc::GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.M = M; p.N = N; p.K = K;
+  return p;
+}
+
+}  // namespace
+
+struct mc_mmdit {
+  mc_mmdit_config cfg;
+  int d, H, Li, Lt, S, Sp, Kin, Kp, img0, txt0, out_feat;
+  size_t mod_rows = 0;  // rows of the fused modulation matrix
+  std::vector<Stream> dimg, dtxt;
+  std::vector<Single> singles;
+  std::vector<Refiner> refiners;
+  Mlp2 time_mlp, guid_mlp, vec_mlp, ref_t_mlp, ref_c_mlp;
+  bf16_t *w_in = nullptr, *w_ctx = nullptr, *w_mod = nullptr;
+  float *b_in = nullptr, *b_ctx = nullptr, *b_mod = nullptr, *w_head = nullptr, *b_head = nullptr;
+  float* cs = nullptr;  // RoPE (cos,sin) [Sp][64][2]
+  std::map<std::string, Slot> slots;
+  std::vector<void*> owned;
+  char* ws = nullptr;
+  size_t ws_need = 0;
+  std::map<std::string, Buf> bufs;
+  int res_cur = 0;  // slot holding residual_cache / previous_residual
+  bool have_res = false, have_stats = false, pads_clean = false;
+
+  template <class T>
+  T* buf(const char* name) const {
+    return reinterpret_cast<T*>(ws + bufs.find(name)->second.off);
+  }
+  float* residual(int i) const { return buf<float>(i ? "residual1" : "residual0"); }
+  size_t mod_double(int blk, int stream) const { return ((size_t)blk * 2 + stream) * 6 * d; }
+  size_t mod_single(int blk) const { return (size_t)cfg.n_double * 12 * d + (size_t)blk * 3 * d; }
+  size_t mod_final() const { return (size_t)cfg.n_double * 12 * d + (size_t)cfg.n_single * 3 * d; }
+};
+
+namespace {
+
+template <class T>
+mc_status dev_alloc(mc_mmdit* e, T** p, size_t n) {
+  void* q = nullptr;
+  hipError_t err = hipMalloc(&q, n * sizeof(T) + 256);
+  if (err != hipSuccess) return fail(MC_ENOMEM, "hipMalloc(%zu) failed: %s", n * sizeof(T), hipGetErrorString(err));
+  e->owned.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return MC_OK;
+}
+
+void add_slot(mc_mmdit* e, const std::string& name, void* dst, mc_dtype dt, size_t numel, size_t off = 0) {
+  Slot s;
+  s.dst = dst; s.dst_dtype = dt; s.numel = numel; s.off = off;
+  e->slots[name] = s;
+}
+
+void add_buf(mc_mmdit* e, size_t& cur, const char* name, size_t bytes) {
+  Buf b;
+  b.off = cur; b.bytes = bytes;
+  e->bufs[name] = b;
+  cur = align_up(cur + bytes, 256);
+}
+
+#define ALLOC(ptr, n) MC_TRY(dev_alloc(e, &(ptr), (n)))
+
+// Linear slots "<prefix>.weight" [n_out, n_in] (bf16) and "<prefix>.bias" [n_out] (fp32) inside fused destinations
+void linear_slot(mc_mmdit* e, const std::string& prefix, bf16_t* w, float* b, size_t n_out, size_t n_in,
+                 size_t row_off = 0) {
+  add_slot(e, prefix + ".weight", w, MC_BF16, n_out * n_in, row_off * n_in);
+  add_slot(e, prefix + ".bias", b, MC_F32, n_out, row_off);
+}
+
+mc_status alloc_mlp2(mc_mmdit* e, Mlp2& m, int k_in, const std::string& l1, const std::string& l2) {
+  const size_t d = e->d;
+  m.k_in = k_in;
+  ALLOC(m.w1, d * k_in); ALLOC(m.b1, d); ALLOC(m.w2, d * d); ALLOC(m.b2, d);
+  linear_slot(e, l1, m.w1, m.b1, d, k_in);
+  linear_slot(e, l2, m.w2, m.b2, d, d);
+  return MC_OK;
+}
+
+mc_status alloc_stream(mc_mmdit* e, Stream& s) {
+  const size_t d = e->d;
+  ALLOC(s.wqkv, 3 * d * d); ALLOC(s.bqkv, 3 * d); ALLOC(s.wo, d * d); ALLOC(s.bo, d);
+  ALLOC(s.w1, 4 * d * d); ALLOC(s.b1, 4 * d); ALLOC(s.w2, 4 * d * d); ALLOC(s.b2, d);
+  ALLOC(s.qn, 128); ALLOC(s.kn, 128);
+  return MC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
+  if (!cfg || !out) return fail(MC_EINVAL, "null argument");
+  const mc_mmdit_config& c = *cfg;
+  const bool hy = c.family == MC_FAMILY_HUNYUAN;
+  if (c.family != MC_FAMILY_FLUX && !hy) return fail(MC_EINVAL, "unknown family %d", c.family);
+  if (c.num_heads <= 0 || c.dim != c.num_heads * 128) return fail(MC_EINVAL, "dim must be num_heads * 128 (head_dim 128)");
+  if ((c.dim % 256) != 0) return fail(MC_EINVAL, "dim %d must be a multiple of 256", c.dim);
+  if (c.n_double < 0 || c.n_single < 0 || c.n_double + c.n_single == 0) return fail(MC_EINVAL, "no blocks");
+  if (c.txt_len <= 0 || c.txt_dim <= 0 || (c.txt_dim % 64) != 0 || c.vec_dim <= 0 || (c.vec_dim % 8) != 0)
+    return fail(MC_EINVAL, "bad text geometry");
+  if (c.img_tokens <= 0) return fail(MC_EINVAL, "img_tokens must be positive");
+  if (hy) {
+    if ((c.latent_h & 1) || (c.latent_w & 1) || c.img_tokens != c.latent_f * (c.latent_h / 2) * (c.latent_w / 2))
+      return fail(MC_EINVAL, "img_tokens must equal F*(H/2)*(W/2) of the latent grid");
+    if (c.out_channels * 4 > 64) return fail(MC_EINVAL, "out_channels*4 > 64 unsupported by the head kernel");
+  } else if (c.out_channels > 64 || c.refiner_depth != 0) {
+    return fail(MC_EINVAL, "FLUX: out_channels <= 64, no refiner");
+  }
+  mc_mmdit* e = new mc_mmdit();
+  e->cfg = c;
+  e->d = c.dim; e->H = c.num_heads; e->Li = c.img_tokens; e->Lt = c.txt_len;
+  e->S = e->Li + e->Lt;
+  e->Sp = (int)align_up(e->S, 256);
+  e->Kin = hy ? c.in_channels * 4 : c.in_channels;
+  e->Kp = (int)align_up(e->Kin, 64);
+  e->img0 = hy ? 0 : e->Lt;
+  e->txt0 = hy ? e->Li : 0;
+  e->out_feat = hy ? c.out_channels * 4 : c.out_channels;
+  const size_t d = e->d;
+  const bool flux = !hy;
+  auto cleanup = [&](mc_status st) { mc_mmdit_destroy(e); return st; };
+#define TRY_C(expr) do { mc_status _s = (expr); if (_s != MC_OK) return cleanup(_s); } while (0)
+#undef ALLOC
+#define ALLOC(ptr, n) TRY_C(dev_alloc(e, &(ptr), (n)))
+
+  // ---- embeds
+  ALLOC(e->w_in, d * e->Kp); ALLOC(e->b_in, d);
+  if (hipMemset(e->w_in, 0, d * e->Kp * 2) != hipSuccess) return cleanup(fail(MC_EHIP, "hipMemset failed"));
+  ALLOC(e->w_ctx, d * c.txt_dim); ALLOC(e->b_ctx, d);
+  add_slot(e, flux ? "x_embedder.weight" : "img_in.proj.weight", e->w_in, MC_BF16, d * e->Kin);
+  add_slot(e, flux ? "x_embedder.bias" : "img_in.proj.bias", e->b_in, MC_F32, d);
+  linear_slot(e, flux ? "context_embedder" : "txt_in.input_embedder", e->w_ctx, e->b_ctx, d, c.txt_dim);
+  if (flux) {
+    TRY_C(alloc_mlp2(e, e->time_mlp, 256, "time_text_embed.timestep_embedder.linear_1", "time_text_embed.timestep_embedder.linear_2"));
+    TRY_C(alloc_mlp2(e, e->guid_mlp, 256, "time_text_embed.guidance_embedder.linear_1", "time_text_embed.guidance_embedder.linear_2"));
+    TRY_C(alloc_mlp2(e, e->vec_mlp, c.vec_dim, "time_text_embed.text_embedder.linear_1", "time_text_embed.text_embedder.linear_2"));
+  } else {
+    TRY_C(alloc_mlp2(e, e->time_mlp, 256, "time_in.mlp.0", "time_in.mlp.2"));
+    TRY_C(alloc_mlp2(e, e->guid_mlp, 256, "guidance_in.mlp.0", "guidance_in.mlp.2"));
+    TRY_C(alloc_mlp2(e, e->vec_mlp, c.vec_dim, "vector_in.in_layer", "vector_in.out_layer"));
+    TRY_C(alloc_mlp2(e, e->ref_t_mlp, 256, "txt_in.t_embedder.mlp.0", "txt_in.t_embedder.mlp.2"));
+    TRY_C(alloc_mlp2(e, e->ref_c_mlp, c.txt_dim, "txt_in.c_embedder.linear_1", "txt_in.c_embedder.linear_2"));
+    e->refiners.resize(c.refiner_depth);
+    for (int i = 0; i < c.refiner_depth; ++i) {
+      Refiner& r = e->refiners[i];
+      const std::string p = "txt_in.individual_token_refiner.blocks." + std::to_string(i) + ".";
+      ALLOC(r.wqkv, 3 * d * d); ALLOC(r.bqkv, 3 * d); ALLOC(r.wo, d * d); ALLOC(r.bo, d);
+      ALLOC(r.w1, 4 * d * d); ALLOC(r.b1, 4 * d); ALLOC(r.w2, 4 * d * d); ALLOC(r.b2, d);
+      ALLOC(r.wada, 2 * d * d); ALLOC(r.bada, 2 * d);
+      ALLOC(r.n1w, d); ALLOC(r.n1b, d); ALLOC(r.n2w, d); ALLOC(r.n2b, d);
+      linear_slot(e, p + "self_attn_qkv", r.wqkv, r.bqkv, 3 * d, d);
+      linear_slot(e, p + "self_attn_proj", r.wo, r.bo, d, d);
+      linear_slot(e, p + "mlp.fc1", r.w1, r.b1, 4 * d, d);
+      linear_slot(e, p + "mlp.fc2", r.w2, r.b2, d, 4 * d);
+      linear_slot(e, p + "adaLN_modulation.1", r.wada, r.bada, 2 * d, d);
+      add_slot(e, p + "norm1.weight", r.n1w, MC_F32, d); add_slot(e, p + "norm1.bias", r.n1b, MC_F32, d);
+      add_slot(e, p + "norm2.weight", r.n2w, MC_F32, d); add_slot(e, p + "norm2.bias", r.n2b, MC_F32, d);
+    }
+  }
+  // ---- fused modulation matrix: every block's AdaLN linear stacked, one GEMV per forward
+  e->mod_rows = e->mod_final() + 2 * d;
+  ALLOC(e->w_mod, e->mod_rows * d); ALLOC(e->b_mod, e->mod_rows);
+  // ---- blocks
+  e->dimg.resize(c.n_double); e->dtxt.resize(c.n_double);
+  for (int i = 0; i < c.n_double; ++i) {
+    Stream &a = e->dimg[i], &t = e->dtxt[i];
+    TRY_C(alloc_stream(e, a));
+    TRY_C(alloc_stream(e, t));
+    const std::string p = (flux ? "transformer_blocks." : "double_blocks.") + std::to_string(i) + ".";
+    if (flux) {
+      linear_slot(e, p + "norm1.linear", e->w_mod, e->b_mod, 6 * d, d, e->mod_double(i, 0));
+      linear_slot(e, p + "norm1_context.linear", e->w_mod, e->b_mod, 6 * d, d, e->mod_double(i, 1));
+      const char* qkv_i[3] = {"attn.to_q", "attn.to_k", "attn.to_v"};
+      const char* qkv_t[3] = {"attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj"};
+      for (int j = 0; j < 3; ++j) {
+        linear_slot(e, p + qkv_i[j], a.wqkv, a.bqkv, d, d, j * d);
+        linear_slot(e, p + qkv_t[j], t.wqkv, t.bqkv, d, d, j * d);
+      }
+      add_slot(e, p + "attn.norm_q.weight", a.qn, MC_F32, 128); add_slot(e, p + "attn.norm_k.weight", a.kn, MC_F32, 128);
+      add_slot(e, p + "attn.norm_added_q.weight", t.qn, MC_F32, 128);
+      add_slot(e, p + "attn.norm_added_k.weight", t.kn, MC_F32, 128);
+      linear_slot(e, p + "attn.to_out.0", a.wo, a.bo, d, d);
+      linear_slot(e, p + "attn.to_add_out", t.wo, t.bo, d, d);
+      linear_slot(e, p + "ff.net.0.proj", a.w1, a.b1, 4 * d, d);
+      linear_slot(e, p + "ff.net.2", a.w2, a.b2, d, 4 * d);
+      linear_slot(e, p + "ff_context.net.0.proj", t.w1, t.b1, 4 * d, d);
+      linear_slot(e, p + "ff_context.net.2", t.w2, t.b2, d, 4 * d);
+    } else {
+      const char* nm[2] = {"img", "txt"};
+      Stream* st[2] = {&a, &t};
+      for (int k = 0; k < 2; ++k) {
+        const std::string q = p + nm[k];
+        linear_slot(e, q + "_mod.linear", e->w_mod, e->b_mod, 6 * d, d, e->mod_double(i, k));
+        linear_slot(e, q + "_attn_qkv", st[k]->wqkv, st[k]->bqkv, 3 * d, d);
+        add_slot(e, q + "_attn_q_norm.weight", st[k]->qn, MC_F32, 128);
+        add_slot(e, q + "_attn_k_norm.weight", st[k]->kn, MC_F32, 128);
+        linear_slot(e, q + "_attn_proj", st[k]->wo, st[k]->bo, d, d);
+        linear_slot(e, q + "_mlp.fc1", st[k]->w1, st[k]->b1, 4 * d, d);
+        linear_slot(e, q + "_mlp.fc2", st[k]->w2, st[k]->b2, d, 4 * d);
+      }
+    }
+  }
+  e->singles.resize(c.n_single);
+  for (int i = 0; i < c.n_single; ++i) {
+    Single& g = e->singles[i];
+    ALLOC(g.w_in, 7 * d * d); ALLOC(g.b_in, 7 * d); ALLOC(g.w_out, 5 * d * d); ALLOC(g.b_out, d);
+    ALLOC(g.qn, 128); ALLOC(g.kn, 128);
+    const std::string p = (flux ? "single_transformer_blocks." : "single_blocks.") + std::to_string(i) + ".";
+    if (flux) {
+      linear_slot(e, p + "norm.linear", e->w_mod, e->b_mod, 3 * d, d, e->mod_single(i));
+      linear_slot(e, p + "attn.to_q", g.w_in, g.b_in, d, d, 0);
+      linear_slot(e, p + "attn.to_k", g.w_in, g.b_in, d, d, d);
+      linear_slot(e, p + "attn.to_v", g.w_in, g.b_in, d, d, 2 * d);
+      linear_slot(e, p + "proj_mlp", g.w_in, g.b_in, 4 * d, d, 3 * d);
+      linear_slot(e, p + "proj_out", g.w_out, g.b_out, d, 5 * d);
+      add_slot(e, p + "attn.norm_q.weight", g.qn, MC_F32, 128); add_slot(e, p + "attn.norm_k.weight", g.kn, MC_F32, 128);
+    } else {
+      linear_slot(e, p + "modulation.linear", e->w_mod, e->b_mod, 3 * d, d, e->mod_single(i));
+      linear_slot(e, p + "linear1", g.w_in, g.b_in, 7 * d, d);
+      linear_slot(e, p + "linear2", g.w_out, g.b_out, d, 5 * d);
+      add_slot(e, p + "q_norm.weight", g.qn, MC_F32, 128); add_slot(e, p + "k_norm.weight", g.kn, MC_F32, 128);
+    }
+  }
+  // ---- final layer
+  linear_slot(e, flux ? "norm_out.linear" : "final_layer.adaLN_modulation.1", e->w_mod, e->b_mod, 2 * d, d, e->mod_final());
+  ALLOC(e->w_head, (size_t)e->out_feat * d); ALLOC(e->b_head, e->out_feat);
+  add_slot(e, flux ? "proj_out.weight" : "final_layer.linear.weight", e->w_head, MC_F32, (size_t)e->out_feat * d);
+  add_slot(e, flux ? "proj_out.bias" : "final_layer.linear.bias", e->b_head, MC_F32, e->out_feat);
+  if (hy) {  // upstream token vector is (c, pt, ph, pw) channel-major; launch_unpatchify wants (ph, pw, c)
+    e->slots["final_layer.linear.weight"].perm_c = c.out_channels;
+    e->slots["final_layer.linear.bias"].perm_c = c.out_channels;
+  }
+  // ---- RoPE table, identity rotation until mc_mmdit_set_rope
+  {
+    ALLOC(e->cs, (size_t)e->Sp * 128);
+    std::vector<float> ident((size_t)e->Sp * 128);
+    for (size_t i = 0; i < ident.size(); i += 2) { ident[i] = 1.f; ident[i + 1] = 0.f; }
+    if (hipMemcpy(e->cs, ident.data(), ident.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return cleanup(fail(MC_EHIP, "RoPE table upload failed"));
+  }
+  // ---- workspace plan
+  size_t cur = 0;
+  const size_t Sp = e->Sp, Li = e->Li;
+  const size_t Ltp = align_up(e->Lt, 256);
+  add_buf(e, cur, "x", Sp * d * 4);
+  add_buf(e, cur, "x0", Li * d * 2);
+  add_buf(e, cur, "xn", Sp * d * 2);
+  add_buf(e, cur, "qkv", Sp * 3 * d * 2);
+  add_buf(e, cur, "am", Sp * 5 * d * 2);               // also the fp32 [img, d] head operand after the last block
+  add_buf(e, cur, "tokens", align_up(Li, 256) * e->Kp * 2);
+  add_buf(e, cur, "txt_in", Ltp * c.txt_dim * 2);
+  add_buf(e, cur, "txt_e", Ltp * d * 2);
+  add_buf(e, cur, "emod", e->mod_rows * 4);
+  add_buf(e, cur, "vecs", 16 * d * 4 + (size_t)c.txt_dim * 4 + 1024);   // sinusoids, hidden vectors, vec, c, gates
+  add_buf(e, cur, "head_tokens", Li * 64 * 4);
+  add_buf(e, cur, "residual0", Li * d * 4);
+  if (c.calibration) add_buf(e, cur, "residual1", Li * d * 4);
+  add_buf(e, cur, "calib_partial", 1024 * 4 * 8);
+  add_buf(e, cur, "calib_sums", 64);
+  add_buf(e, cur, "calib_stats", 64);
+  e->ws_need = cur;
+  *out = e;
+  return MC_OK;
+#undef TRY_C
+}
+
+void mc_mmdit_destroy(mc_mmdit* e) {
+  if (!e) return;
+  for (void* p : e->owned) (void)hipFree(p);
+  delete e;
+}
+
+size_t mc_mmdit_workspace_bytes(const mc_mmdit* e) { return e ? e->ws_need : 0; }
+
+mc_status mc_mmdit_set_workspace(mc_mmdit* e, void* ws_dev, size_t bytes) {
+  if (!e || !ws_dev) return fail(MC_EINVAL, "null argument");
+  if (bytes < e->ws_need) return fail(MC_EINVAL, "workspace too small: %zu < %zu", bytes, e->ws_need);
+  if (((uintptr_t)ws_dev) & 255) return fail(MC_EINVAL, "workspace must be 256-byte aligned");
+  e->ws = (char*)ws_dev;
+  e->have_res = e->have_stats = e->pads_clean = false;
+  return MC_OK;
+}
+
+mc_status mc_mmdit_buffer_info(const mc_mmdit* e, const char* name, size_t* offset, size_t* bytes) {
+  if (!e || !name) return fail(MC_EINVAL, "null argument");
+  std::string n(name);
+  if (n == "residual") n = e->res_cur ? "residual1" : "residual0";
+  auto it = e->bufs.find(n);
+  if (it == e->bufs.end()) return fail(MC_EINVAL, "unknown buffer '%s'", name);
+  if (offset) *offset = it->second.off;
+  if (bytes) *bytes = it->second.bytes;
+  return MC_OK;
+}
+
+mc_status mc_mmdit_set_weight(mc_mmdit* e, const char* name, const void* src_dev, mc_dtype dtype, const int64_t* shape,
+                              int ndim, mc_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!e || !name || !src_dev || !shape) return fail(MC_EINVAL, "null argument");
+  auto it = e->slots.find(name);
+  if (it == e->slots.end()) return fail(MC_EINVAL, "unknown weight '%s'", name);
+  Slot& s = it->second;
+  size_t numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+  if (numel != s.numel) return fail(MC_EINVAL, "weight '%s': %zu elements given, %zu expected", name, numel, s.numel);
+  if (s.dst_dtype == MC_F32) {
+    if (dtype != MC_F32) return fail(MC_EINVAL, "weight '%s' must be given as fp32", name);
+    float* dst = (float*)s.dst + s.off;
+    if (s.perm_c > 0) {  // rows (c, pq) -> (pq, c)
+      const size_t C = s.perm_c, row = numel / (4 * C);
+      for (size_t c = 0; c < C; ++c)
+        for (size_t pq = 0; pq < 4; ++pq)
+          HIP_TRY(hipMemcpyAsync(dst + (pq * C + c) * row, (const float*)src_dev + (c * 4 + pq) * row, row * 4,
+                                 hipMemcpyDeviceToDevice, stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(dst, src_dev, numel * 4, hipMemcpyDeviceToDevice, stream));
+    }
+  } else {
+    bf16_t* dst = (bf16_t*)s.dst + s.off;
+    const bool is_in = (s.dst == e->w_in);
+    if (is_in && e->Kin != e->Kp) {
+      if (dtype == MC_F32) {
+        HIP_TRY(mc::launch_cast_pad_bf16((const float*)src_dev, e->Kin, e->d, e->d, e->Kin, dst, e->Kp, stream));
+      } else {
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)e->Kp * 2, src_dev, (size_t)e->Kin * 2, (size_t)e->Kin * 2, e->d,
+                                 hipMemcpyDeviceToDevice, stream));
+      }
+    } else if (dtype == MC_F32) {
+      HIP_TRY(mc::launch_cast_bf16((const float*)src_dev, dst, numel, stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(dst, src_dev, numel * 2, hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  s.loaded = true;
+  return MC_OK;
+}
+
+int mc_mmdit_weights_missing(const mc_mmdit* e, char* buf, size_t buflen) {
+  if (!e) return -1;
+  int n = 0;
+  size_t pos = 0;
+  if (buf && buflen) buf[0] = 0;
+  for (auto& kv : e->slots) {
+    if (kv.second.loaded) continue;
+    ++n;
+    if (buf && pos + kv.first.size() + 2 < buflen) {
+      memcpy(buf + pos, kv.first.c_str(), kv.first.size());
+      pos += kv.first.size();
+      buf[pos++] = '\n';
+      buf[pos] = 0;
+    }
+  }
+  return n;
+}
+
+mc_status mc_mmdit_set_rope(mc_mmdit* e, const float* cos_dev, const float* sin_dev, int n_rows, mc_stream stream) {
+  if (!e || !cos_dev || !sin_dev) return fail(MC_EINVAL, "null argument");
+  const bool hy = e->cfg.family == MC_FAMILY_HUNYUAN;
+  const int want = hy ? e->Li : e->S;
+  if (n_rows != want) return fail(MC_EINVAL, "RoPE table has %d rows, %d expected", n_rows, want);
+  HIP_TRY(mc::launch_rope_table_from_cos_sin(cos_dev, sin_dev, 128, n_rows, e->cs, (hipStream_t)stream));
+  return MC_OK;
+}
+
+mc_status mc_mmdit_state_reset(mc_mmdit* e) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  e->have_res = e->have_stats = false;
+  return MC_OK;
+}
+
+mc_status mc_mmdit_calib_stats(mc_mmdit* e, float out[3], mc_stream stream) {
+  if (!e || !out) return fail(MC_EINVAL, "null argument");
+  if (!e->have_stats) return fail(MC_ESTATE, "no calibration statistics: needs two MC_MODE_CALIB forwards");
+  HIP_TRY(hipMemcpyAsync(out, e->buf<float>("calib_stats"), 12, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return MC_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// y = W2 silu(W1 x + b1) + b2   (TimestepEmbedding / MLPEmbedder / TextProjection); h: scratch [d]
+mc_status run_mlp2(const mc_mmdit* e, const Mlp2& m, const float* x, float* h, float* y, int accumulate, hipStream_t s) {
+  HIP_TRY(mc::launch_gemv_bf16w(m.w1, x, m.b1, h, e->d, m.k_in, 0, 0, 0, s));
+  HIP_TRY(mc::launch_gemv_bf16w(m.w2, h, m.b2, y, e->d, e->d, 1, 0, accumulate, s));
+  return MC_OK;
+}
+
+mc_status joint_attention(const mc_mmdit* e, int q_rows_pad, int n_valid, hipStream_t s) {
+  const int d = e->d;
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  mc::AttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.Q = qkv; a.ldq = 3 * d;
+  a.K = qkv + d; a.ldk = 3 * d;
+  a.V = qkv + 2 * d; a.ldv = 3 * d;
+  a.O = e->buf<bf16_t>("am"); a.ldo = 5 * d;
+  a.Lq_pad = q_rows_pad; a.n_heads = e->H; a.scale = 1.0f / std::sqrt(128.0f);
+  a.shard_rows = q_rows_pad; a.shard_valid = n_valid; a.n_shards = 1;
+  HIP_TRY(mc::launch_attention(a, s));
+  return MC_OK;
+}
+
+// HunyuanVideo txt_in = SingleTokenRefiner(text_states, t, mask)  (reference :75; upstream token_refiner.py):
+// result in the text rows of x.  Works on rows [0, Ltp) of xn / qkv / am, which the main blocks overwrite later.
+mc_status run_refiner(mc_mmdit* e, const float* txt_dev, int txt_valid, float* vecs, hipStream_t s) {
+  const mc_mmdit_config& c = e->cfg;
+  const int d = e->d, Lt = e->Lt;
+  const int Ltp = (int)align_up(Lt, 256);
+  float* sin_t = vecs;              // [256] sinusoid of t (written by the caller)
+  float* hid = vecs + 2 * d;        // hidden scratch [d]
+  float* cvec = vecs + 4 * d;       // c = t_embedder(t) + c_embedder(mean of the valid text states)
+  float* gates = vecs + 5 * d;      // [2d]
+  float* cmean = vecs + 16 * d;     // [txt_dim]
+  MC_TRY(run_mlp2(e, e->ref_t_mlp, sin_t, hid, cvec, 0, s));
+  HIP_TRY(mc::launch_colmean(txt_dev, c.txt_dim, txt_valid, c.txt_dim, cmean, s));
+  MC_TRY(run_mlp2(e, e->ref_c_mlp, cmean, hid, cvec, 1, s));
+  float* xt = e->buf<float>("x") + (size_t)e->txt0 * d;
+  bf16_t* xn = e->buf<bf16_t>("xn");
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  bf16_t* am = e->buf<bf16_t>("am");
+  for (const Refiner& r : e->refiners) {
+    HIP_TRY(mc::launch_gemv_bf16w(r.wada, cvec, r.bada, gates, 2 * d, d, 1, 0, 0, s));
+    HIP_TRY(mc::launch_ln_modulate(xt, d, nullptr, 0, r.n1w, r.n1b, 1, 1e-6f, xn, d, nullptr, 0, Lt, d, s));
+    mc::GemmParams p = gp(xn, d, r.wqkv, d, r.bqkv, Lt, 3 * d, d);
+    p.Cb = qkv; p.ldc = 3 * d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    MC_TRY(joint_attention(e, Ltp, txt_valid, s));
+    mc::GemmParams o = gp(am, 5 * d, r.wo, d, r.bo, Lt, d, d);
+    o.X = xt; o.ldx = d; o.gate = gates;
+    HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+    HIP_TRY(mc::launch_ln_modulate(xt, d, nullptr, 0, r.n2w, r.n2b, 1, 1e-6f, xn, d, nullptr, 0, Lt, d, s));
+    mc::GemmParams f1 = gp(xn, d, r.w1, d, r.b1, Lt, 4 * d, d);
+    f1.Cb = am + d; f1.ldc = 5 * d;
+    HIP_TRY(mc::launch_gemm_bf16(f1, mc::EPI_SILU_BF16, s));
+    mc::GemmParams f2 = gp(am + d, 5 * d, r.w2, 4 * d, r.b2, Lt, d, 4 * d);
+    f2.X = xt; f2.ldx = d; f2.gate = gates + d;
+    HIP_TRY(mc::launch_gemm_bf16(f2, mc::EPI_RESID_GATE, s));
+  }
+  return MC_OK;
+}
+
+// one stream of a double block, before the joint attention: LN + modulate, QKV, per-head q/k norm, RoPE
+mc_status stream_pre_attn(const mc_mmdit* e, const Stream& w, const float* mod, int row0, int rows, hipStream_t s) {
+  const int d = e->d;
+  float* x = e->buf<float>("x") + (size_t)row0 * d;
+  bf16_t* xn = e->buf<bf16_t>("xn") + (size_t)row0 * d;
+  bf16_t* qkv = e->buf<bf16_t>("qkv") + (size_t)row0 * 3 * d;
+  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, mod + d, mod, 0, 1e-6f, xn, d, nullptr, 0, rows, d, s));
+  mc::GemmParams p = gp(xn, d, w.wqkv, d, w.bqkv, rows, 3 * d, d);
+  p.Cb = qkv; p.ldc = 3 * d;
+  HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+  HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, w.qn, w.kn, 1e-6f, e->cs, row0, rows, e->H, s));
+  return MC_OK;
+}
+
+// ... and after it: output projection (+gated residual), LN + modulate, MLP (+gated residual)
+mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod, int row0, int rows, hipStream_t s) {
+  const int d = e->d;
+  float* x = e->buf<float>("x") + (size_t)row0 * d;
+  bf16_t* xn = e->buf<bf16_t>("xn") + (size_t)row0 * d;
+  bf16_t* am = e->buf<bf16_t>("am") + (size_t)row0 * 5 * d;
+  mc::GemmParams o = gp(am, 5 * d, w.wo, d, w.bo, rows, d, d);
+  o.X = x; o.ldx = d; o.gate = mod + 2 * d;
+  HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, mod + 4 * d, mod + 3 * d, 0, 1e-6f, xn, d, nullptr, 0, rows, d, s));
+  mc::GemmParams f1 = gp(xn, d, w.w1, d, w.b1, rows, 4 * d, d);
+  f1.Cb = am + d; f1.ldc = 5 * d;
+  HIP_TRY(mc::launch_gemm_bf16(f1, mc::EPI_GELU_BF16, s));
+  mc::GemmParams f2 = gp(am + d, 5 * d, w.w2, 4 * d, w.b2, rows, d, 4 * d);
+  f2.X = x; f2.ldx = d; f2.gate = mod + 5 * d;
+  HIP_TRY(mc::launch_gemm_bf16(f2, mc::EPI_RESID_GATE, s));
+  return MC_OK;
+}
+
+}  // namespace
+
+extern "C" mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double timestep, double guidance,
+                                      const float* txt_dev, int txt_valid, const float* vec_dev, mc_mode mode,
+                                      float* out_dev, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (!e->ws) return fail(MC_ESTATE, "workspace not set (mc_mmdit_set_workspace)");
+  for (auto& kv : e->slots)
+    if (!kv.second.loaded) return fail(MC_ESTATE, "weight '%s' was never set", kv.first.c_str());
+  if (!img_dev || !txt_dev || !vec_dev || !out_dev) return fail(MC_EINVAL, "null input / output");
+  const mc_mmdit_config& c = e->cfg;
+  const bool hy = c.family == MC_FAMILY_HUNYUAN;
+  if (hy && (txt_valid <= 0 || txt_valid > e->Lt)) return fail(MC_EINVAL, "txt_valid %d out of (0, %d]", txt_valid, e->Lt);
+  if (mode == MC_MODE_SKIP && !e->have_res)
+    return fail(MC_ESTATE, "skip requested but the residual cache is empty");
+  if (mode == MC_MODE_CALIB && !c.calibration) return fail(MC_ESTATE, "engine was created without calibration");
+  const int d = e->d, Li = e->Li, Lt = e->Lt, S = e->S, Sp = e->Sp;
+  float* x = e->buf<float>("x");
+  bf16_t* x0 = e->buf<bf16_t>("x0");
+  bf16_t* xn = e->buf<bf16_t>("xn");
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  bf16_t* am = e->buf<bf16_t>("am");
+  float* vecs = e->buf<float>("vecs");
+  float* emod = e->buf<float>("emod");
+  float *sin_t = vecs, *sin_g = vecs + d, *hid = vecs + 2 * d, *vec = vecs + 3 * d;
+  if (!e->pads_clean) {
+    // rows [S, S_pad) are read by the attention kernel (masked keys, ignored queries) and never written by a GEMM
+    HIP_TRY(hipMemsetAsync(qkv + (size_t)S * 3 * d, 0, (size_t)(Sp - S) * 3 * d * 2, s));
+    HIP_TRY(hipMemsetAsync(x + (size_t)S * d, 0, (size_t)(Sp - S) * d * 4, s));
+    if (hy) HIP_TRY(hipMemsetAsync(qkv, 0, (size_t)Sp * 3 * d * 2, s));   // refiner: rows [Lt, Ltp) of its own pass
+    e->pads_clean = true;
+  }
+
+  // ---- conditioning vector: time + guidance + pooled text   (flux :303-313, hunyuan :53-67)
+  HIP_TRY(mc::launch_sinusoid(nullptr, timestep, 256, sin_t, s));
+  HIP_TRY(mc::launch_sinusoid(nullptr, guidance, 256, sin_g, s));
+  MC_TRY(run_mlp2(e, e->time_mlp, sin_t, hid, vec, 0, s));
+  MC_TRY(run_mlp2(e, e->guid_mlp, sin_g, hid, vec, 1, s));
+  MC_TRY(run_mlp2(e, e->vec_mlp, vec_dev, hid, vec, 1, s));
+  // modulation of every block = Linear(silu(vec)); a skipped step needs the final layer's only
+  if (mode == MC_MODE_SKIP) {
+    const size_t r0 = e->mod_final();
+    HIP_TRY(mc::launch_gemv_bf16w(e->w_mod + r0 * d, vec, e->b_mod + r0, emod + r0, 2 * d, d, 1, 0, 0, s));
+  } else {
+    HIP_TRY(mc::launch_gemv_bf16w(e->w_mod, vec, e->b_mod, emod, (int)e->mod_rows, d, 1, 0, 0, s));
+  }
+
+  // ---- image embedding: x_img = x_embedder(tokens) / img_in(latent); ori copy for MagCache
+  {
+    bf16_t* tokens = e->buf<bf16_t>("tokens");
+    if (hy) {
+      if (e->Kp != e->Kin) HIP_TRY(hipMemsetAsync(tokens, 0, (size_t)align_up(Li, 256) * e->Kp * 2, s));
+      HIP_TRY(mc::launch_patchify(img_dev, c.in_channels, c.latent_f, c.latent_h, c.latent_w, 0, Li, Li, tokens,
+                                  e->Kp, s));
+    } else {
+      HIP_TRY(mc::launch_cast_pad_bf16(img_dev, e->Kin, Li, Li, e->Kin, tokens, e->Kp, s));
+    }
+    mc::GemmParams p = gp(tokens, e->Kp, e->w_in, e->Kp, e->b_in, Li, d, e->Kp);
+    p.X = x + (size_t)e->img0 * d; p.ldx = d; p.X0out = x0; p.ldx0out = d; p.m_valid = Li;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
+  }
+
+  if (mode != MC_MODE_SKIP) {
+    // ---- text embedding -> text rows of x   (flux :314; hunyuan :72-78 incl. the token refiner)
+    {
+      bf16_t* tin = e->buf<bf16_t>("txt_in");
+      HIP_TRY(mc::launch_cast_pad_bf16(txt_dev, c.txt_dim, Lt, Lt, c.txt_dim, tin, c.txt_dim, s));
+      mc::GemmParams p = gp(tin, c.txt_dim, e->w_ctx, c.txt_dim, e->b_ctx, Lt, d, c.txt_dim);
+      p.X = x + (size_t)e->txt0 * d; p.ldx = d; p.X0out = e->buf<bf16_t>("txt_e"); p.ldx0out = d; p.m_valid = Lt;
+      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
+      if (hy) MC_TRY(run_refiner(e, txt_dev, txt_valid, vecs, s));
+    }
+    const int n_valid = hy ? Li + txt_valid : S;
+    // ---- double-stream blocks
+    for (int i = 0; i < c.n_double; ++i) {
+      const float* mi = emod + e->mod_double(i, 0);
+      const float* mt = emod + e->mod_double(i, 1);
+      MC_TRY(stream_pre_attn(e, e->dimg[i], mi, e->img0, Li, s));
+      MC_TRY(stream_pre_attn(e, e->dtxt[i], mt, e->txt0, Lt, s));
+      MC_TRY(joint_attention(e, Sp, n_valid, s));
+      MC_TRY(stream_post_attn(e, e->dimg[i], mi, e->img0, Li, s));
+      MC_TRY(stream_post_attn(e, e->dtxt[i], mt, e->txt0, Lt, s));
+    }
+    // ---- single-stream blocks on the joint sequence
+    for (int i = 0; i < c.n_single; ++i) {
+      const Single& g = e->singles[i];
+      const float* m = emod + e->mod_single(i);
+      HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, m + d, m, 0, 1e-6f, xn, d, nullptr, 0, S, d, s));
+      mc::GemmParams p = gp(xn, d, g.w_in, d, g.b_in, S, 3 * d, d);
+      p.Cb = qkv; p.ldc = 3 * d;
+      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+      mc::GemmParams q = gp(xn, d, g.w_in + (size_t)3 * d * d, d, g.b_in + 3 * d, S, 4 * d, d);
+      q.Cb = am + d; q.ldc = 5 * d;
+      HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_GELU_BF16, s));
+      HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, g.qn, g.kn, 1e-6f, e->cs, 0, S, e->H, s));
+      MC_TRY(joint_attention(e, Sp, n_valid, s));
+      mc::GemmParams o = gp(am, 5 * d, g.w_out, 5 * d, g.b_out, S, d, 5 * d);
+      o.X = x; o.ldx = d; o.gate = m + 2 * d;
+      HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+    }
+    // ---- MagCache residual capture: cur_residual = hidden_states - ori_hidden_states   (flux :428, hunyuan :140)
+    const int dst = (mode == MC_MODE_CALIB && e->have_res) ? 1 - e->res_cur : e->res_cur;
+    HIP_TRY(mc::launch_residual_sub(x + (size_t)e->img0 * d, d, x0, d, e->residual(dst), d, Li, d, s));
+    if (mode == MC_MODE_CALIB && e->have_res) {
+      HIP_TRY(mc::launch_calib_stats(e->residual(dst), d, e->residual(e->res_cur), d, Li, d,
+                                     e->buf<double>("calib_partial"), 1024, e->buf<double>("calib_sums"),
+                                     e->buf<float>("calib_stats"), s));
+      e->have_stats = true;
+    }
+    e->res_cur = dst;
+    e->have_res = true;
+  }
+
+  // ---- final layer on the image tokens: AdaLN (no affine) + Linear   (flux :431-432, hunyuan :144)
+  {
+    const float* mf = emod + e->mod_final();
+    const float* scale = hy ? mf + d : mf;   // hunyuan: (shift, scale); flux AdaLayerNormContinuous: (scale, shift)
+    const float* shift = hy ? mf : mf + d;
+    float* hn = reinterpret_cast<float*>(am);
+    if (mode == MC_MODE_SKIP) {
+      // hidden_states = ori + cur_residual (flux :348, hunyuan :102) folded into the LayerNorm load
+      HIP_TRY(mc::launch_ln_modulate(e->residual(e->res_cur), d, x0, d, scale, shift, 0, 1e-6f, nullptr, 0, hn, d, Li, d, s));
+    } else {
+      HIP_TRY(mc::launch_ln_modulate(x + (size_t)e->img0 * d, d, nullptr, 0, scale, shift, 0, 1e-6f, nullptr, 0, hn, d,
+                                     Li, d, s));
+    }
+    if (hy) {
+      float* ht = e->buf<float>("head_tokens");
+      HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, ht, 64, Li, e->out_feat, d, s));
+      HIP_TRY(mc::launch_unpatchify(ht, 64, c.out_channels, c.latent_f, c.latent_h, c.latent_w, 0, Li, out_dev, s));
+    } else {
+      HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, out_dev, e->out_feat, Li, e->out_feat, d, s));
+    }
+  }
+  return MC_OK;
+}

@@ -18,6 +18,7 @@ enum GemmEpi {
   EPI_EMBED = 4,         // X = bf16(acc + bias) (as fp32), X0out = same (bf16)
   EPI_F32 = 5,           // X = acc + bias (fp32 store)
   EPI_GELU_ERF_BF16 = 6, // Cb = bf16(gelu_erf(bf16(acc + bias)))   (128x128 kernel only)
+  EPI_SILU_BF16 = 7,     // Cb = bf16(silu(bf16(acc + bias)))       (128x128 kernel only; HunyuanVideo token refiner)
 };
 
 struct GemmParams {
@@ -79,6 +80,21 @@ hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long l
 //   y = bf16(x * rsqrt(mean(x^2)+eps)) * w ; rope pairs (2i,2i+1) with cs[token][64] (cos,sin)
 hipError_t launch_rmsnorm_rope(bf16_t* x, long ldx, const float* w, float eps, const float* cs, int cs_row0,
                                int M, int D, hipStream_t stream);
+
+// MM-DiT (FLUX / HunyuanVideo) q and k of one [M, >= 2*n_heads*128] bf16 block, in place:
+//   per head RMSNorm over the 128 channels (y = bf16(x * rsqrt(mean(x^2)+eps)) * w[128]), then RoPE on the pairs
+//   (2i,2i+1) with cs[cs_row0 + row][64] (cos,sin).  q = columns [0, H*128) with wq, k = [k_col0, k_col0+H*128)
+//   with wk.  wq/wk null: no norm; cs null: no RoPE.
+hipError_t launch_headnorm_rope(bf16_t* x, long ldx, long k_col0, const float* wq, const float* wk, float eps,
+                                const float* cs, int cs_row0, int M, int n_heads, hipStream_t stream);
+// y[n] = (accumulate ? y[n] : 0) + act_out( dot(W[n,:] (bf16), act_in(x) (fp32)) + b[n] ), act: 0 none, 1 silu
+hipError_t launch_gemv_bf16w(const bf16_t* W, const float* x, const float* b, float* y, int N, int K, int act_in,
+                             int act_out, int accumulate, hipStream_t stream);
+// out[c] = mean over rows [0, n_rows) of x[r, c]  (HunyuanVideo token refiner: masked mean of the text states)
+hipError_t launch_colmean(const float* x, long ldx, int n_rows, int D, float* out, hipStream_t stream);
+// rows [0, n_rows) of a bf16 [., D] block <- fp32 (optionally (cos,sin)-interleaving two [n, 128] tables, see mmdit)
+hipError_t launch_rope_table_from_cos_sin(const float* cosv, const float* sinv, long ld, int n_rows, float* cs,
+                                          hipStream_t stream);
 
 // latent fp32 [C,F,H,W] -> im2col bf16 tokens [L_pad, C*pt*ph*pw] for patch (1,2,2)
 hipError_t launch_patchify(const float* lat, int C, int F, int H, int W, int tok0, int n_tok, int n_rows,

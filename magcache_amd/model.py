@@ -101,10 +101,10 @@ class WanModelHIP:
             lat = torch.cat([lat, y[0].to(self.device)], dim=0)
         if clip_fea is not None:
             # img_emb(clip_fea) is constant over a video: run it when the tensor changes, not every call
-            key = (clip_fea.data_ptr(), clip_fea._version, tuple(clip_fea.shape))
-            if key != self._clip_key:
+            k = self._clip_key
+            if k is None or k.shape != clip_fea.shape or k.dtype != clip_fea.dtype or not torch.equal(k, clip_fea.to(k.device)):
                 self.engine.set_clip_fea(clip_fea)
-                self._clip_key = key
+                self._clip_key = clip_fea.detach().to(self.device).clone()
         t = t if not torch.is_tensor(t) else t.to(self.device)
         ctx = context[0].to(self.device)
         if self.engine.sp_size > 1:

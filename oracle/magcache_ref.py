@@ -164,6 +164,59 @@ class MagCacheWan:
         return [u.float() for u in x]
 
 
+class MagCacheMMDiT:
+    """magcache_forward / magcache_calibration around an oracle FLUX or HunyuanVideo model: scalar state, one residual
+    slot (MagCache4FLUX/magcache_flux.py:326-438; MagCache4HunyuanVideo/magcache_sample_video.py:88-153)."""
+
+    def __init__(self, model, variant, num_steps, thresh, K, retention_ratio, mag_ratios):
+        assert variant in ("flux", "hunyuan")
+        self.model, self.variant = model, variant
+        self.rule = RuleState(variant, num_steps, thresh, K, retention_ratio, mag_ratios)
+        self.residual = None
+        self.norm_ratio, self.norm_std, self.cos_dis = [], [], []
+        self.trace = []
+
+    def _parts(self, kw):
+        m = self.model
+        if self.variant == "flux":
+            h, e, temb, rope = m.pre_blocks(kw["hidden_states"], kw["encoder_hidden_states"], kw["pooled_projections"],
+                                            kw["timestep"], kw["img_ids"], kw["txt_ids"], kw["guidance"])
+            return h, (lambda: m.run_blocks(h, e, temb, rope)), (lambda x: m.post_blocks(x, temb))
+        x = kw["x"]
+        thw = (x.shape[2], x.shape[3] // 2, x.shape[4] // 2)
+        img, txt, vec = m.pre_blocks(x, kw["t"], kw["text_states"], kw["text_mask"], kw["text_states_2"], kw["guidance"])
+        return (img, (lambda: m.run_blocks(img, txt, vec, kw["text_mask"], kw["freqs_cos"], kw["freqs_sin"])),
+                (lambda y: m.post_blocks(y, vec, thw)))
+
+    def forward(self, **kw):
+        with torch.no_grad():
+            ori, blocks, post = self._parts(kw)
+            cnt = self.rule.cnt
+            skip, _ = self.rule.step()
+            if skip:
+                out = ori + self.residual
+            else:
+                out = blocks()
+                self.residual = out - ori
+            self.trace.append((cnt, skip))
+            return post(out)
+
+    def calibrate(self, **kw):
+        with torch.no_grad():
+            ori, blocks, post = self._parts(kw)
+            cnt = self.rule.cnt
+            out = blocks()
+            residual = out - ori
+            if cnt >= 1:
+                a, b, c = calibration_stats(residual, self.residual)
+                self.norm_ratio.append(round(a, 5))
+                self.norm_std.append(round(b, 5))
+                self.cos_dis.append(round(c, 5))
+            self.residual = residual
+            self.rule.cnt = cnt + 1
+            return post(out)
+
+
 def flow_timesteps(num_steps, shift=5.0, num_train_timesteps=1000):
     """Shifted flow-matching schedule, MagCache4Wan2.2/magcache_generate.py:72-93 (sigma_min 0.01 ...
     sigma_max 1.0, sigma' = s*sigma/(1+(s-1)*sigma)); returns (sigmas[n+1], timesteps[n])."""

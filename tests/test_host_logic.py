@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
-    hdr = open(os.path.join(ROOT, "include", "magcache_hip.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("magcache_hip.h", "magcache_mmdit.h"))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 30

@@ -1,0 +1,240 @@
+"""GPU parity of the MM-DiT engine (FLUX.1 / HunyuanVideo) through the C ABI (include/magcache_mmdit.h):
+one forward vs the oracle restatements, the MagCache loop through the monkey-patch shims vs the golden produced by the
+reference's own magcache_forward, calibration statistics, error behaviour."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from magcache_amd import _lib  # noqa: E402
+from magcache_amd import mmdit as MM  # noqa: E402
+from oracle import flux_ref as FR  # noqa: E402
+from oracle import hunyuan_ref as HR  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def record_modes(cls):
+    """log the engine mode (full / skip / calib) of every forward a shim class issues"""
+    modes, base = [], cls.__mro__[1]._run
+
+    def _run(self, *a):
+        modes.append(a[-1])
+        return base(self, *a)
+    cls._run = _run
+    return modes
+
+
+# ----------------------------------------------------------------------------- FLUX
+@pytest.fixture(scope="module")
+def flux(golden_dir):
+    g = np.load(os.path.join(golden_dir, "flux_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = dict(meta["cfg"], axes_dims_rope=tuple(meta["cfg"]["axes_dims_rope"]))
+    oracle = FR.init_synthetic_(FR.FluxTransformer2DModel(**cfg), seed=meta["weight_seed"], std=meta["weight_std"])
+    cls = type("FluxHIPUnderTest", (MM.FluxTransformer2DModelHIP,), {})
+    m = cls(cfg, meta["h2"] * meta["w2"], txt_len=meta["txt_len"], device=DEV, calibration=True)
+    m.load_state_dict(oracle.state_dict())
+    kw = dict(encoder_hidden_states=torch.from_numpy(g["ctx"]), pooled_projections=torch.from_numpy(g["pooled"]),
+              img_ids=torch.from_numpy(g["img_ids"]), txt_ids=torch.from_numpy(g["txt_ids"]),
+              guidance=torch.tensor([meta["guidance"]]))
+    return g, meta, cfg, oracle, m, kw
+
+
+def test_flux_forward_vs_oracle(flux):
+    """Tolerance: the engine keeps the residual streams in fp32 and rounds GEMM operands to bf16, the reference runs
+    everything in bf16; it must be at least as close to the fp32 oracle as the reference's own bf16 mode is (factor 2
+    + 1e-3), and within 2e-2 relative L2 of the fp32 oracle."""
+    g, meta, cfg, oracle, m, kw = flux
+    x = torch.from_numpy(g["latent0"])
+    t = torch.tensor([0.5])                     # 0.5 * 1000 and the guidance are exact in bf16: same effective inputs
+    kw = dict(kw, guidance=torch.tensor([4.0]))
+    with torch.no_grad():
+        ref32 = oracle(hidden_states=x, timestep=t, **kw)[0]
+        ob = FR.init_synthetic_(FR.FluxTransformer2DModel(**cfg), seed=meta["weight_seed"], std=meta["weight_std"]).bfloat16()
+        refbf = ob(hidden_states=x.bfloat16(), timestep=t.bfloat16(),
+                   **{k: (v.bfloat16() if v.is_floating_point() and "ids" not in k else v) for k, v in kw.items()})[0].float()
+    got = m(hidden_states=dev(x), timestep=dev(t), return_dict=False, **{k: dev(v) for k, v in kw.items()})[0]
+    assert got.dtype == torch.float32 and tuple(got.shape) == tuple(ref32.shape)
+    e_hip, e_bf = rel_l2(got, ref32), rel_l2(refbf, ref32)
+    assert e_hip < 2 * e_bf + 1e-3, (e_hip, e_bf)
+    assert e_hip < 2e-2, e_hip
+    # RoPE matters: permuting the image ids changes the output
+    ids2 = kw["img_ids"].flip(0).contiguous()
+    other = m(hidden_states=dev(x), timestep=dev(t), return_dict=False, **{k: dev(v) for k, v in dict(kw, img_ids=ids2).items()})[0]
+    assert rel_l2(other, got) > 1e-2
+
+
+def test_flux_magcache_loop_vs_reference_golden(flux):
+    """flux_magcache_forward on the engine vs the reference's own magcache_forward (tests/golden): identical skip
+    schedule (host arithmetic), per-call outputs within the precision-mode tolerance, cnt wraps."""
+    g, meta, cfg, oracle, m, kw = flux
+    steps = meta["steps"]
+    MM.init_flux_magcache(m, steps, meta["thresh"], meta["K"], meta["R"])
+    cls = type(m)
+    x = dev(torch.from_numpy(g["latent0"]).clone())
+    sig = g["sigmas"]
+    kwd = {k: dev(v) for k, v in kw.items()}
+    modes, errs = record_modes(cls), []
+    for i in range(steps):
+        o = m(hidden_states=x, timestep=torch.tensor([float(sig[i])], device=DEV), return_dict=False, **kwd)[0]
+        errs.append(rel_l2(o[0], g["outs"][i]))
+        x = x + float(sig[i + 1] - sig[i]) * o
+    assert cls.cnt == 0 and cls.accumulated_steps == 0
+    assert [int(mo == MM.MC_MODE_SKIP) for mo in modes] == g["skipped"].tolist()
+    assert max(errs) < 3e-2, errs
+    # like the reference, the forward assigns through `self`: the instance attribute shadows the class default
+    assert tuple(m.previous_residual.shape) == (meta["h2"] * meta["w2"], m.inner_dim)
+    del m.previous_residual
+    cls.forward = MM.flux_plain_forward
+
+
+def test_flux_calibration_vs_reference_golden(flux):
+    g, meta, cfg, oracle, m, kw = flux
+    steps, want = meta["steps"], meta["calib"]
+    MM.init_flux_magcache(m, steps, calibration=True)
+    cls = type(m)
+    x = dev(torch.from_numpy(g["latent0"]).clone())
+    sig = g["sigmas"]
+    kwd = {k: dev(v) for k, v in kw.items()}
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i in range(steps - 1):
+            o = m(hidden_states=x, timestep=torch.tensor([float(sig[i])], device=DEV), return_dict=False, **kwd)[0]
+            x = x + float(sig[i + 1] - sig[i]) * o
+    assert len(cls.norm_ratio) == steps - 2
+    # tolerance: statistics of bf16-operand residuals against the fp32 reference run
+    np.testing.assert_allclose(cls.norm_ratio, want["norm_ratio"], rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(cls.norm_std, want["norm_std"], rtol=5e-2, atol=3e-3)
+    np.testing.assert_allclose(cls.cos_dis, want["cos_dis"], rtol=5e-2, atol=2e-3)
+    cls.forward = MM.flux_plain_forward
+
+
+def test_flux_errors(flux):
+    g, meta, cfg, oracle, m, kw = flux
+    x = torch.from_numpy(g["latent0"])
+    with pytest.raises(ValueError):
+        m(hidden_states=dev(x), timestep=torch.tensor([0.5]), **{k: dev(v) for k, v in dict(kw, guidance=None).items() if v is not None})
+    with pytest.raises(AssertionError):
+        m(hidden_states=dev(x[:, :50]), timestep=torch.tensor([0.5]), **{k: dev(v) for k, v in kw.items()})
+    e = m.engine
+    e.reset()
+    with pytest.raises(_lib.MagCacheHipError):       # skip with an empty residual cache
+        e.forward(dev(x[0]), 500.0, 4000.0, dev(kw["encoder_hidden_states"][0]), meta["txt_len"], dev(kw["pooled_projections"][0]),
+                  mode=MM.MC_MODE_SKIP)
+
+
+# ----------------------------------------------------------------------------- HunyuanVideo
+@pytest.fixture(scope="module")
+def hunyuan(golden_dir):
+    g = np.load(os.path.join(golden_dir, "hunyuan_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = dict(meta["cfg"], patch_size=tuple(meta["cfg"]["patch_size"]), rope_dim_list=tuple(meta["cfg"]["rope_dim_list"]))
+    oracle = HR.init_synthetic_(HR.HYVideoDiffusionTransformer(**cfg), seed=meta["weight_seed"], std=meta["weight_std"])
+    cls = type("HunyuanHIPUnderTest", (MM.HYVideoDiffusionTransformerHIP,), {})
+    m = cls(cfg, tuple(meta["grid"]), txt_len=meta["txt_len"], device=DEV, calibration=True)
+    m.load_state_dict(oracle.state_dict())
+    kw = dict(text_states=torch.from_numpy(g["txt"]), text_mask=torch.from_numpy(g["mask"]),
+              text_states_2=torch.from_numpy(g["txt2"]), freqs_cos=torch.from_numpy(g["cos"]),
+              freqs_sin=torch.from_numpy(g["sin"]), guidance=torch.tensor([meta["guidance"]]))
+    return g, meta, cfg, oracle, m, kw
+
+
+def test_hunyuan_forward_vs_oracle(hunyuan):
+    g, meta, cfg, oracle, m, kw = hunyuan
+    x = torch.from_numpy(g["latent0"])
+    t = torch.tensor([500.0])
+    with torch.no_grad():
+        ref32 = oracle(x, t, **kw)["x"]
+        ob = HR.init_synthetic_(HR.HYVideoDiffusionTransformer(**cfg), seed=meta["weight_seed"], std=meta["weight_std"]).bfloat16()
+        refbf = ob(x.bfloat16(), t, **dict(kw, text_states=kw["text_states"].bfloat16(),
+                                           text_states_2=kw["text_states_2"].bfloat16()))["x"].float()
+    got = m(dev(x), dev(t), **{k: dev(v) for k, v in kw.items()})["x"]
+    assert got.dtype == torch.float32 and tuple(got.shape) == tuple(ref32.shape)
+    e_hip, e_bf = rel_l2(got, ref32), rel_l2(refbf, ref32)
+    assert e_hip < 2 * e_bf + 1e-3, (e_hip, e_bf)
+    assert e_hip < 2e-2, e_hip
+    # the text mask matters: more valid text tokens -> different output; padded text rows never influence the image
+    mask2 = kw["text_mask"].clone()
+    mask2[0, :meta["n_valid"] + 5] = 1
+    other = m(dev(x), dev(t), **{k: dev(v) for k, v in dict(kw, text_mask=mask2).items()})["x"]
+    assert rel_l2(other, got) > 1e-3
+    txt2 = kw["text_states"].clone()
+    txt2[0, meta["n_valid"]:] = 7.0
+    same = m(dev(x), dev(t), **{k: dev(v) for k, v in dict(kw, text_states=txt2).items()})["x"]
+    assert rel_l2(same, got) < 1e-6
+
+
+def test_hunyuan_magcache_loop_vs_reference_golden(hunyuan):
+    g, meta, cfg, oracle, m, kw = hunyuan
+    steps = meta["steps"]
+    MM.init_hunyuan_magcache(m, steps, meta["thresh"], meta["K"], meta["R"], video_height=720)
+    cls = type(m)
+    x = dev(torch.from_numpy(g["latent0"]).clone())
+    sig, ts = g["sigmas"], g["timesteps"]
+    kwd = {k: dev(v) for k, v in kw.items()}
+    modes, errs = record_modes(cls), []
+    for i in range(steps):
+        o = m(x, torch.tensor([float(ts[i])], device=DEV), **kwd)["x"]
+        errs.append(rel_l2(o[0], g["outs"][i]))
+        x = x + float(sig[i + 1] - sig[i]) * o
+    assert cls.cnt == 0
+    assert [int(mo == MM.MC_MODE_SKIP) for mo in modes] == g["skipped"].tolist()
+    assert max(errs) < 3e-2, errs
+    assert tuple(m.residual_cache.shape) == (m.img_tokens, m.hidden_size)
+    del m.residual_cache
+    cls.forward = MM.hunyuan_plain_forward
+
+
+def test_hunyuan_calibration_vs_reference_golden(hunyuan):
+    g, meta, cfg, oracle, m, kw = hunyuan
+    steps, want = meta["steps"], meta["calib"]
+    MM.init_hunyuan_magcache(m, steps, calibration=True)
+    cls = type(m)
+    x = dev(torch.from_numpy(g["latent0"]).clone())
+    sig, ts = g["sigmas"], g["timesteps"]
+    kwd = {k: dev(v) for k, v in kw.items()}
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i in range(steps):
+            o = m(x, torch.tensor([float(ts[i])], device=DEV), **kwd)["x"]
+            x = x + float(sig[i + 1] - sig[i]) * o
+    assert len(cls.norm_ratio) == steps - 1
+    np.testing.assert_allclose(cls.norm_ratio, want["norm_ratio"], rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(cls.norm_std, want["norm_std"], rtol=5e-2, atol=3e-3)
+    np.testing.assert_allclose(cls.cos_dis, want["cos_dis"], rtol=5e-2, atol=2e-3)
+    cls.forward = MM.hunyuan_plain_forward
+    cls.cnt = 0
+
+
+def test_mmdit_full_width_block_shapes():
+    """FLUX.1-dev / HunyuanVideo real widths (d = 3072, 24 heads, mlp 12288, fused 5d output projection) on a short
+    sequence with 1 + 1 blocks: engine vs the fp32 oracle, same tolerance as the tiny geometry."""
+    cfg = dict(FR.FLUX_DEV, num_layers=1, num_single_layers=1, joint_attention_dim=512)
+    oracle = FR.init_synthetic_(FR.FluxTransformer2DModel(**cfg), seed=9, std=0.02)
+    h2, w2, txt_len = 10, 14, 96
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, h2 * w2, 64, generator=g)
+    kw = dict(encoder_hidden_states=torch.randn(1, txt_len, 512, generator=g), pooled_projections=torch.randn(1, 768, generator=g),
+              img_ids=FR.prepare_latent_image_ids(h2, w2), txt_ids=torch.zeros(txt_len, 3), guidance=torch.tensor([4.0]))
+    t = torch.tensor([0.5])
+    with torch.no_grad():
+        ref32 = oracle(hidden_states=x, timestep=t, **kw)[0]
+    cls = type("FluxHIPFullWidth", (MM.FluxTransformer2DModelHIP,), {})
+    m = cls(cfg, h2 * w2, txt_len=txt_len, device=DEV, calibration=False)
+    m.load_state_dict(oracle.state_dict())
+    got = m(hidden_states=dev(x), timestep=dev(t), return_dict=False, **{k: dev(v) for k, v in kw.items()})[0]
+    assert rel_l2(got, ref32) < 2e-2

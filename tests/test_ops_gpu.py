@@ -42,7 +42,8 @@ def kernel_variant(request):
 
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (512, 1536, 1536), (1000, 384, 4096),
-                                   (77, 8960, 1536), (256, 1536, 8960), (768, 512, 256), (256, 256, 4096)])
+                                   (77, 8960, 1536), (256, 1536, 8960), (768, 512, 256), (256, 256, 4096),
+                                   (300, 512, 512), (1000, 768, 1024)])   # partial last M tile of the 256^2 kernel
 def test_gemm_bf16_epilogues(M, N, K, kernel_variant):
     A = rnd(M, K, seed=1, dtype=torch.bfloat16)
     Wt = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)   # asymmetric operands (transposes would show)

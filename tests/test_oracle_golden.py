@@ -190,3 +190,71 @@ def test_autocast_oracle_close_to_fp32_oracle(golden_run):
 def test_psnr_identity():
     a = np.random.RandomState(0).rand(4, 4)
     assert MR.psnr(a, a) == 100.0   # calculate_psnr.py:13-14
+
+
+# ----------------------------------------------------------------------------- MM-DiT families (FLUX, HunyuanVideo)
+def _flux_case(golden_dir):
+    from oracle import flux_ref as FR
+    g = np.load(os.path.join(golden_dir, "flux_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = dict(meta["cfg"], axes_dims_rope=tuple(meta["cfg"]["axes_dims_rope"]))
+    model = FR.init_synthetic_(FR.FluxTransformer2DModel(**cfg), seed=meta["weight_seed"], std=meta["weight_std"])
+    kw = dict(encoder_hidden_states=torch.from_numpy(g["ctx"]), pooled_projections=torch.from_numpy(g["pooled"]),
+              img_ids=torch.from_numpy(g["img_ids"]), txt_ids=torch.from_numpy(g["txt_ids"]),
+              guidance=torch.tensor([meta["guidance"]]))
+    return g, meta, model, kw
+
+
+def _hunyuan_case(golden_dir):
+    from oracle import hunyuan_ref as HR
+    g = np.load(os.path.join(golden_dir, "hunyuan_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg = dict(meta["cfg"], patch_size=tuple(meta["cfg"]["patch_size"]), rope_dim_list=tuple(meta["cfg"]["rope_dim_list"]))
+    model = HR.init_synthetic_(HR.HYVideoDiffusionTransformer(**cfg), seed=meta["weight_seed"], std=meta["weight_std"])
+    kw = dict(text_states=torch.from_numpy(g["txt"]), text_mask=torch.from_numpy(g["mask"]),
+              text_states_2=torch.from_numpy(g["txt2"]), freqs_cos=torch.from_numpy(g["cos"]),
+              freqs_sin=torch.from_numpy(g["sin"]), guidance=torch.tensor([meta["guidance"]]))
+    return g, meta, model, kw
+
+
+@pytest.mark.parametrize("family", ["flux", "hunyuan"])
+def test_mmdit_magcache_forward_matches_reference_run(golden_dir, family):
+    """oracle MagCacheMMDiT == the reference's own magcache_forward (FLUX: source exec'd; HunyuanVideo: module
+    imported) run around the same oracle model: per-call outputs, skip schedule."""
+    g, meta, model, kw = (_flux_case if family == "flux" else _hunyuan_case)(golden_dir)
+    steps = meta["steps"]
+    table = TABLES["flux_dev" if family == "flux" else "hunyuan_720p"]
+    mc = MR.MagCacheMMDiT(model, family, steps, meta["thresh"], meta["K"], meta["R"], MR.nearest_interp(np.asarray(table), steps))
+    x = torch.from_numpy(g["latent0"]).clone()
+    sig = g["sigmas"]
+    for i in range(steps):
+        if family == "flux":
+            o = mc.forward(hidden_states=x, timestep=torch.tensor([float(sig[i])]), **kw)
+        else:
+            o = mc.forward(x=x, t=torch.tensor([float(g["timesteps"][i])]), **kw)
+        np.testing.assert_allclose(o[0].numpy(), g["outs"][i], rtol=1e-4, atol=1e-4)
+        x = x + float(sig[i + 1] - sig[i]) * o
+    assert [int(s) for _, s in mc.trace] == g["skipped"].tolist() and g["skipped"].sum() > 0
+    # the same schedule from the table alone (the rule is data independent)
+    rs = MR.RuleState(family, steps, meta["thresh"], meta["K"], meta["R"], MR.nearest_interp(np.asarray(table), steps))
+    assert [int(s) for s, _ in rs.schedule()] == g["skipped"].tolist()
+
+
+@pytest.mark.parametrize("family", ["flux", "hunyuan"])
+def test_mmdit_calibration_matches_reference_run(golden_dir, family):
+    g, meta, model, kw = (_flux_case if family == "flux" else _hunyuan_case)(golden_dir)
+    steps, want = meta["steps"], meta["calib"]
+    mc = MR.MagCacheMMDiT(model, family, steps, 0.0, 0, 0.2, np.ones(steps))
+    x = torch.from_numpy(g["latent0"]).clone()
+    sig = g["sigmas"]
+    n = steps - 1 if family == "flux" else steps          # the FLUX reference clears its lists when cnt wraps
+    for i in range(n):
+        if family == "flux":
+            o = mc.calibrate(hidden_states=x, timestep=torch.tensor([float(sig[i])]), **kw)
+        else:
+            o = mc.calibrate(x=x, t=torch.tensor([float(g["timesteps"][i])]), **kw)
+        x = x + float(sig[i + 1] - sig[i]) * o
+    assert len(want["norm_ratio"]) == n - 1
+    np.testing.assert_allclose(mc.norm_ratio, want["norm_ratio"], atol=2e-5)
+    np.testing.assert_allclose(mc.norm_std, want["norm_std"], atol=2e-5)
+    np.testing.assert_allclose(mc.cos_dis, want["cos_dis"], atol=2e-5)
