@@ -61,6 +61,9 @@ typedef struct {
   int clip_dim;         /* 0: t2v.  > 0: Wan2.1 I2V -- width of the CLIP image features (1280); the model then
                            has img_emb (MLPProj) and the k_img / v_img cross-attention branch over 257 image
                            tokens (upstream WanI2VCrossAttention), and in_dim counts the y channels (36) */
+  int vace_layers;      /* 0: none.  > 0: Wan2.1 VACE -- number of control blocks (15 for 1.3B, 8 for 14B);           */
+  int vace_stride;      /*   block i hints main layer i * vace_stride (2 / 5); upstream vace_layers                    */
+  int vace_in_dim;      /*   channels of vace_context (96)                                                             */
 } mc_config;
 
 const char* mc_last_error(void);
@@ -101,6 +104,11 @@ mc_status mc_forward(mc_engine* e, const float* latent_dev, const float* t_dev, 
 /* Wan2.1 I2V: clip_fea (upstream `clip_fea`, magcache_generate.py:203,264-266) = [n_tokens (257), clip_dim]
  * fp32 or bf16.  Runs img_emb on it and keeps the image-token context for the following forwards. */
 mc_status mc_set_clip_fea(mc_engine* e, const void* clip_dev, mc_dtype dtype, int n_tokens, mc_stream stream);
+
+/* Wan2.1 VACE: vace_context [vace_in_dim, F, H, W] fp32 (reference magcache_vace_forward argument, :443, :544) and
+ * vace_context_scale (:446, :546).  The patch embedding of the context is computed here, once per video; pass NULL to
+ * change the scale only. */
+mc_status mc_set_vace_context(mc_engine* e, const float* vace_dev, float context_scale, mc_stream stream);
 
 /* ---- the same forward in phases (sequence parallel: the caller runs the K/V all-gather between
  * pre_attn and post_attn of every layer with its own communicator, e.g. torch.distributed/RCCL) */

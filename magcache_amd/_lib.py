@@ -20,7 +20,8 @@ class McConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("dim", "ffn_dim", "num_heads", "num_layers", "in_dim", "out_dim", "freq_dim",
                                        "text_dim", "text_len", "latent_f", "latent_h", "latent_w")] + \
                [("eps", C.c_float)] + \
-               [(n, C.c_int) for n in ("sp_rank", "sp_size", "n_branches", "calibration", "clip_dim")]
+               [(n, C.c_int) for n in ("sp_rank", "sp_size", "n_branches", "calibration", "clip_dim", "vace_layers",
+                                         "vace_stride", "vace_in_dim")]
 
 
 class MagCacheHipError(RuntimeError):
@@ -45,6 +46,7 @@ SIGNATURES = {
     "mc_weights_missing": (_i, [_vp, C.c_char_p, _sz]),
     "mc_forward": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mc_set_clip_fea": (_i, [_vp, _vp, _i, _i, _vp]),
+    "mc_set_vace_context": (_i, [_vp, _vp, _f, _vp]),
     "mc_embed": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _vp]),
     "mc_block_pre_attn": (_i, [_vp, _i, _vp]),
     "mc_block_attn_local": (_i, [_vp, _i, _vp]),

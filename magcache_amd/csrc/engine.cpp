@@ -79,6 +79,15 @@ struct mc_engine {
   int img_rows = 0;     // 257 image tokens padded to a multiple of 64
   bool have_clip = false;
   int local_attn_layer = -1;  // layer whose local-shard attention already ran (two-phase SP attention)
+  // VACE (upstream wan/modules/vace_model.py VaceWanModel): n_vace extra blocks on a control stream c; block i feeds
+  // main layer i * vace_stride through after_proj ("hint")
+  std::vector<Layer> vlayers;
+  std::vector<bf16_t*> w_after;
+  std::vector<float*> b_after;
+  bf16_t *w_vpatch = nullptr, *w_before = nullptr;
+  float *b_vpatch = nullptr, *b_before = nullptr, *vscale = nullptr;
+  int NV = 0, Kvp = 0;
+  bool have_vace = false;
   float* cs_table = nullptr;  // rope (cos,sin) [Lp][64][2]
   std::map<std::string, Slot> slots;
   std::vector<void*> owned;
@@ -200,6 +209,10 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (c.n_branches != 1 && c.n_branches != 2) return fail(MC_EINVAL, "n_branches must be 1 or 2");
   if (c.out_dim * 4 > 64) return fail(MC_EINVAL, "out_dim*4 > 64 unsupported by the head kernel");
   if (c.clip_dim < 0 || (c.clip_dim % 256) != 0) return fail(MC_EINVAL, "clip_dim %d must be 0 or a multiple of 256", c.clip_dim);
+  if (c.vace_layers < 0 || (c.vace_layers > 0 && (c.vace_stride <= 0 || c.vace_in_dim <= 0 ||
+                                                   (c.vace_layers - 1) * c.vace_stride >= c.num_layers)))
+    return fail(MC_EINVAL, "bad VACE geometry: %d blocks, stride %d, in_dim %d", c.vace_layers, c.vace_stride, c.vace_in_dim);
+  if (c.vace_layers > 0 && c.sp_size > 1) return fail(MC_EINVAL, "VACE is single-GPU in this engine (sp_size must be 1)");
 
   mc_engine* e = new mc_engine();
   e->cfg = c;
@@ -220,8 +233,11 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   mc_status st = MC_OK;
 #define ALLOC(ptr, n) do { st = dev_alloc(e, &(ptr), (n)); if (st != MC_OK) { mc_destroy(e); return st; } } while (0)
   e->layers.resize(e->NL);
-  for (int i = 0; i < e->NL; ++i) {
-    Layer& l = e->layers[i];
+  e->NV = c.vace_layers;
+  e->vlayers.resize(e->NV);
+  for (int i = 0; i < e->NL + e->NV; ++i) {
+    const bool is_vace = i >= e->NL;
+    Layer& l = is_vace ? e->vlayers[i - e->NL] : e->layers[i];
     ALLOC(l.wqkv, 3 * d * d); ALLOC(l.bqkv, 3 * d); ALLOC(l.nq, d); ALLOC(l.nk, d);
     ALLOC(l.wo, d * d); ALLOC(l.bo, d);
     ALLOC(l.n3w, d); ALLOC(l.n3b, d);
@@ -230,7 +246,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     ALLOC(l.wco, d * d); ALLOC(l.bco, d);
     ALLOC(l.w1, ffn * d); ALLOC(l.b1, ffn); ALLOC(l.w2, d * ffn); ALLOC(l.b2, d);
     ALLOC(l.mod, 6 * d);
-    const std::string p = "blocks." + std::to_string(i) + ".";
+    const std::string p = (is_vace ? "vace_blocks." + std::to_string(i - e->NL) : "blocks." + std::to_string(i)) + ".";
     add_slot(e, p + "self_attn.q.weight", l.wqkv, MC_BF16, d * d, 0);
     add_slot(e, p + "self_attn.k.weight", l.wqkv, MC_BF16, d * d, d * d);
     add_slot(e, p + "self_attn.v.weight", l.wqkv, MC_BF16, d * d, 2 * d * d);
@@ -265,6 +281,24 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
       add_slot(e, p + "cross_attn.k_img.bias", l.bckv_img, MC_F32, d, 0);
       add_slot(e, p + "cross_attn.v_img.bias", l.bckv_img, MC_F32, d, d);
       add_slot(e, p + "cross_attn.norm_k_img.weight", l.cnk_img, MC_F32, d);
+    }
+  }
+  if (e->NV > 0) {
+    e->Kvp = (int)align_up((size_t)c.vace_in_dim * 4, 64);
+    const size_t kv = (size_t)c.vace_in_dim * 4;
+    if (kv != (size_t)e->Kvp) { mc_destroy(e); return fail(MC_EINVAL, "vace_in_dim*4 must be a multiple of 64"); }
+    ALLOC(e->w_vpatch, d * kv); ALLOC(e->b_vpatch, d); ALLOC(e->w_before, d * d); ALLOC(e->b_before, d);
+    ALLOC(e->vscale, d);
+    add_slot(e, "vace_patch_embedding.weight", e->w_vpatch, MC_BF16, d * kv);
+    add_slot(e, "vace_patch_embedding.bias", e->b_vpatch, MC_F32, d);
+    add_slot(e, "vace_blocks.0.before_proj.weight", e->w_before, MC_BF16, d * d);
+    add_slot(e, "vace_blocks.0.before_proj.bias", e->b_before, MC_F32, d);
+    e->w_after.resize(e->NV); e->b_after.resize(e->NV);
+    for (int i = 0; i < e->NV; ++i) {
+      ALLOC(e->w_after[i], d * d); ALLOC(e->b_after[i], d);
+      const std::string p = "vace_blocks." + std::to_string(i) + ".after_proj.";
+      add_slot(e, p + "weight", e->w_after[i], MC_BF16, d * d);
+      add_slot(e, p + "bias", e->b_after[i], MC_F32, d);
     }
   }
   if (c.clip_dim > 0) {
@@ -332,7 +366,12 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   add_buf(e, cur, "ctx", (size_t)e->ctx_rows * d * 2);
   add_buf(e, cur, "ckv", (size_t)e->ctx_rows * 2 * d * 2);
   add_buf(e, cur, "temb", (size_t)(c.freq_dim + 2 * d + 6 * d) * 4);  // sinus | h1 | e | e0
-  add_buf(e, cur, "emod", (size_t)e->NL * 6 * d * 4);
+  add_buf(e, cur, "emod", (size_t)(e->NL + e->NV) * 6 * d * 4);
+  if (e->NV > 0) {
+    add_buf(e, cur, "xc", Lp * d * 4);                       // VACE control stream c (fp32 like x)
+    add_buf(e, cur, "c0", Lp * d * 2);                       // vace_patch_embedding(vace_context), constant per video
+    add_buf(e, cur, "vtokens", Lp * (size_t)e->Kvp * 2);
+  }
   add_buf(e, cur, "ehead", 2 * d * 4);
   add_buf(e, cur, "head_tokens", Lp * 64 * 4);
   add_buf(e, cur, "kv_gather", e->P > 1 ? (size_t)e->P * Lp * 2 * d * 2 : 256);
@@ -485,6 +524,34 @@ mc_status mc_set_clip_fea(mc_engine* e, const void* clip_dev, mc_dtype dtype, in
   return MC_OK;
 }
 
+// VACE: c0 = vace_patch_embedding(vace_context) (upstream forward_vace; reference call site :544), constant over a
+// video, and the hint scale (vace_context_scale, :546).
+mc_status mc_set_vace_context(mc_engine* e, const float* vace_dev, float context_scale, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  mc_status st = check_ready(e);
+  if (st != MC_OK) return st;
+  if (e->NV <= 0) return fail(MC_EINVAL, "engine was created without VACE blocks");
+  const mc_config& c = e->cfg;
+  const int d = e->d;
+  if (vace_dev) {
+    bf16_t* vt = e->buf<bf16_t>("vtokens");
+    HIP_TRY(mc::launch_patchify(vace_dev, c.vace_in_dim, c.latent_f, c.latent_h, c.latent_w, e->tok0, e->Lr, e->Lp, vt,
+                                e->Kvp, s));
+    mc::GemmParams p = gp(vt, e->Kvp, e->w_vpatch, e->Kvp, e->b_vpatch, e->Lp, d, e->Kvp);
+    p.X = e->buf<float>("xc"); p.ldx = d;
+    p.X0out = e->buf<bf16_t>("c0"); p.ldx0out = d;
+    p.m_valid = e->Lr;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
+    e->have_vace = true;
+  } else if (!e->have_vace) {
+    return fail(MC_EINVAL, "null vace_context and none set before");
+  }
+  std::vector<float> sc(d, context_scale);
+  HIP_TRY(hipMemcpyAsync(e->vscale, sc.data(), (size_t)d * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));   // sc is a host temporary
+  return MC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // embeds: patch embedding, time embedding + projection, text embedding   (reference :236-262)
 mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
@@ -523,8 +590,9 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
   HIP_TRY(mc::launch_gemv_f32(e->w_tproj, ev, e->b_tproj, e0, 6 * d, d, 1, 0, s));
   // per-layer modulation vectors (block.modulation + e0) and the head's (head.modulation + e)
   float* emod = e->buf<float>("emod");
-  for (int l = 0; l < e->NL; ++l)
-    HIP_TRY(mc::launch_add_bcast(e0, 6 * d, e->layers[l].mod, emod + (size_t)l * 6 * d, 6 * d, s));
+  for (int l = 0; l < e->NL + e->NV; ++l)
+    HIP_TRY(mc::launch_add_bcast(e0, 6 * d, (l < e->NL ? e->layers[l] : e->vlayers[l - e->NL]).mod,
+                                 emod + (size_t)l * 6 * d, 6 * d, s));
   HIP_TRY(mc::launch_add_bcast(ev, d, e->head_mod, e->buf<float>("ehead"), 2 * d, s));
   // context = text_embedding(zero-padded context)   (:256-262)
   bf16_t* ctx_in = e->buf<bf16_t>("ctx_in");
@@ -548,14 +616,10 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
 }
 
 // LN + modulate -> q,k,v Linear -> RMSNorm(q), RMSNorm(k) -> RoPE(q,k)      (upstream WanSelfAttention)
-mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream_) {
-  hipStream_t s = (hipStream_t)stream_;
-  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
-  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
-  const Layer& l = e->layers[layer];
+// l / em / x: the block's weights, its 6 modulation vectors and the residual stream it works on (the main stream
+// "x", or the VACE control stream "xc")
+static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float* x, hipStream_t s) {
   const int d = e->d, Lp = e->Lp;
-  const float* em = e->buf<float>("emod") + (size_t)layer * 6 * d;
-  float* x = e->buf<float>("x");
   bf16_t* xn = e->buf<bf16_t>("xn");
   bf16_t* qkv = e->buf<bf16_t>("qkv");
   HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + d, em, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s));
@@ -580,6 +644,13 @@ mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream_) {
   return MC_OK;
 }
 
+mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream_) {
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
+  return block_pre(e, e->layers[layer], e->buf<float>("emod") + (size_t)layer * 6 * e->d, e->buf<float>("x"),
+                   (hipStream_t)stream_);
+}
+
 // Self-attention over this rank's own K/V shard (slot `rank` of "kv_gather"): normalised partial result -> "ao",
 // log2-sum-exp -> "attn_lse".  Needs nothing from the other ranks, so the caller overlaps it with the all-gather.
 mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream_) {
@@ -602,15 +673,11 @@ mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream_) {
 }
 
 // attention -> o (+gated residual) -> norm3 -> cross-attn (+residual) -> LN+mod -> FFN (+gated residual)
-mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream_) {
-  hipStream_t s = (hipStream_t)stream_;
-  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
-  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
-  if (branch < 0 || branch >= e->cfg.n_branches) return fail(MC_EINVAL, "branch %d out of range", branch);
-  const Layer& l = e->layers[layer];
+// layer: main-layer index (sequence-parallel two-phase bookkeeping), -1 for a VACE block.  capture: fuse the MagCache
+// residual capture into the last epilogue (the last main layer, unless a VACE hint is still to be added to it).
+static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float* x, int layer, bool capture, int branch,
+                            mc_mode mode, hipStream_t s) {
   const int d = e->d, Lp = e->Lp, ffn = e->ffn;
-  const float* em = e->buf<float>("emod") + (size_t)layer * 6 * d;
-  float* x = e->buf<float>("x");
   bf16_t* xn = e->buf<bf16_t>("xn");
   bf16_t* qkv = e->buf<bf16_t>("qkv");
   bf16_t* ao = e->buf<bf16_t>("ao");
@@ -632,7 +699,7 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
       a.K = kvg; a.ldk = 2 * d; a.k_shard_stride = (long)Lp * 2 * d;
       a.V = kvg + d; a.ldv = 2 * d; a.v_shard_stride = (long)Lp * 2 * d;
       a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = e->P;
-      if (e->local_attn_layer == layer) {  // the local shard is done: the others only, merged into ao
+      if (layer >= 0 && e->local_attn_layer == layer) {  // the local shard is done: the others only, merged into ao
         a.skip_shard_p1 = e->rank + 1;
         a.lse_in = e->buf<float>("attn_lse");
       }
@@ -691,7 +758,7 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
     HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
     mc::GemmParams q = gp(h, ffn, l.w2, ffn, l.b2, Lp, d, ffn);
     q.X = x; q.ldx = d; q.gate = em + 5 * d;
-    if (layer == e->NL - 1) {
+    if (capture) {
       // MagCache residual capture fused into the last epilogue: residual = x_out - ori_x  (:299-301)
       const int dst = (mode == MC_MODE_CALIB) ? e->res_scratch : e->res_slot[branch];
       q.X0 = e->buf<bf16_t>("x0"); q.ldx0 = d;
@@ -714,6 +781,69 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
       HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_RESID_GATE, s));
     }
   }
+  return MC_OK;
+}
+
+// The last main layer receives a VACE hint: no fused capture there, the residual is taken after the hint was added.
+static bool hint_on_last_layer(const mc_engine* e) {
+  return e->NV > 0 && (e->NV - 1) * e->cfg.vace_stride == e->NL - 1;
+}
+
+mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream_) {
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
+  if (branch < 0 || branch >= e->cfg.n_branches) return fail(MC_EINVAL, "branch %d out of range", branch);
+  return block_post(e, e->layers[layer], e->buf<float>("emod") + (size_t)layer * 6 * e->d, e->buf<float>("x"), layer,
+                    layer == e->NL - 1 && !hint_on_last_layer(e), branch, mode, (hipStream_t)stream_);
+}
+
+// VACE: control block i on the stream c, then x += after_proj(c) * context_scale (the "hint" of main layer
+// i * vace_stride; upstream VaceWanAttentionBlock / BaseWanAttentionBlock, reference call site :544-549)
+static mc_status vace_block(mc_engine* e, int i, int branch, mc_mode mode, hipStream_t s) {
+  const int d = e->d, Lp = e->Lp;
+  float* xc = e->buf<float>("xc");
+  float* x = e->buf<float>("x");
+  const Layer& l = e->vlayers[i];
+  const float* em = e->buf<float>("emod") + (size_t)(e->NL + i) * 6 * d;
+  if (i == 0) {
+    // c = before_proj(c0) + x, x = the embedded latent (ori_x, bf16 under autocast)
+    HIP_TRY(hipMemsetAsync(xc, 0, (size_t)Lp * d * 4, s));
+    HIP_TRY(mc::launch_skip_add(e->buf<bf16_t>("x0"), d, xc, d, xc, d, Lp, d, s));
+    mc::GemmParams p = gp(e->buf<bf16_t>("c0"), d, e->w_before, d, e->b_before, Lp, d, d);
+    p.X = xc; p.ldx = d; p.gate = nullptr;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_RESID_GATE, s));
+  }
+  mc_status st = block_pre(e, l, em, xc, s);
+  if (st != MC_OK) return st;
+  st = block_post(e, l, em, xc, -1, false, branch, mode, s);
+  if (st != MC_OK) return st;
+  // hint: after_proj(c) needs bf16 rows of c; the LayerNorm scratch xn is free here
+  bf16_t* xn = e->buf<bf16_t>("xn");
+  HIP_TRY(mc::launch_cast_bf16(xc, xn, (size_t)Lp * d, s));
+  mc::GemmParams h = gp(xn, d, e->w_after[i], d, e->b_after[i], Lp, d, d);
+  h.X = x; h.ldx = d; h.gate = e->vscale;
+  HIP_TRY(mc::launch_gemm_bf16(h, mc::EPI_RESID_GATE, s));
+  return MC_OK;
+}
+
+// residual capture + calibration statistics as separate kernels (only when the last layer carries a VACE hint)
+static mc_status capture_unfused(mc_engine* e, int branch, mc_mode mode, hipStream_t s) {
+  const int d = e->d;
+  const int dst = (mode == MC_MODE_CALIB) ? e->res_scratch : e->res_slot[branch];
+  HIP_TRY(mc::launch_residual_sub(e->buf<float>("x"), d, e->buf<bf16_t>("x0"), d, e->residual(dst), d, e->Lp, d, s));
+  if (mode == MC_MODE_CALIB) {
+    if (!e->cfg.calibration) return fail(MC_ESTATE, "engine was created without calibration=1");
+    if (e->have_res[branch]) {
+      HIP_TRY(mc::launch_calib_stats(e->residual(dst), d, e->residual(e->res_slot[branch]), d, e->Lr, d,
+                                     e->buf<double>("calib_partial"), 1024, e->buf<double>("calib_sums"),
+                                     e->buf<float>("calib_stats") + 3 * branch, s));
+      e->have_stats[branch] = true;
+    } else {
+      e->have_stats[branch] = false;
+    }
+    std::swap(e->res_slot[branch], e->res_scratch);
+  }
+  e->have_res[branch] = true;
   return MC_OK;
 }
 
@@ -755,6 +885,8 @@ mc_status mc_forward(mc_engine* e, const float* latent_dev, const float* t_dev, 
   if (!e) return fail(MC_EINVAL, "null engine");
   if (e->P != 1) return fail(MC_ESTATE, "mc_forward is single-GPU; drive a sharded engine through the phase calls");
   if (!out_dev) return fail(MC_EINVAL, "null output");
+  if (e->NV > 0 && mode != MC_MODE_SKIP && !e->have_vace)
+    return fail(MC_ESTATE, "VACE model: mc_set_vace_context must run before a non-skipped forward");
   mc_status st = mc_embed(e, latent_dev, t_dev, t_host, context_dev, ctx_dtype, ctx_len, stream);
   if (st != MC_OK) return st;
   if (mode != MC_MODE_SKIP) {
@@ -762,6 +894,14 @@ mc_status mc_forward(mc_engine* e, const float* latent_dev, const float* t_dev, 
       st = mc_block_pre_attn(e, l, stream);
       if (st != MC_OK) return st;
       st = mc_block_post_attn(e, l, branch, mode, stream);
+      if (st != MC_OK) return st;
+      if (e->NV > 0 && l % e->cfg.vace_stride == 0 && l / e->cfg.vace_stride < e->NV) {
+        st = vace_block(e, l / e->cfg.vace_stride, branch, mode, (hipStream_t)stream);
+        if (st != MC_OK) return st;
+      }
+    }
+    if (hint_on_last_layer(e)) {
+      st = capture_unfused(e, branch, mode, (hipStream_t)stream);
       if (st != MC_OK) return st;
     }
   }

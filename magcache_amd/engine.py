@@ -14,6 +14,20 @@ WAN_T2V_14B = dict(dim=5120, ffn_dim=13824, freq_dim=256, num_heads=40, num_laye
 # Wan2.1 I2V-14B (480P and 720P share the architecture): x ++ y = 16 + 20 channels, CLIP ViT-H features 1280 wide
 WAN_I2V_14B = dict(WAN_T2V_14B, model_type="i2v", in_dim=36, clip_dim=1280)
 N_CLIP_TOKENS = 257
+# Wan2.1 VACE (upstream wan/configs vace-1.3B / vace-14B): control blocks every 2nd / 5th layer, 96 context channels
+WAN_VACE_1_3B = dict(WAN_T2V_1_3B, model_type="vace", vace_layers=list(range(0, 30, 2)), vace_in_dim=96)
+WAN_VACE_14B = dict(WAN_T2V_14B, model_type="vace", vace_layers=list(range(0, 40, 5)), vace_in_dim=96)
+
+
+def vace_geometry(cfg):
+    """(number of control blocks, stride) from upstream's `vace_layers` list (None: every 2nd layer)"""
+    if "vace_in_dim" not in cfg and "vace_layers" not in cfg:
+        return 0, 0
+    layers = cfg.get("vace_layers") or list(range(0, cfg["num_layers"], 2))
+    stride = layers[1] - layers[0] if len(layers) > 1 else cfg["num_layers"]
+    assert layers[0] == 0 and all(b - a == stride for a, b in zip(layers, layers[1:])), \
+        f"vace_layers {layers}: the engine takes an arithmetic progression starting at 0 (upstream's configs are)"
+    return len(layers), stride
 
 
 def _stream():
@@ -41,8 +55,12 @@ def weight_names(cfg):
                 ("img_emb.proj.1.weight", (cd, cd)), ("img_emb.proj.1.bias", (cd,)),
                 ("img_emb.proj.3.weight", (d, cd)), ("img_emb.proj.3.bias", (d,)),
                 ("img_emb.proj.4.weight", (d,)), ("img_emb.proj.4.bias", (d,))]
-    for i in range(cfg["num_layers"]):
-        p = f"blocks.{i}."
+    nv, _ = vace_geometry(cfg)
+    if nv:
+        out += [("vace_patch_embedding.weight", (d, cfg["vace_in_dim"], 1, 2, 2)), ("vace_patch_embedding.bias", (d,)),
+                ("vace_blocks.0.before_proj.weight", (d, d)), ("vace_blocks.0.before_proj.bias", (d,))]
+        out += [(f"vace_blocks.{i}.after_proj.{w}", (d, d) if w == "weight" else (d,)) for i in range(nv) for w in ("weight", "bias")]
+    for p in [f"blocks.{i}." for i in range(cfg["num_layers"])] + [f"vace_blocks.{i}." for i in range(nv)]:
         for a in ("self_attn", "cross_attn"):
             for w in ("q", "k", "v", "o"):
                 out += [(p + f"{a}.{w}.weight", (d, d)), (p + f"{a}.{w}.bias", (d,))]
@@ -92,7 +110,8 @@ class Engine:
                      in_dim=cfg["in_dim"], out_dim=cfg["out_dim"], freq_dim=cfg["freq_dim"], text_dim=cfg["text_dim"],
                      text_len=cfg["text_len"], latent_f=F_, latent_h=H_, latent_w=W_, eps=cfg.get("eps", 1e-6),
                      sp_rank=sp_rank, sp_size=sp_size, n_branches=n_branches, calibration=int(calibration),
-                     clip_dim=cfg.get("clip_dim", 0))
+                     clip_dim=cfg.get("clip_dim", 0), vace_layers=vace_geometry(cfg)[0], vace_stride=vace_geometry(cfg)[1],
+                     vace_in_dim=cfg.get("vace_in_dim", 0) if vace_geometry(cfg)[0] else 0)
         self.sp_rank, self.sp_size, self.n_branches = sp_rank, sp_size, n_branches
         h = C.c_void_p()
         check(self.lib.mc_create(C.byref(c), C.byref(h)))
@@ -152,6 +171,11 @@ class Engine:
         c = clip_fea.detach().to(self.device, torch.float32).reshape(-1, clip_fea.shape[-1]).contiguous()
         check(self.lib.mc_set_clip_fea(self.h, _ptr(c), MC_F32, c.shape[0], _stream()))
         torch.cuda.current_stream().synchronize()
+
+    def set_vace_context(self, vace_context, scale=1.0):
+        """Wan2.1 VACE: vace_context [96, F, H, W] (None: change the scale only) and vace_context_scale."""
+        v = None if vace_context is None else vace_context.detach().to(self.device, torch.float32).contiguous()
+        check(self.lib.mc_set_vace_context(self.h, _ptr(v), float(scale), _stream()))
 
     # ---- forward
     def _ctx(self, context):

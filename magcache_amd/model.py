@@ -72,6 +72,7 @@ class WanModelHIP:
         if cfg.get("model_type", "t2v") != "t2v":
             self.model_type = cfg["model_type"]          # instance attribute, like upstream's self.model_type
         self._clip_key = None
+        self._vace_key = None
         self.engine = engine or Engine(cfg, latent_grid, device=device, n_branches=2, calibration=calibration,
                                        sp_rank=sp_rank, sp_size=sp_size)
         self.device = self.engine.device
@@ -95,10 +96,20 @@ class WanModelHIP:
         assert self.engine.seq_len <= seq_len  # seq_lens.max() <= seq_len (:242)
         assert context[0].shape[0] <= self.text_len and context[0].shape[1] == self.text_dim
 
-    def _run(self, x, t, context, branch, mode, clip_fea=None, y=None):
+    def _run(self, x, t, context, branch, mode, clip_fea=None, y=None, vace=None):
         lat = x[0].to(self.device)
         if y is not None:
             lat = torch.cat([lat, y[0].to(self.device)], dim=0)
+        if vace is not None:
+            # vace_patch_embedding(vace_context) is constant over a video: upload when the content / scale changes
+            vc, scale = vace[0][0], float(vace[1])
+            k = self._vace_key
+            if k is None or k[0].shape != vc.shape or not torch.equal(k[0], vc.to(k[0].device)):
+                self.engine.set_vace_context(vc, scale)
+                self._vace_key = (vc.detach().to(self.device).clone(), scale)
+            elif k[1] != scale:
+                self.engine.set_vace_context(None, scale)
+                self._vace_key = (k[0], scale)
         if clip_fea is not None:
             # img_emb(clip_fea) is constant over a video: run it when the tensor changes, not every call
             k = self._clip_key
@@ -200,6 +211,75 @@ def magcache_calibration(self, x, t, context, seq_len, clip_fea=None, y=None):
             with open(fn + ".json", "w") as f:
                 json.dump(v, f)
     return out
+
+
+def _vace_checks(self, x, vace_context, context, seq_len):
+    # the i2v inputs are commented out in the reference's VACE forwards (:471-476, :508-510): plain t2v checks
+    type(self)._check_inputs(self, x, context, seq_len, None, None)
+    assert len(vace_context) == 1 and tuple(vace_context[0].shape[1:]) == self.latent_grid \
+        and vace_context[0].shape[0] == self.cfg["vace_in_dim"], f"vace_context {tuple(vace_context[0].shape)}"
+
+
+def magcache_vace_forward(self, x, t, vace_context, context, seq_len, vace_context_scale=1.0, clip_fea=None, y=None):
+    """Drop-in for the reference's magcache_vace_forward (:439-560): the MagCache rule of magcache_forward around the
+    VACE model (control blocks + hints run inside the engine)."""
+    _vace_checks(self, x, vace_context, context, seq_len)
+    p = self.cnt % 2
+    skip_forward = False
+    if self.cnt >= int(self.num_steps * self.retention_ratio):                              # :521-536
+        self.accumulated_ratio[p] = self.accumulated_ratio[p] * self.mag_ratios[self.cnt]
+        self.accumulated_steps[p] += 1
+        self.accumulated_err[p] += np.abs(1 - self.accumulated_ratio[p])
+        if self.accumulated_err[p] < self.magcache_thresh and self.accumulated_steps[p] <= self.K:
+            skip_forward = True
+        else:
+            self.accumulated_err[p] = 0
+            self.accumulated_steps[p] = 0
+            self.accumulated_ratio[p] = 1.0
+    if skip_forward and self.residual_cache[p] is None:
+        raise RuntimeError("MagCache asked to skip before any residual was cached (retention_ratio too small?)")
+    out = self._run(x, t, context, p, MC_MODE_SKIP if skip_forward else MC_MODE_FULL,
+                    vace=(vace_context, vace_context_scale))
+    self.residual_cache[p] = self.engine.residual(p)
+    _advance(self)
+    return out
+
+
+def magcache_vace_calibration(self, x, t, vace_context, context, seq_len, vace_context_scale=1.0, clip_fea=None, y=None):
+    """Drop-in for the reference's magcache_vace_calibration (:314-437)."""
+    _vace_checks(self, x, vace_context, context, seq_len)
+    p = self.cnt % 2
+    out = self._run(x, t, context, p, MC_MODE_CALIB, vace=(vace_context, vace_context_scale))
+    if self.cnt >= 2:
+        norm_ratio, norm_std, cos_dis = self.engine.calib_stats(p)
+        self.norm_ratio.append(round(norm_ratio, 5))
+        self.norm_std.append(round(norm_std, 5))
+        self.cos_dis.append(round(cos_dis, 5))
+        print(f"time: {self.cnt}, norm_ratio: {norm_ratio}, norm_std: {norm_std}, cos_dis: {cos_dis}")
+    self.residual_cache[p] = self.engine.residual(p)
+    self.cnt += 1
+    if self.cnt >= self.num_steps:
+        self.cnt = 0
+        self.accumulated_ratio = [1.0, 1.0]
+        self.accumulated_err = [0.0, 0.0]
+        self.accumulated_steps = [0, 0]
+        print("norm ratio")
+        print(self.norm_ratio)
+        print("norm std")
+        print(self.norm_std)
+        print("cos_dis")
+        print(self.cos_dis)
+        for fn, v in (("wan2_1_mag_ratio", self.norm_ratio), ("wan2_1_mag_std", self.norm_std),
+                      ("wan2_1_cos_dis", self.cos_dis)):
+            with open(fn + ".json", "w") as f:
+                json.dump(v, f)
+    return out
+
+
+def vace_plain_forward(self, x, t, vace_context, context, seq_len, vace_context_scale=1.0, clip_fea=None, y=None):
+    """upstream VaceWanModel.forward (no cache)"""
+    _vace_checks(self, x, vace_context, context, seq_len)
+    return self._run(x, t, context, 0, MC_MODE_FULL, vace=(vace_context, vace_context_scale))
 
 
 def call_branch(model, step, branch, x, t, context, seq_len):

@@ -279,6 +279,48 @@ def main():
                                              guide=5.0, shift=3.0, weight_seed=11, weight_std=0.05,
                                              table="wan2.1_i2v_480P")))
 
+    # ---------------------------------------------------------------- VACE wrapper forward golden
+    # the reference's magcache_vace_forward (:439-560) around the oracle VaceWanModel
+    cfg_v = W.tiny_config(num_layers=4, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64)
+    vace_kw = dict(vace_layers=[0, 2], vace_in_dim=96)
+    Fv, Hv, Wv, steps_v, scale_v = 2, 16, 20, 8, 0.8
+    seq_v = Fv * (Hv // 2) * (Wv // 2)
+    gv = torch.Generator().manual_seed(91)
+    lat_v = torch.randn(16, Fv, Hv, Wv, generator=gv)
+    vctx = torch.randn(96, Fv, Hv, Wv, generator=gv)
+    ctx_v = torch.randn(23, cfg_v["text_dim"], generator=gv)
+    ctxn_v = torch.randn(7, cfg_v["text_dim"], generator=gv)
+    sig_v, ts_v = flow_timesteps(steps_v, shift=5.0)
+    cls = type("PatchedVaceWanModel", (W.VaceWanModel,), {})
+    model = W.init_synthetic_(cls(**cfg_v, **vace_kw), seed=13, std=0.05)
+    patch_like_reference(cls, ref, steps_v * 2, 0.12, 2, 0.2, TABLES["wan2.1_vace_1.3B"], steps_v)
+    cls.forward = ref.magcache_vace_forward               # :1127
+    outs_v, ran, sk_v = [], [], []
+    hook = model.blocks[0].register_forward_hook(lambda *a: ran.append(True))
+    x = lat_v.clone()
+    import contextlib, io
+    with torch.no_grad(), warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+        warnings.simplefilter("ignore")
+        for i in range(steps_v):
+            t = torch.tensor([float(ts_v[i])])
+            pred = []
+            for c in (ctx_v, ctxn_v):
+                n0 = len(ran)
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    pred.append(model([x], t=t, vace_context=[vctx], context=[c], seq_len=seq_v, vace_context_scale=scale_v)[0])
+                sk_v.append(len(ran) == n0)
+            outs_v += [pred[0].numpy().copy(), pred[1].numpy().copy()]
+            x = x + float(sig_v[i + 1] - sig_v[i]) * (pred[1] + 5.0 * (pred[0] - pred[1]))
+    hook.remove()
+    assert sum(sk_v) > 0 and cls.cnt == 0
+    np.savez_compressed(os.path.join(GOLD, "wan_vace_forward_golden.npz"),
+                        outs=np.stack(outs_v).astype(np.float32), final_latent=x.numpy(), latent0=lat_v.numpy(),
+                        vace_context=vctx.numpy(), ctx=ctx_v.numpy(), ctx_null=ctxn_v.numpy(), timesteps=ts_v, sigmas=sig_v,
+                        skipped=np.array(sk_v, dtype=np.int8),
+                        meta=json.dumps(dict(cfg=cfg_v, vace=vace_kw, F=Fv, H=Hv, W=Wv, steps=steps_v, thresh=0.12, K=2,
+                                             R=0.2, guide=5.0, shift=5.0, scale=scale_v, weight_seed=13, weight_std=0.05,
+                                             table="wan2.1_vace_1.3B")))
+
     # ---------------------------------------------------------------- calibration goldens
     cfg = W.tiny_config(num_layers=2, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64)
     cls = fresh_model_class()

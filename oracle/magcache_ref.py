@@ -120,12 +120,21 @@ class MagCacheWan:
     def _ctx(self):
         return torch.autocast("cpu", dtype=torch.bfloat16) if self.autocast else torch.autocast("cpu", enabled=False)
 
-    def forward(self, x, t, context, seq_len, use_cache=True, clip_fea=None, y=None):
+    def _peek_skip(self):
+        import copy
+        return copy.deepcopy(self.rule).step()[0]
+
+    def forward(self, x, t, context, seq_len, use_cache=True, clip_fea=None, y=None, vace_context=None,
+                vace_context_scale=1.0):
         m = self.model
         cnt = self.rule.cnt
         with torch.no_grad(), self._ctx():
             x, e, kwargs = m.embed(x, t, context, seq_len, clip_fea, y)
             ori_x = x
+            if vace_context is not None and not (use_cache and self._peek_skip()):
+                # magcache_vace_forward (:544-546): the control blocks run only when the step is not skipped
+                kwargs["hints"] = m.forward_vace(x, vace_context, seq_len, kwargs)
+                kwargs["context_scale"] = vace_context_scale
             skip, p = self.rule.step() if use_cache else (False, cnt % 2)
             if not use_cache:
                 self.rule.cnt = (cnt + 1) % self.rule.num_steps

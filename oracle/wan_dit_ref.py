@@ -36,7 +36,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 __all__ = ["WanModel", "sinusoidal_embedding_1d", "rope_params", "rope_apply", "WAN_T2V_1_3B", "WAN_T2V_14B",
-           "WAN_I2V_14B", "tiny_config", "init_synthetic_"]
+           "WAN_I2V_14B", "VaceWanModel", "tiny_config", "init_synthetic_"]
 
 
 def sinusoidal_embedding_1d(dim, position):
@@ -314,6 +314,67 @@ class WanModel(nn.Module):
         for m in self.modules():
             if isinstance(m, WanSelfAttention):
                 m.fp32_attention = flag
+
+
+class VaceWanModel(WanModel):
+    """Upstream wan/modules/vace_model.py VaceWanModel: `vace_blocks` (one per entry of vace_layers) run a control
+    stream c = vace_patch_embedding(vace_context) next to the main blocks; block 0 first adds before_proj(c) to the
+    embedded latent; every control block emits a hint after_proj(c) that main layer vace_layers[i] adds to its output
+    scaled by context_scale (BaseWanAttentionBlock).  The reference calls forward_vace(x, vace_context, seq_len,
+    kwargs) and passes kwargs['hints'] / kwargs['context_scale'] to every block (magcache_generate.py:544-549)."""
+
+    def __init__(self, vace_layers=None, vace_in_dim=None, **kw):
+        kw = dict(kw)
+        kw.pop("model_type", None)
+        super().__init__(model_type="t2v", **kw)
+        self.model_type = "vace"
+        self.vace_layers = list(range(0, self.num_layers, 2)) if vace_layers is None else list(vace_layers)
+        self.vace_in_dim = self.in_dim if vace_in_dim is None else vace_in_dim
+        assert 0 in self.vace_layers
+        mapping = {l: n for n, l in enumerate(self.vace_layers)}
+        for i, b in enumerate(self.blocks):
+            b.block_id = mapping.get(i)
+            b.forward = _hinted_forward.__get__(b)
+        self.vace_blocks = nn.ModuleList()
+        for l in self.vace_layers:
+            vb = WanAttentionBlock(self.dim, self.ffn_dim, self.num_heads, True, True, self.eps)
+            vb.block_id = l
+            if l == 0:
+                vb.before_proj = nn.Linear(self.dim, self.dim)
+            vb.after_proj = nn.Linear(self.dim, self.dim)
+            self.vace_blocks.append(vb)
+        self.vace_patch_embedding = nn.Conv3d(self.vace_in_dim, self.dim, kernel_size=self.patch_size, stride=self.patch_size)
+
+    def forward_vace(self, x, vace_context, seq_len, kwargs):
+        c = [self.vace_patch_embedding(u.unsqueeze(0)).flatten(2).transpose(1, 2) for u in vace_context]
+        c = torch.cat([torch.cat([u, u.new_zeros(1, seq_len - u.size(1), u.size(2))], dim=1) for u in c])
+        hints = []
+        for vb in self.vace_blocks:
+            if vb.block_id == 0:
+                c = vb.before_proj(c) + x
+            c = WanAttentionBlock.forward(vb, c, **kwargs)
+            hints.append(vb.after_proj(c))
+        return hints
+
+    def forward(self, x, t, vace_context, context, seq_len, vace_context_scale=1.0, autocast=True):
+        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else nullcontext()
+        with torch.no_grad(), ctx:
+            x, e, kwargs = self.embed(x, t, context, seq_len)
+            kwargs["hints"] = self.forward_vace(x, vace_context, seq_len, kwargs)
+            kwargs["context_scale"] = vace_context_scale
+            for block in self.blocks:
+                x = block(x, **kwargs)
+            x = self.head(x, e)
+            x = self.unpatchify(x, kwargs["grid_sizes"])
+        return [u.float() for u in x]
+
+
+def _hinted_forward(self, x, hints=None, context_scale=1.0, **kwargs):
+    # upstream BaseWanAttentionBlock.forward
+    x = WanAttentionBlock.forward(self, x, **kwargs)
+    if hints is not None and self.block_id is not None:
+        x = x + hints[self.block_id] * context_scale
+    return x
 
 
 WAN_T2V_1_3B = dict(dim=1536, ffn_dim=8960, freq_dim=256, num_heads=12, num_layers=30, text_len=512, in_dim=16,

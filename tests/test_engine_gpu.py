@@ -146,6 +146,64 @@ def test_wan21_i2v_forward_and_magcache_run_vs_reference_golden(golden_dir):
     assert cls.cnt == 0
 
 
+def test_wan21_vace_forward_and_magcache_run_vs_reference_golden(golden_dir):
+    """Wan2.1 VACE (control blocks on vace_patch_embedding(vace_context), before/after_proj, hints added to the main
+    layers with vace_context_scale).  (1) forward vs the oracle incl. a geometry whose LAST main layer carries a hint
+    (unfused residual capture); (2) the MagCache CFG loop through magcache_vace_forward vs the golden produced by the
+    reference's own magcache_vace_forward."""
+    g = np.load(os.path.join(golden_dir, "wan_vace_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    grid = (meta["F"], meta["H"], meta["W"])
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    lat, vctx = torch.from_numpy(g["latent0"]), torch.from_numpy(g["vace_context"])
+    ctx, ctxn = torch.from_numpy(g["ctx"]), torch.from_numpy(g["ctx_null"])
+    t = torch.tensor([float(g["timesteps"][0])])
+    for nl, layers in ((meta["cfg"]["num_layers"], meta["vace"]["vace_layers"]), (3, [0, 2])):
+        cfg = dict(meta["cfg"], num_layers=nl)
+        vace = dict(vace_layers=layers, vace_in_dim=96)
+        oracle = W.init_synthetic_(W.VaceWanModel(**cfg, **vace), seed=meta["weight_seed"], std=meta["weight_std"])
+        cls = type(f"WanVaceHIP{nl}", (M.WanModelHIP,), {"forward": M.vace_plain_forward})
+        m = cls(dict(cfg, **vace), grid, device=DEV, calibration=False)
+        m.load_state_dict(oracle.state_dict())
+        ref_ac = oracle.forward([lat], t, [vctx], [ctx], L, vace_context_scale=meta["scale"], autocast=True)[0]
+        oracle.set_fp32_attention(True)
+        ref_32 = oracle.forward([lat], t, [vctx], [ctx], L, vace_context_scale=meta["scale"], autocast=False)[0]
+        oracle.set_fp32_attention(False)
+        got = m([lat.to(DEV)], t=t.to(DEV), vace_context=[vctx.to(DEV)], context=[ctx.to(DEV)], seq_len=L,
+                vace_context_scale=meta["scale"])[0]
+        e_hip, e_ac = rel_l2(got, ref_32), rel_l2(ref_ac, ref_32)
+        assert e_hip < 2 * e_ac + 1e-3, (nl, e_hip, e_ac)
+        assert rel_l2(got, ref_ac) < 2e-2
+        # the control stream matters, and so does its scale
+        other = m([lat.to(DEV)], t=t.to(DEV), vace_context=[(vctx * 0.3).to(DEV)], context=[ctx.to(DEV)], seq_len=L,
+                  vace_context_scale=meta["scale"])[0]
+        assert rel_l2(other, got) > 1e-2
+        other = m([lat.to(DEV)], t=t.to(DEV), vace_context=[vctx.to(DEV)], context=[ctx.to(DEV)], seq_len=L,
+                  vace_context_scale=0.0)[0]
+        assert rel_l2(other, got) > 1e-2
+    # (2) MagCache loop on the golden geometry (m is the 3-layer model now: rebuild the golden one)
+    cfg = dict(meta["cfg"], **meta["vace"])
+    oracle = W.init_synthetic_(W.VaceWanModel(**meta["cfg"], **meta["vace"]), seed=meta["weight_seed"], std=meta["weight_std"])
+    cls = type("WanVaceHIPLoop", (M.WanModelHIP,), {})
+    m = cls(cfg, grid, device=DEV, calibration=False)
+    m.load_state_dict(oracle.state_dict())
+    steps = meta["steps"]
+    M.init_magcache(m, steps, meta["thresh"], meta["K"], meta["R"], mag_ratios=TABLES[meta["table"]])
+    cls.forward = M.magcache_vace_forward                                      # :1127
+    x = lat.to(DEV).clone()
+    sig, errs = g["sigmas"], []
+    for i in range(steps):
+        tt = torch.tensor([float(g["timesteps"][i])], device=DEV)
+        kw = dict(t=tt, vace_context=[vctx.to(DEV)], seq_len=L, vace_context_scale=meta["scale"])
+        ec = m([x], context=[ctx.to(DEV)], **kw)[0]
+        eu = m([x], context=[ctxn.to(DEV)], **kw)[0]
+        errs += [rel_l2(ec, g["outs"][2 * i]), rel_l2(eu, g["outs"][2 * i + 1])]
+        x = x + float(sig[i + 1] - sig[i]) * (eu + meta["guide"] * (ec - eu))
+    assert max(errs) < 3e-2, errs
+    assert rel_l2(x, g["final_latent"]) < 2e-2
+    assert cls.cnt == 0
+
+
 @pytest.mark.parametrize("solver", ["unipc", "dpm++"])
 def test_sampler_multistep_solvers_run_on_engine(golden, hip_model, solver):
     """the upstream default solvers around the MagCache-wrapped engine: finite result, same skip schedule

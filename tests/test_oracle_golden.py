@@ -150,6 +150,31 @@ def test_i2v_magcache_forward_matches_reference_run(golden_dir):
     np.testing.assert_allclose(x.numpy(), g["final_latent"], rtol=5e-3, atol=5e-3)
 
 
+def test_vace_magcache_forward_matches_reference_run(golden_dir):
+    """Wan2.1 VACE: oracle VaceWanModel (control blocks, before/after_proj, hints) under the oracle MagCache loop == the
+    reference's magcache_vace_forward around the same model."""
+    g = np.load(os.path.join(golden_dir, "wan_vace_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    model = W.init_synthetic_(W.VaceWanModel(**meta["cfg"], **meta["vace"]), seed=meta["weight_seed"], std=meta["weight_std"])
+    steps = meta["steps"]
+    mc = MR.MagCacheWan(model, steps * 2, meta["thresh"], meta["K"], meta["R"],
+                        MR.interp_cfg_table(TABLES[meta["table"]], steps), autocast=True)
+    x = torch.from_numpy(g["latent0"]).clone()
+    kw = dict(vace_context=[torch.from_numpy(g["vace_context"])], vace_context_scale=meta["scale"])
+    ctx, ctxn = torch.from_numpy(g["ctx"]), torch.from_numpy(g["ctx_null"])
+    sig, ts = g["sigmas"], g["timesteps"]
+    seq_len = meta["F"] * (meta["H"] // 2) * (meta["W"] // 2)
+    for i in range(steps):
+        t = torch.tensor([float(ts[i])])
+        ec = mc.forward([x], t, [ctx], seq_len, **kw)[0]
+        eu = mc.forward([x], t, [ctxn], seq_len, **kw)[0]
+        np.testing.assert_allclose(ec.numpy(), g["outs"][2 * i], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(eu.numpy(), g["outs"][2 * i + 1], rtol=2e-3, atol=2e-3)
+        x, _ = MR.cfg_euler_step(x, ec, eu, meta["guide"], float(sig[i + 1] - sig[i]))
+    assert [int(s) for _, s in mc.trace] == g["skipped"].tolist() and g["skipped"].sum() > 0
+    np.testing.assert_allclose(x.numpy(), g["final_latent"], rtol=5e-3, atol=5e-3)
+
+
 def test_calibration_matches_reference_run(golden_run, golden_dir):
     g, meta, model = golden_run
     want = json.load(open(os.path.join(golden_dir, "wan_calibration_golden.json")))
