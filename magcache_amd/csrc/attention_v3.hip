@@ -108,16 +108,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
   // one 1 KiB piece.  saddr form: uniform 64-bit base + 32-bit lane offset; M0 = LDS byte address of
   // the piece; s_nop covers the SALU-write-M0 -> LDS-DMA hazard; M0 is restored for the compiler.
   auto dma1 = [&](const bf16_t* base, uint32_t off, uint32_t lds) {
-    uint32_t keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, %2"
+        :
         : "v"(off), "s"(lds), "s"(base)
-        : "memory");
+        : "memory", "m0");
   };
   // Tile cursors (all scalar): the DMA streams run ahead of the compute, each with its
   // own position.  Past the last tile a cursor stays on it: the reload lands in a dead slot and
@@ -340,15 +337,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
   MC_PIN();
 
   // One iteration: S_cur = S(t) (row maximum in mx) -> P(t), O += V(t)^T P(t); S_nxt = S(t+1).
-#define MC_ATTN_BODY(S_cur, S_nxt)                                                                  \
+#define MC_ATTN_BODY_(S_cur, S_nxt, SK, SV, ADV)                                                                \
   {                                                                                                  \
     /* K(t+1), V(t) were issued two iterations ago, K(t+2) early in the last one: only the two V   */ \
     /* pieces issued last may still be in flight                                                    */ \
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                 \
     asm volatile("s_barrier" ::: "memory");                                                          \
     /* the slots freed by iteration t-1 are refilled inside the phases: K(t) -> K(t+3), V(t-1) -> V(t+2) */ \
-    const uint32_t kdst_ = dma_lds + ((slot_k == 0) ? NST - 1 : slot_k - 1) * TILE_BYTES;            \
-    const uint32_t vdst_ = dma_lds + V_RING + ((slot_v == 0) ? NST - 1 : slot_v - 1) * TILE_BYTES;   \
+    const uint32_t kdst_ = dma_lds + (((SK) == 0) ? NST - 1 : (SK) - 1) * TILE_BYTES;                \
+    const uint32_t vdst_ = dma_lds + V_RING + (((SV) == 0) ? NST - 1 : (SV) - 1) * TILE_BYTES;     \
     const bf16_t* kptr_ = ck.ptr;  /* the cursors move here, outside the pinned region (branches) */  \
     const bf16_t* vptr_ = cv.ptr;                                                                    \
     advance(ck, p.ldk, p.k_shard_stride);                                                            \
@@ -357,16 +354,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
     decide(S_cur);                                                                                   \
     MC_PIN();                                                                                        \
     { /* ---- phase 1: fragment sets rotate x, y, z, w; x, y, z arrive pre-read */                      \
-      const char* st_ = smem + slot_k * TILE_BYTES;                                                  \
-      const char* stv_ = smem + slot_v * TILE_BYTES;                                                 \
+      const char* st_ = smem + (SK) * TILE_BYTES;                                                    \
+      const char* stv_ = smem + (SV) * TILE_BYTES;                                                   \
       MC_QK_STEP(S_cur, S_nxt, 0, kx0, kx1, kw0, kw1) MC_QK_STEP(S_cur, S_nxt, 1, ky0, ky1, kx0, kx1)  \
       MC_QK_STEP(S_cur, S_nxt, 2, kz0, kz1, ky0, ky1) MC_QK_STEP(S_cur, S_nxt, 3, kw0, kw1, kz0, kz1)  \
       MC_QK_STEP(S_cur, S_nxt, 4, kx0, kx1, kw0, kw1) MC_QK_STEP(S_cur, S_nxt, 5, ky0, ky1, kx0, kx1)  \
       MC_QK_STEP(S_cur, S_nxt, 6, kz0, kz1, ky0, ky1) MC_QK_STEP(S_cur, S_nxt, 7, kw0, kw1, kz0, kz1) \
     }                                                                                                \
     { /* ---- phase 2 */                                                                             \
-      const char* st_ = smem + slot_v * TILE_BYTES;                                                  \
-      const char* stk_ = smem + ((slot_k + 1 == NST) ? 0 : slot_k + 1) * TILE_BYTES; /* K(t+2) */    \
+      const char* st_ = smem + (SV) * TILE_BYTES;                                                    \
+      const char* stk_ = smem + (((SK) + 1 == NST) ? 0 : (SK) + 1) * TILE_BYTES; /* K(t+2) */        \
       float rm_[4];                                                                                  \
       MC_PV_STEP(S_cur, S_nxt, 0, va_, ve_) MC_PV_STEP(S_cur, S_nxt, 1, vb_, va_)  \
       MC_PV_STEP(S_cur, S_nxt, 2, vc_, vb_) MC_PV_STEP(S_cur, S_nxt, 3, vd_, vc_)  \
@@ -382,20 +379,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
     /* exponentials stay live across the whole iteration */                                          \
     asm volatile("" : "+v"(l_run));                                                                  \
     MC_PIN();                                                                                        \
-    slot_k = (slot_k + 1 == NST) ? 0 : slot_k + 1;                                                   \
-    slot_v = (slot_v + 1 == NST) ? 0 : slot_v + 1;                                                   \
+    ADV                                                                                              \
   }
+  // generic form: ring slots in registers (remainder iterations)
+#define MC_SLOT_ADV slot_k = (slot_k + 1 == NST) ? 0 : slot_k + 1; slot_v = (slot_v + 1 == NST) ? 0 : slot_v + 1;
+#define MC_ATTN_BODY(S_cur, S_nxt) MC_ATTN_BODY_(S_cur, S_nxt, slot_k, slot_v, MC_SLOT_ADV)
+  // static form: ring slots are compile-time constants, so every LDS address is base VGPR + immediate offset
+#define MC_ATTN_BODY_S(S_cur, S_nxt, SK, SV) MC_ATTN_BODY_(S_cur, S_nxt, SK, SV, )
 
+  // Main loop: 6 iterations per trip (S buffers alternate with period 2, ring slots with period 3), all slots
+  // static; on entry slot_k == 1 and slot_v == 0, and 6 iterations later again.  Then the remainder (0..5
+  // iterations) with the slots in registers.
   int t = 0;
-  if ((ntiles - 1) & 1) {  // odd number of full iterations: peel one, so the pair loop ends on `s`
+  const int nfull = ntiles - 1;
+  for (; t + 6 <= nfull; t += 6) {
+    MC_ATTN_BODY_S(s, sn, 1, 0)
+    MC_ATTN_BODY_S(sn, s, 2, 1)
+    MC_ATTN_BODY_S(s, sn, 0, 2)
+    MC_ATTN_BODY_S(sn, s, 1, 0)
+    MC_ATTN_BODY_S(s, sn, 2, 1)
+    MC_ATTN_BODY_S(sn, s, 0, 2)
+  }
+  for (; t + 2 <= nfull; t += 2) {
+    MC_ATTN_BODY(s, sn)
+    MC_ATTN_BODY(sn, s)
+  }
+  if (t < nfull) {
     MC_ATTN_BODY(s, sn)
     s[0] = sn[0];
     s[1] = sn[1];
-    t = 1;
-  }
-  for (; t < ntiles - 1; t += 2) {
-    MC_ATTN_BODY(s, sn)
-    MC_ATTN_BODY(sn, s)
   }
   // ---- last tile: no next S
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -420,6 +432,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
     }
   }
 #undef MC_ATTN_BODY
+#undef MC_ATTN_BODY_S
+#undef MC_ATTN_BODY_
+#undef MC_SLOT_ADV
 #undef MC_QK_STEP
 #undef MC_PV_STEP
 #undef MC_ROWMAX_PART
