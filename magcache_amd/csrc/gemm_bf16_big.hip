@@ -113,8 +113,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   int fo[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) fo[ks] = l31 * 128 + ((((2 * ks + half) ^ sw)) << 4);
-  const int a_base = wr * (64 * 128);  // + ms*32*128
-  const int w_base = wc * (32 * 128);
+  // per-wave bases folded into the lane offsets: every ds_read below is base VGPR + immediate
+  // (one set per stage: the second stage starts at 64 KiB, beyond the 16-bit DS offset field)
+  int foa[2][4], fow[2][4];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      foa[st][ks] = fo[ks] + wr * (64 * 128) + st * STAGE_BYTES;  // + ms*32*128
+      fow[st][ks] = fo[ks] + wc * (32 * 128) + st * STAGE_BYTES;
+    }
+  }
 
   f32x16 acc[2][2][2];  // [m half][ms][n half]
 #pragma unroll
@@ -136,16 +145,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   // one 1 KiB piece: M0 = LDS byte address (wave-uniform), saddr form: 64-bit uniform base + 32-bit
   // lane offset; s_nop covers the SALU-write-M0 -> LDS-DMA hazard; M0 is restored for the compiler.
   auto dma1 = [&](const bf16_t* base, uint32_t off, uint32_t lds) {
-    uint32_t keep;
+    // M0 is clobbered, not saved: nothing the compiler emits in this kernel reads it
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, %2"
+        :
         : "v"(off), "s"(lds), "s"(base)
-        : "memory");
+        : "memory", "m0");
   };
   // piece j (0/1) of half h of K tile kt into stage st (= kt & 1)
   auto dma_a1 = [&](int kt, int st, int h, int j) {
@@ -159,10 +166,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   // fragment i = 4*ms + ks of this wave's A half h / fragment ks of its W half h
   auto read_a1 = [&](int st, int h, int i, Frag4 (&f)[2]) {
     f[i >> 2].v[i & 3] =
-        *(const bf16x8*)(smem + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0) + a_base + (i >> 2) * (32 * 128) + fo[i & 3]);
+        *(const bf16x8*)(smem + (h ? OFF_AM1 : OFF_AM0) + (i >> 2) * (32 * 128) + foa[st][i & 3]);
   };
   auto read_w1 = [&](int st, int h, int ks, Frag4& f) {
-    f.v[ks] = *(const bf16x8*)(smem + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0) + w_base + fo[ks]);
+    f.v[ks] = *(const bf16x8*)(smem + (h ? OFF_WN1 : OFF_WN0) + fow[st][ks]);
   };
   auto read_a = [&](int st, int h, Frag4 (&f)[2]) {  // prologue
 #pragma unroll
