@@ -26,6 +26,8 @@
 //    between MFMAs; one counted s_waitcnt vmcnt(4) + s_barrier per tile.
 //  * the VALU work is written between the MFMAs it should hide behind and pinned with
 //    sched_barrier(0): the compiler otherwise sinks the softmax out of the MFMA shadow.
+// the LDS-DMA asm below names m0 in its clobber list on purpose (reserved register: the compiler only warns)
+#pragma clang diagnostic ignored "-Winline-asm"
 #include "common.h"
 #include "ops.h"
 

@@ -34,6 +34,8 @@
 //     oldest half must have landed.  The data is read one interval AFTER the wait + barrier that
 //     retires it (every wave waits for its own pieces, the barrier publishes them).
 //   - the last two K tiles use exact smaller counts (8,6,4,2 / 0).
+// the LDS-DMA asm below names m0 in its clobber list on purpose (reserved register: the compiler only warns)
+#pragma clang diagnostic ignored "-Winline-asm"
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "ops.h"

@@ -298,3 +298,86 @@ def test_wan22_timesteps_and_split():
     assert ts.dtype == np.int64 and len(ts) == 40 and len(sig) == 41 and sig[-1] == 0.0 and ts[0] == 1000
     assert wan22.high_noise_steps(12.0, 40, 0.875) == int((ts >= 875).sum())
     assert wan22.WAN22_I2V_A14B["in_dim"] == 36 and wan22.WAN22_T2V_A14B["dim"] == 5120
+
+
+# ----------------------------------------------------------------------------- FLUX / HunyuanVideo / VACE shims
+class FakeMMDiTEngine:
+    def __init__(self):
+        self.calls = []
+
+    def reset(self):
+        self.calls.append("reset")
+
+    def residual(self):
+        return "residual"
+
+    def calib_stats(self):
+        return 1.25, 0.5, 0.125
+
+
+def test_flux_and_hunyuan_shims_follow_the_reference_rules(golden_dir, capsys):
+    """mmdit.flux_magcache_forward / hunyuan_magcache_forward: the scalar-state rules of MagCache4FLUX/magcache_flux.py
+    :333-344 (retention int(R n + 0.5), `<=`, step 11 of 28 never skipped) and MagCache4HunyuanVideo/
+    magcache_sample_video.py:91-102 reproduce the schedules obtained by exec'ing the reference's own lines."""
+    from magcache_amd import mmdit as MM
+    g = json.load(open(os.path.join(golden_dir, "rule_schedules.json")))
+    seen = set()
+    for key, want in g.items():
+        d = parse_key(key)
+        if d["variant"] not in ("flux", "hunyuan"):
+            continue
+        seen.add(d["variant"])
+        base = MM.FluxTransformer2DModelHIP if d["variant"] == "flux" else MM.HYVideoDiffusionTransformerHIP
+        cls = type("Patched" + base.__name__, (base,), {})
+        m = cls.__new__(cls)
+        m.engine, modes = FakeMMDiTEngine(), []
+        cls._run = lambda self, *a: (modes.append(a[-1]) or "out")
+        if d["variant"] == "flux":
+            MM.init_flux_magcache(m, d["steps"], d["thresh"], d["K"], d["R"])
+            assert cls.forward is MM.flux_magcache_forward and cls.previous_residual is None
+            call = lambda: m(hidden_states=None, return_dict=False)
+            want_out = ("out",)
+        else:
+            MM.init_hunyuan_magcache(m, d["steps"], d["thresh"], d["K"], d["R"], video_height=720 if "720" in d["table"] else 544)
+            assert cls.forward is MM.hunyuan_magcache_forward and cls.residual_cache is None
+            call = lambda: m(None, None, return_dict=False)
+            want_out = "out"
+        assert len(cls.mag_ratios) == d["steps"] == cls.num_steps
+        for i in range(d["steps"]):
+            assert m.cnt == i
+            assert call() == want_out
+        assert [int(mo == _lib.MC_MODE_SKIP) for mo in modes] == want, key
+        assert m.cnt == 0 and m.accumulated_steps == 0 and m.accumulated_err == 0
+    assert seen == {"flux", "hunyuan"}
+    # calibration shims: statistics from the engine, rounded to 5 decimals like the reference
+    for base, init in ((MM.FluxTransformer2DModelHIP, MM.init_flux_magcache), (MM.HYVideoDiffusionTransformerHIP, MM.init_hunyuan_magcache)):
+        cls = type("Calib" + base.__name__, (base,), {})
+        m = cls.__new__(cls)
+        m.engine = FakeMMDiTEngine()
+        cls._run = lambda self, *a: "out"
+        init(m, 4, calibration=True)
+        for i in range(3):
+            m(hidden_states=None, return_dict=False) if base is MM.FluxTransformer2DModelHIP else m(None, None)
+        assert m.norm_ratio == [1.25, 1.25] and m.norm_std == [0.5, 0.5] and m.cos_dis == [0.125, 0.125]
+    capsys.readouterr()
+
+
+def test_vace_shim_schedule_matches_wan21_rule(golden_dir):
+    """magcache_vace_forward carries the Wan2.1 rule (reference :521-536) and hands vace_context / scale to the engine"""
+    g = json.load(open(os.path.join(golden_dir, "rule_schedules.json")))
+    key = next(k for k in g if "wan2.1_vace_1.3B" in k and "K2" in k)
+    d = parse_key(key)
+    m = make_shim()
+    cls = m.__class__
+    seen = []
+    cls._run = lambda self, x, t, ctx, branch, mode, vace=None: (self.trace.append((branch, mode)), seen.append(vace), ["out"])[2]
+    cls._check_inputs = lambda self, *a: None
+    m.latent_grid, m.cfg = (1, 2, 2), {"vace_in_dim": 96}
+    M.init_magcache(m, d["steps"], d["thresh"], d["K"], d["R"], mag_ratios=TABLES[d["table"]])
+    cls.forward = M.magcache_vace_forward
+    import torch
+    vc = [torch.zeros(96, 1, 2, 2)]
+    for i in range(2 * d["steps"]):
+        assert m(["x"], t=0, vace_context=vc, context=["c"], seq_len=4, vace_context_scale=0.5) == ["out"]
+    assert [int(mode == _lib.MC_MODE_SKIP) for _, mode in m.trace] == g[key]
+    assert all(v[0] is vc and v[1] == 0.5 for v in seen) and m.cnt == 0
