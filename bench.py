@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernels", action="store_true")
     ap.add_argument("--no_nocache", action="store_true", help="skip the second (cache off) timed region")
+    ap.add_argument("--fp8_linear", action="store_true",
+                    help="OPTIONAL precision mode, never the headline: QKV / FFN Linears on the fp8 e4m3 MFMA path")
     ap.add_argument("--no_cfg_parallel", action="store_true",
                     help="N > 1: shard the sequence over all N ranks instead of CFG branches x N/2")
     args = ap.parse_args()
@@ -177,7 +179,7 @@ def main():
     from magcache_amd.mag_ratios import TABLES
     from magcache_amd.sampler import sample
 
-    cfg = WAN_T2V_1_3B
+    cfg = dict(WAN_T2V_1_3B, fp8_linear=True) if args.fp8_linear else WAN_T2V_1_3B
     model = M.WanModelHIP(cfg, GRID, device=device, calibration=False,
                           sp_rank=layout.sp_rank if layout else 0, sp_size=layout.sp_size if layout else 1,
                           sp_group=layout.sp_group if layout else None)
@@ -231,7 +233,9 @@ def main():
             "metric": "denoising steps/sec (MagCache on), Wan2.1-T2V-1.3B 480p 81f",
             "value": args.steps / t_mc, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": t_mc / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16 + fp8(e4m3) QKV/FFN Linears (reduced precision: NOT the headline)" if args.fp8_linear else "bf16",
+            "data": "synthetic",
             "config": {"workload": "Wan2.1-T2V-1.3B 832x480 81 frames: latent 16x21x60x104, 32760 tokens, "
                                    "30 layers d=1536 12 heads ffn=8960; cond+uncond per step, CFG 5.0, flow-Euler; "
                                    "synthetic latents/contexts, random-init weights",

@@ -64,6 +64,9 @@ typedef struct {
   int vace_layers;      /* 0: none.  > 0: Wan2.1 VACE -- number of control blocks (15 for 1.3B, 8 for 14B);           */
   int vace_stride;      /*   block i hints main layer i * vace_stride (2 / 5); upstream vace_layers                    */
   int vace_in_dim;      /*   channels of vace_context (96)                                                             */
+  int fp8_linear;       /* 1: the three large Linears of every block (QKV, FFN-1, FFN-2) run on the fp8 (OCP e4m3) MFMA
+                           path: weights quantised per output channel at mc_set_weight, activations per token on the
+                           fly; a speed / quality option (~3 % relative error per GEMM), never the default */
 } mc_config;
 
 const char* mc_last_error(void);
@@ -167,6 +170,13 @@ mc_status mc_op_gemm_bf16(const void* A_dev, long lda, const void* W_dev, long l
                           int N, int K, int epi, void* Cb_dev, long ldc, float* X_dev, long ldx,
                           const float* gate_dev, const void* X0_dev, long ldx0, float* R_dev, long ldr,
                           void* X0out_dev, long ldx0out, int m_valid, mc_stream stream);
+/* fp8 path (OCP e4m3, v_mfma_f32_32x32x64_f8f6f4): row-wise quantisation q = e4m3(x / s), s = max|row| / 448, and
+ * C = (A_q W_q^T) * a_scale[m] * w_scale[n] + bias with the bf16 / gelu / residual-gate / fp32 epilogues */
+mc_status mc_op_quantize_rows_fp8(const void* x_dev, mc_dtype dtype, long ldx, int M, int K, void* q_dev, long ldq,
+                                  float* scale_dev, mc_stream stream);
+mc_status mc_op_gemm_fp8(const void* A_q_dev, long lda, const float* a_scale_dev, const void* W_q_dev, long ldw,
+                         const float* w_scale_dev, const float* bias_dev, int M, int N, int K, int epi, void* Cb_dev,
+                         long ldc, float* X_dev, long ldx, const float* gate_dev, mc_stream stream);
 /* attention: head_dim 128; Q rows Lq_pad (multiple of 256); KV = n_shards shards of shard_rows rows
  * (multiple of 64), the first shard_valid of each valid */
 mc_status mc_op_attention(const void* Q_dev, long ldq, const void* K_dev, long ldk, long k_shard_stride,

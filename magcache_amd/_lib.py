@@ -21,7 +21,7 @@ class McConfig(C.Structure):
                                        "text_dim", "text_len", "latent_f", "latent_h", "latent_w")] + \
                [("eps", C.c_float)] + \
                [(n, C.c_int) for n in ("sp_rank", "sp_size", "n_branches", "calibration", "clip_dim", "vace_layers",
-                                         "vace_stride", "vace_in_dim")]
+                                         "vace_stride", "vace_in_dim", "fp8_linear")]
 
 
 class MagCacheHipError(RuntimeError):
@@ -66,6 +66,8 @@ SIGNATURES = {
     "mc_op_gemm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l,
                              _i, _vp]),
     "mc_op_attention": (_i, [_vp, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
+    "mc_op_quantize_rows_fp8": (_i, [_vp, _i, _l, _i, _i, _vp, _l, _vp, _vp]),
+    "mc_op_gemm_fp8": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
     "mc_op_attention_partial": (_i, [_vp, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "mc_op_ln_modulate": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _f, _vp, _l, _vp, _l, _i, _i, _vp]),
     "mc_op_rmsnorm_rope": (_i, [_vp, _l, _vp, _f, _vp, _i, _i, _i, _vp]),

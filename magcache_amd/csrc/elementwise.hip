@@ -219,6 +219,46 @@ __global__ void rope_table_from_cos_sin_kernel(const float* __restrict__ cosv, c
   cs[2 * i + 1] = sinv[(size_t)r * ld + 2 * p];
 }
 
+// ------------------------------------------------------------------ row-wise fp8 (OCP e4m3) quantisation
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __restrict__ x,
+                                                                const float* __restrict__ xf, long ldx, int M, int K,
+                                                                uint8_t* __restrict__ q, long ldq,
+                                                                float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float amax = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    f32x4 v;
+    if (xf) {
+      v = *(const f32x4*)(xf + (size_t)row * ldx + k);
+    } else {
+      const u32x2 b = *(const u32x2*)(x + (size_t)row * ldx + k);
+      v = f32x4{__uint_as_float(b[0] << 16), __uint_as_float(b[0] & 0xffff0000u), __uint_as_float(b[1] << 16),
+                __uint_as_float(b[1] & 0xffff0000u)};
+    }
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float s = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / s;
+  if (lane == 0) scale[row] = s;
+  for (int k = lane * 4; k < K; k += 256) {
+    f32x4 v;
+    if (xf) {
+      v = *(const f32x4*)(xf + (size_t)row * ldx + k);
+    } else {
+      const u32x2 b = *(const u32x2*)(x + (size_t)row * ldx + k);
+      v = f32x4{__uint_as_float(b[0] << 16), __uint_as_float(b[0] & 0xffff0000u), __uint_as_float(b[1] << 16),
+                __uint_as_float(b[1] & 0xffff0000u)};
+    }
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w, true);
+    *(int*)(q + (size_t)row * ldq + k) = w;
+  }
+}
+
 // ------------------------------------------------------------------ patch im2col / unpatchify, patch (1,2,2)
 __global__ void patchify_kernel(const float* __restrict__ lat, int C, int F, int H, int W, int tok0, int n_tok,
                                 int n_rows, bf16_t* __restrict__ out, long ldo) {
@@ -483,6 +523,14 @@ hipError_t launch_rope_table_from_cos_sin(const float* cosv, const float* sinv, 
   if (n_rows <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(rope_table_from_cos_sin_kernel, dim3(((long)n_rows * 64 + 255) / 256), dim3(256), 0, stream, cosv,
                      sinv, ld, n_rows, cs);
+  return hipGetLastError();
+}
+
+hipError_t launch_quantize_rows_fp8(const bf16_t* x, const float* x_f32, long ldx, int M, int K, uint8_t* q, long ldq,
+                                    float* scale, hipStream_t stream) {
+  if (M <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0 || (ldq % 4) != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, x_f32, ldx, M, K, q, ldq,
+                     scale);
   return hipGetLastError();
 }
 

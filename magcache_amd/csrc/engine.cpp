@@ -46,6 +46,10 @@ struct Slot {  // one named parameter
   size_t numel = 0;
   size_t row_off = 0;  // for fused destinations (q/k/v -> wqkv): element offset
   bool loaded = false;
+  // fp8 weight path: after the bf16 store the same rows are quantised (per output channel) into q8 / q8_scale
+  uint8_t* q8 = nullptr;
+  float* q8_scale = nullptr;
+  size_t q8_k = 0;  // row length (in_features)
 };
 
 struct Layer {
@@ -54,6 +58,9 @@ struct Layer {
   float *nq, *nk, *cnq, *cnk, *n3w, *n3b, *mod;
   bf16_t* wckv_img = nullptr;  // I2V: [k_img ; v_img]
   float *bckv_img = nullptr, *cnk_img = nullptr;
+  // fp8_linear: e4m3 copies of the three large Linears + per-output-channel scales
+  uint8_t *q_wqkv = nullptr, *q_w1 = nullptr, *q_w2 = nullptr;
+  float *s_wqkv = nullptr, *s_w1 = nullptr, *s_w2 = nullptr;
 };
 
 struct Buf {
@@ -212,6 +219,8 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (c.vace_layers < 0 || (c.vace_layers > 0 && (c.vace_stride <= 0 || c.vace_in_dim <= 0 ||
                                                    (c.vace_layers - 1) * c.vace_stride >= c.num_layers)))
     return fail(MC_EINVAL, "bad VACE geometry: %d blocks, stride %d, in_dim %d", c.vace_layers, c.vace_stride, c.vace_in_dim);
+  if (c.fp8_linear && ((c.dim % 256) || (c.ffn_dim % 256) || c.dim < 512 || c.ffn_dim < 512))
+    return fail(MC_EINVAL, "fp8_linear needs dim and ffn_dim to be multiples of 256 and >= 512");
   if (c.vace_layers > 0 && c.sp_size > 1) return fail(MC_EINVAL, "VACE is single-GPU in this engine (sp_size must be 1)");
 
   mc_engine* e = new mc_engine();
@@ -274,6 +283,20 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_slot(e, p + "ffn.2.weight", l.w2, MC_BF16, d * ffn);
     add_slot(e, p + "ffn.2.bias", l.b2, MC_F32, d);
     add_slot(e, p + "modulation", l.mod, MC_F32, 6 * d);
+    if (c.fp8_linear) {
+      ALLOC(l.q_wqkv, 3 * d * d); ALLOC(l.s_wqkv, 3 * d);
+      ALLOC(l.q_w1, ffn * d); ALLOC(l.s_w1, ffn);
+      ALLOC(l.q_w2, d * ffn); ALLOC(l.s_w2, d);
+      const char* qkv_names[3] = {"self_attn.q.weight", "self_attn.k.weight", "self_attn.v.weight"};
+      for (int j = 0; j < 3; ++j) {
+        Slot& sl = e->slots[p + qkv_names[j]];
+        sl.q8 = l.q_wqkv; sl.q8_scale = l.s_wqkv; sl.q8_k = d;
+      }
+      Slot& s1 = e->slots[p + "ffn.0.weight"];
+      s1.q8 = l.q_w1; s1.q8_scale = l.s_w1; s1.q8_k = d;
+      Slot& s2 = e->slots[p + "ffn.2.weight"];
+      s2.q8 = l.q_w2; s2.q8_scale = l.s_w2; s2.q8_k = ffn;
+    }
     if (c.clip_dim > 0) {
       ALLOC(l.wckv_img, 2 * d * d); ALLOC(l.bckv_img, 2 * d); ALLOC(l.cnk_img, d);
       add_slot(e, p + "cross_attn.k_img.weight", l.wckv_img, MC_BF16, d * d, 0);
@@ -367,6 +390,10 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   add_buf(e, cur, "ckv", (size_t)e->ctx_rows * 2 * d * 2);
   add_buf(e, cur, "temb", (size_t)(c.freq_dim + 2 * d + 6 * d) * 4);  // sinus | h1 | e | e0
   add_buf(e, cur, "emod", (size_t)(e->NL + e->NV) * 6 * d * 4);
+  if (c.fp8_linear) {
+    add_buf(e, cur, "aq", Lp * std::max(d, ffn));            // e4m3 activations of the current fp8 GEMM
+    add_buf(e, cur, "a_scale", Lp * 4);                      // their per-token scales
+  }
   if (e->NV > 0) {
     add_buf(e, cur, "xc", Lp * d * 4);                       // VACE control stream c (fp32 like x)
     add_buf(e, cur, "c0", Lp * d * 2);                       // vace_patch_embedding(vace_context), constant per video
@@ -465,6 +492,11 @@ mc_status mc_set_weight(mc_engine* e, const char* name, const void* src_dev, mc_
       HIP_TRY(mc::launch_cast_bf16((const float*)src_dev, dst, numel, stream));
     } else {
       HIP_TRY(hipMemcpyAsync(dst, src_dev, numel * 2, hipMemcpyDeviceToDevice, stream));
+    }
+    if (s.q8) {  // fp8 weight path: e4m3 copy of the rows just stored, one scale per output channel
+      const size_t rows = numel / s.q8_k, row0 = s.row_off / s.q8_k;
+      HIP_TRY(mc::launch_quantize_rows_fp8(dst, nullptr, (long)s.q8_k, (int)rows, (int)s.q8_k, s.q8 + s.row_off,
+                                           (long)s.q8_k, s.q8_scale + row0, stream));
     }
   }
   s.loaded = true;
@@ -616,6 +648,19 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
 }
 
 // LN + modulate -> q,k,v Linear -> RMSNorm(q), RMSNorm(k) -> RoPE(q,k)      (upstream WanSelfAttention)
+// fp8_linear: y = epilogue((quantise_rows(A) . Wq^T) * a_scale * w_scale + bias): per-token activation scales are
+// computed here (one pass over the bf16 rows), the weights were quantised per output channel at load time.
+static mc_status gemm_fp8_rows(mc_engine* e, const bf16_t* A, long lda, int M, int K, const uint8_t* Wq, const float* ws,
+                               mc::GemmParams p, int epi, hipStream_t s) {
+  uint8_t* aq = e->buf<uint8_t>("aq");
+  float* as = e->buf<float>("a_scale");
+  HIP_TRY(mc::launch_quantize_rows_fp8(A, nullptr, lda, M, K, aq, K, as, s));
+  p.A = (const bf16_t*)aq; p.lda = K; p.W = (const bf16_t*)Wq; p.ldw = K; p.K = K;
+  p.a_scale = as; p.w_scale = ws;
+  HIP_TRY(mc::launch_gemm_fp8(p, epi, s));
+  return MC_OK;
+}
+
 // l / em / x: the block's weights, its 6 modulation vectors and the residual stream it works on (the main stream
 // "x", or the VACE control stream "xc")
 static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float* x, hipStream_t s) {
@@ -626,7 +671,12 @@ static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float*
   if (e->P == 1) {
     mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    if (l.q_wqkv) {
+      mc_status st = gemm_fp8_rows(e, xn, d, Lp, d, l.q_wqkv, l.s_wqkv, p, mc::EPI_BF16, s);
+      if (st != MC_OK) return st;
+    } else {
+      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    }
     HIP_TRY(mc::launch_rmsnorm_rope(qkv, 3 * d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
     HIP_TRY(mc::launch_rmsnorm_rope(qkv + d, 3 * d, l.nk, e->cfg.eps, e->cs_table, 0, Lp, d, s));
   } else {
@@ -755,15 +805,29 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
   {
     mc::GemmParams p = gp(xn, d, l.w1, d, l.b1, Lp, ffn, d);
     p.Cb = h; p.ldc = ffn;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
+    if (l.q_w1) {
+      mc_status st = gemm_fp8_rows(e, xn, d, Lp, d, l.q_w1, l.s_w1, p, mc::EPI_GELU_BF16, s);
+      if (st != MC_OK) return st;
+    } else {
+      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
+    }
     mc::GemmParams q = gp(h, ffn, l.w2, ffn, l.b2, Lp, d, ffn);
     q.X = x; q.ldx = d; q.gate = em + 5 * d;
+    const bool f8 = l.q_w2 != nullptr;
+    auto ffn2 = [&](int epi) -> mc_status {
+      if (f8) return gemm_fp8_rows(e, h, ffn, Lp, ffn, l.q_w2, l.s_w2, q, epi, s);
+      HIP_TRY(mc::launch_gemm_bf16(q, epi, s));
+      return MC_OK;
+    };
     if (capture) {
       // MagCache residual capture fused into the last epilogue: residual = x_out - ori_x  (:299-301)
       const int dst = (mode == MC_MODE_CALIB) ? e->res_scratch : e->res_slot[branch];
       q.X0 = e->buf<bf16_t>("x0"); q.ldx0 = d;
       q.R = e->residual(dst); q.ldr = d;
-      HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_RESID_CAPTURE, s));
+      {
+        mc_status st = ffn2(mc::EPI_RESID_CAPTURE);
+        if (st != MC_OK) return st;
+      }
       if (mode == MC_MODE_CALIB) {
         if (!e->cfg.calibration) return fail(MC_ESTATE, "engine was created without calibration=1");
         if (e->have_res[branch]) {
@@ -778,7 +842,8 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
       }
       e->have_res[branch] = true;
     } else {
-      HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_RESID_GATE, s));
+      mc_status st = ffn2(mc::EPI_RESID_GATE);
+      if (st != MC_OK) return st;
     }
   }
   return MC_OK;
@@ -967,6 +1032,29 @@ mc_status mc_op_attention(const void* Q, long ldq, const void* K, long ldk, long
   a.n_shards = n_shards; a.scale = scale;
   hipError_t err = mc::launch_attention(a, (hipStream_t)s);
   if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "attention: unsupported shape");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_quantize_rows_fp8(const void* x, mc_dtype dtype, long ldx, int M, int K, void* q, long ldq, float* scale,
+                                  mc_stream s) {
+  hipError_t err = mc::launch_quantize_rows_fp8(dtype == MC_BF16 ? (const bf16_t*)x : nullptr,
+                                                dtype == MC_F32 ? (const float*)x : nullptr, ldx, M, K, (uint8_t*)q, ldq,
+                                                scale, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "quantize_rows_fp8: K, ldx, ldq must be multiples of 4");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_gemm_fp8(const void* A, long lda, const float* a_scale, const void* W, long ldw, const float* w_scale,
+                         const float* bias, int M, int N, int K, int epi, void* Cb, long ldc, float* X, long ldx,
+                         const float* gate, mc_stream s) {
+  mc::GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, M, N, K);
+  p.a_scale = a_scale; p.w_scale = w_scale;
+  p.Cb = (bf16_t*)Cb; p.ldc = ldc; p.X = X; p.ldx = ldx; p.gate = gate;
+  hipError_t err = mc::launch_gemm_fp8(p, epi, (hipStream_t)s);
+  if (err == hipErrorInvalidValue)
+    return fail(MC_EINVAL, "gemm_fp8: needs N %% 256 == 0, K %% 256 == 0, K >= 512, lda/ldw %% 16 == 0, both scale vectors");
   HIP_TRY(err);
   return MC_OK;
 }

@@ -50,6 +50,10 @@ constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // Am0 | Am1 | Wn0 | Wn1
 constexpr int OFF_AM0 = 0, OFF_AM1 = HALF_BYTES, OFF_WN0 = 2 * HALF_BYTES, OFF_WN1 = 3 * HALF_BYTES;
 constexpr int GROUP_M = 8;
+// E8M0 block scale 127 = 2^0 in all four bytes: the MX-scaled MFMA with unit scales
+#define MC_F8_UNIT_SCALE 0x7f7f7f7f
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 // end-of-interval wait: at most n LDS-DMA instructions of this wave still in flight.  (ds_reads need
 // no wait here: a region is re-filled two barriers after its last read, and every read has been
@@ -69,8 +73,15 @@ struct Frag4 {  // one 32-row block x 64 k = 4 MFMA operands
   bf16x8 v[4];
 };
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int tilesM, int tilesN) {
+// F8: the same pipeline on fp8 (OCP e4m3) operands.  A K tile is still 128 bytes per row (128 k instead of 64), the
+// LDS image, the DMA pieces and the ds_read_b128 fragment reads are byte-identical; a wave issues 4
+// v_mfma_f32_32x32x64_f8f6f4 per interval (unit block scales; 64 k each, twice the MACs per pipe cycle of the bf16
+// form) instead of 8 bf16 MFMAs.  Per-row activation scales and per-output-channel weight scales (fp32) are applied
+// to the fp32 accumulator in the epilogue.  p.A / p.W point to bytes, lda / ldw / K count fp8 elements.
+template <int EPI, bool F8>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tilesM, int tilesN) {
+  constexpr int EL = F8 ? 1 : 2;        // bytes per element
+  constexpr int KE = 128 / EL;          // elements per K tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -102,8 +113,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
       const int chunk = (lane & 7) ^ ((r >> 1) & 7);
       const int ra = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
       const int rw = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-      srcA[h][j] = ((uint32_t)ra * (uint32_t)p.lda + chunk * 8) * 2u;
-      srcW[h][j] = ((uint32_t)rw * (uint32_t)p.ldw + chunk * 8) * 2u;
+      srcA[h][j] = ((uint32_t)ra * (uint32_t)p.lda) * EL + chunk * 16;
+      srcW[h][j] = ((uint32_t)rw * (uint32_t)p.ldw) * EL + chunk * 16;
     }
   }
   // LDS byte address (M0 value) of this wave's two pieces inside half 0 of stage 0
@@ -114,7 +125,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   const int sw = (lane >> 1) & 7;
   int fo[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) fo[ks] = l31 * 128 + ((((2 * ks + half) ^ sw)) << 4);
+  for (int ks = 0; ks < 4; ++ks) {
+    // bf16: fragment ks = k-substep ks, 16-B chunk 2*ks + half.  fp8: fragments (2s, 2s+1) = the 32 bytes of
+    // k-substep s that this lane half owns, chunks 4s + 2*half + {0, 1}
+    const int chunk = F8 ? 4 * (ks >> 1) + 2 * half + (ks & 1) : 2 * ks + half;
+    fo[ks] = l31 * 128 + ((chunk ^ sw) << 4);
+  }
   // per-wave bases folded into the lane offsets: every ds_read below is base VGPR + immediate
   // (one set per stage: the second stage starts at 64 KiB, beyond the 16-bit DS offset field)
   int foa[2][4], fow[2][4];
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
 
-  const int nk = p.K / BK;
+  const int nk = p.K / KE;
 
   // LDS-DMA issue in inline asm: hipcc's waitcnt pass makes every ds_read that follows a
   // __builtin_amdgcn_global_load_lds wait for it (vmcnt(0) in the loop); an asm DMA is invisible to
@@ -158,10 +174,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   };
   // piece j (0/1) of half h of K tile kt into stage st (= kt & 1)
   auto dma_a1 = [&](int kt, int st, int h, int j) {
-    dma1(p.A + (size_t)kt * BK, srcA[h][j], dma_lds + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0) + j * 1024);
+    dma1((const bf16_t*)((const char*)p.A + (size_t)kt * 128), srcA[h][j], dma_lds + st * STAGE_BYTES + (h ? OFF_AM1 : OFF_AM0) + j * 1024);
   };
   auto dma_w1 = [&](int kt, int st, int h, int j) {
-    dma1(p.W + (size_t)kt * BK, srcW[h][j], dma_lds + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0) + j * 1024);
+    dma1((const bf16_t*)((const char*)p.W + (size_t)kt * 128), srcW[h][j], dma_lds + st * STAGE_BYTES + (h ? OFF_WN1 : OFF_WN0) + j * 1024);
   };
   auto dma_a = [&](int kt, int st, int h) { dma_a1(kt, st, h, 0); dma_a1(kt, st, h, 1); };  // prologue
   auto dma_w = [&](int kt, int st, int h) { dma_w1(kt, st, h, 0); dma_w1(kt, st, h, 1); };
@@ -183,8 +199,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   };
   // MFMA i (0..7) of an interval: k-substep i/2, 32-row block i%2 -> two rotating accumulators
   auto mma1 = [&](int i, const Frag4& w, const Frag4 (&a)[2], f32x16 (&c0), f32x16 (&c1)) {
-    if (i & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i >> 1], a[1].v[i >> 1], c1, 0, 0, 0);
-    else c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i >> 1], a[0].v[i >> 1], c0, 0, 0, 0);
+    if constexpr (F8) {
+      // slots 0, 2, 4, 6: k-substep s = i/4 (64 k), 32-row block (i/2)%2; odd slots are empty
+      if ((i & 1) == 0) {
+        const int s2 = (i >> 2) * 2, blk = (i >> 1) & 1;
+        const i32x8 wv = __builtin_shufflevector(__builtin_bit_cast(i32x4, w.v[s2]), __builtin_bit_cast(i32x4, w.v[s2 + 1]),
+                                                 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8 av = __builtin_shufflevector(__builtin_bit_cast(i32x4, a[blk].v[s2]),
+                                                 __builtin_bit_cast(i32x4, a[blk].v[s2 + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
+        f32x16& c = blk ? c1 : c0;
+        c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, c, 0, 0, 0, MC_F8_UNIT_SCALE, 0, MC_F8_UNIT_SCALE);
+      }
+    } else {
+      if (i & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i >> 1], a[1].v[i >> 1], c1, 0, 0, 0);
+      else c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i >> 1], a[0].v[i >> 1], c0, 0, 0, 0);
+    }
   };
 
   // ---- prologue: K tiles 0 and 1 in the steady-state issue order; Wn0(0), Am0(0), Wn1(0) landed
@@ -332,6 +361,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
     for (int ms = 0; ms < 2; ++ms) {
       const int m = m0 + wr * 128 + mh * 64 + ms * 32 + l31;
       if (m >= p.M) continue;
+      float sa = 1.f;
+      if constexpr (F8) sa = p.a_scale[m];
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
 #pragma unroll
@@ -340,8 +371,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
           f32x4 val;
           f32x4 b = {0.f, 0.f, 0.f, 0.f};
           if (p.bias) b = *(const f32x4*)(p.bias + n);
+          if constexpr (F8) {
+            const f32x4 sw4 = *(const f32x4*)(p.w_scale + n);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) val[i] = acc[mh][ms][nh][4 * g + i] + b[i];
+            for (int i = 0; i < 4; ++i) val[i] = acc[mh][ms][nh][4 * g + i] * (sa * sw4[i]) + b[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) val[i] = acc[mh][ms][nh][4 * g + i] + b[i];
+          }
           gemm_epilogue_quad<EPI>(p, m, n, val);
         }
       }
@@ -349,17 +386,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(GemmParams p, int
   }
 }
 
-template <int EPI>
+template <int EPI, bool F8 = false>
 hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
   const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<EPI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, F8>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI>), dim3(tilesM * tilesN), dim3(512), 2 * STAGE_BYTES, stream, p,
+  hipLaunchKernelGGL((gemm_big_kernel<EPI, F8>), dim3(tilesM * tilesN), dim3(512), 2 * STAGE_BYTES, stream, p,
                      tilesM, tilesN);
   return hipGetLastError();
 }
@@ -381,6 +418,25 @@ hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream
     case EPI_RESID_GATE: return launch_big_t<EPI_RESID_GATE>(p, stream);
     case EPI_RESID_CAPTURE: return launch_big_t<EPI_RESID_CAPTURE>(p, stream);
     case EPI_F32: return launch_big_t<EPI_F32>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// fp8 variant: K in fp8 elements, two K tiles of 128 per loop trip
+bool gemm_fp8_supported(const GemmParams& p) {
+  return p.M > 0 && p.N > 0 && (p.N % TB) == 0 && (p.K % 256) == 0 && p.K >= 512 && (p.lda % 16) == 0 &&
+         (p.ldw % 16) == 0 && p.a_scale && p.w_scale && (size_t)p.M * (size_t)p.lda < (1ull << 32) &&
+         (size_t)p.N * (size_t)p.ldw < (1ull << 32);
+}
+
+hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream) {
+  if (!gemm_fp8_supported(p)) return hipErrorInvalidValue;
+  switch (epi) {
+    case EPI_BF16: return launch_big_t<EPI_BF16, true>(p, stream);
+    case EPI_GELU_BF16: return launch_big_t<EPI_GELU_BF16, true>(p, stream);
+    case EPI_RESID_GATE: return launch_big_t<EPI_RESID_GATE, true>(p, stream);
+    case EPI_RESID_CAPTURE: return launch_big_t<EPI_RESID_CAPTURE, true>(p, stream);
+    case EPI_F32: return launch_big_t<EPI_F32, true>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -33,6 +33,9 @@ struct GemmParams {
   float* R; long ldr;
   bf16_t* X0out; long ldx0out;
   int m_valid;  // EPI_EMBED: rows >= m_valid are written as zeros (sequence padding)
+  // fp8 GEMM (launch_gemm_fp8): A / W point to OCP e4m3 bytes, C = (A W^T) * a_scale[m] * w_scale[n] + bias
+  const float* a_scale;
+  const float* w_scale;
 };
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
@@ -40,6 +43,13 @@ hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stre
 hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);    // 256x256 tiles
 bool gemm_bf16_big_supported(const GemmParams& p);
 extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported
+// fp8 (e4m3) operands, 256x256 tiles, v_mfma_f32_32x32x64_f8f6f4; K (fp8 elements) a multiple of 256
+hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);
+bool gemm_fp8_supported(const GemmParams& p);
+// row-wise fp8 quantisation: q[m, :] = e4m3(x[m, :] / s[m]), s[m] = max|x[m, :]| / 448 (1 for an all-zero row).
+// x bf16 (x_f32 null) or fp32.  Used for activations (per token) and for weights (per output channel).
+hipError_t launch_quantize_rows_fp8(const bf16_t* x, const float* x_f32, long ldx, int M, int K, uint8_t* q, long ldq,
+                                    float* scale, hipStream_t stream);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 struct AttnParams {

@@ -111,7 +111,8 @@ class Engine:
                      text_len=cfg["text_len"], latent_f=F_, latent_h=H_, latent_w=W_, eps=cfg.get("eps", 1e-6),
                      sp_rank=sp_rank, sp_size=sp_size, n_branches=n_branches, calibration=int(calibration),
                      clip_dim=cfg.get("clip_dim", 0), vace_layers=vace_geometry(cfg)[0], vace_stride=vace_geometry(cfg)[1],
-                     vace_in_dim=cfg.get("vace_in_dim", 0) if vace_geometry(cfg)[0] else 0)
+                     vace_in_dim=cfg.get("vace_in_dim", 0) if vace_geometry(cfg)[0] else 0,
+                     fp8_linear=int(bool(cfg.get("fp8_linear", False))))
         self.sp_rank, self.sp_size, self.n_branches = sp_rank, sp_size, n_branches
         h = C.c_void_p()
         check(self.lib.mc_create(C.byref(c), C.byref(h)))

@@ -31,6 +31,26 @@ def gemm(A, W, bias, epi, Cb=None, X=None, gate=None, X0=None, R=None, X0out=Non
                               P(X0out), X0out.stride(0) if X0out is not None else 0, m_valid, S()))
 
 
+def quantize_rows_fp8(x):
+    """x [M, K] bf16 or fp32 -> (q uint8 [M, K], scale fp32 [M])"""
+    lib = _lib.load()
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    s = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib.mc_op_quantize_rows_fp8(P(x), _lib.MC_BF16 if x.dtype == torch.bfloat16 else _lib.MC_F32, x.stride(0), M, K,
+                                      P(q), q.stride(0), P(s), S()))
+    return q, s
+
+
+def gemm_fp8(Aq, sa, Wq, sw, bias, epi, Cb=None, X=None, gate=None):
+    lib = _lib.load()
+    M, K = Aq.shape
+    N = Wq.shape[0]
+    check(lib.mc_op_gemm_fp8(P(Aq), Aq.stride(0), P(sa), P(Wq), Wq.stride(0), P(sw), P(bias), M, N, K, epi,
+                             P(Cb), Cb.stride(0) if Cb is not None else 0, P(X), X.stride(0) if X is not None else 0,
+                             P(gate), S()))
+
+
 def attention(Q, K, V, O, n_heads, shard_rows, shard_valid, n_shards, scale, k_shard_stride=0, v_shard_stride=0):
     lib = _lib.load()
     check(lib.mc_op_attention(P(Q), Q.stride(0), P(K), K.stride(0), k_shard_stride, P(V), V.stride(0),

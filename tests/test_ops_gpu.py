@@ -89,6 +89,68 @@ def test_gemm_bf16_epilogues(M, N, K, kernel_variant):
     assert float(X[mv:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (300, 512, 1024), (1024, 1536, 1536), (512, 256, 8960 - 8960 % 256)])
+def test_gemm_fp8_vs_dequantised_reference(M, N, K):
+    """fp8 path: (1) the row quantiser == torch's e4m3fn rounding of x / s; (2) the fp8 MFMA GEMM == the fp32 product of
+    the DEQUANTISED operands (exact products, fp32 accumulation order aside); (3) close to the unquantised product at
+    the precision fp8 e4m3 offers (3 mantissa bits: a few percent)."""
+    a = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    a[:, 3] *= 30.0                                   # an outlier column: per-row scales must absorb it
+    w = rnd(N, K, seed=2, scale=0.05)
+    bias = rnd(N, seed=3)
+    aq, sa = H.quantize_rows_fp8(a)
+    wq, sw = H.quantize_rows_fp8(w)
+    torch.testing.assert_close(sa, a.float().abs().amax(dim=1) / 448.0, rtol=1e-6, atol=0)
+    want_q = (a.float() / sa[:, None]).to(torch.float8_e4m3fn)
+    got_q = aq.view(torch.float8_e4m3fn)
+    mism = (got_q.float() != want_q.float()).float().mean().item()
+    assert mism < 1e-3, mism                          # ties of x / s against the reciprocal multiply used on the device
+    ad = got_q.float() * sa[:, None]
+    wd = wq.view(torch.float8_e4m3fn).float() * sw[:, None]
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    H.gemm_fp8(aq, sa, wq, sw, bias, H.EPI_F32 if hasattr(H, "EPI_F32") else 5, X=out)
+    want = ad.double() @ wd.double().t() + bias.double()
+    torch.testing.assert_close(out.double(), want, rtol=1e-3, atol=1e-3)
+    full = a.double() @ w.double().t() + bias.double()
+    assert rel_l2(out, full.float()) < 5e-2
+    # bf16 store + gated residual epilogues
+    cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    H.gemm_fp8(aq, sa, wq, sw, bias, 0, Cb=cb)
+    torch.testing.assert_close(cb.float(), want.float(), rtol=1e-2, atol=1e-2)
+    x0 = rnd(M, N, seed=5)
+    x, gate = x0.clone(), rnd(N, seed=6)
+    H.gemm_fp8(aq, sa, wq, sw, bias, 2, X=x, gate=gate)
+    torch.testing.assert_close(x, x0 + gate * want.float().to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)
+
+
+def test_gemm_fp8_speed_vs_bf16():
+    """informational: the fp8 kernel against the bf16 256x256 kernel on the FFN-1 shape (printed, asserted only to be
+    faster)"""
+    M, N, K = 32768, 8960 - 8960 % 256, 1536
+    a = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    aq, sa = H.quantize_rows_fp8(a)
+    wq, sw = H.quantize_rows_fp8(w)
+    cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+
+    def timed(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    t8 = timed(lambda: H.gemm_fp8(aq, sa, wq, sw, None, 1, Cb=cb))
+    t16 = timed(lambda: H.gemm(a, w, None, 1, Cb=cb))
+    tq = timed(lambda: H.quantize_rows_fp8(a))
+    fl = 2.0 * M * N * K
+    print(f"\nfp8 {t8:.3f} ms {fl / t8 / 1e9:.0f} TF | bf16 {t16:.3f} ms {fl / t16 / 1e9:.0f} TF | quantise A {tq:.3f} ms")
+    assert t8 < t16
+
+
 def test_gemm_rejects_bad_shapes():
     A = rnd(64, 48, dtype=torch.bfloat16)
     Wt = rnd(64, 48, dtype=torch.bfloat16)
