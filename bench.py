@@ -214,10 +214,14 @@ def main():
         dist.all_reduce(cnt)
         skipped = int(cnt[0])
     # ---- timed region 2: the same K steps with the cache off
-    t_nc, psnr = None, None
+    t_nc, psnr, attn_live = None, None, None
     if not args.no_nocache:
         M.disable_magcache(model)
+        # hipEvent pairs around every self-attention launch of THIS timed region, on the launch stream
+        model.engine.profile(True)
         t_nc, lat_nc = timed(lambda: run(args.steps), sync, barrier)
+        attn_live = model.engine.profile_read()
+        model.engine.profile(False)
         mse = float(((lat_mc - lat_nc) ** 2).mean())
         rng = float(lat_nc.abs().max())
         psnr = 100.0 if mse < 1e-10 else float(20 * np.log10(rng / np.sqrt(mse)))
@@ -254,6 +258,15 @@ def main():
         if world == 1 and not args.no_kernels:
             k = kernel_rooflines(cfg, device)
             line["roofline"] = {kk: k["attention"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+            if attn_live and attn_live[1] > 0:
+                # the dominant kernel's average launch duration inside the timed (no-cache) region: algorithmic
+                # FLOPs per launch = 4 L^2 d (attention core, no padding, no recompute)
+                ms = attn_live[0] / attn_live[1]
+                fl_attn = 4.0 * SEQ * SEQ * cfg["dim"]
+                line["roofline"].update(achieved=fl_attn / (ms * 1e-3) / 1e12, frac=fl_attn / (ms * 1e-3) / 2.5e15,
+                                        avg_launch_ms=ms, launches=attn_live[1],
+                                        measured="hipEvent pairs around every self-attention launch of the timed "
+                                                 "no-cache region (mc_profile_read)")
             line["roofline"]["kernel"] = "attn_fwd_v3_kernel (self-attention, 71% of forward FLOPs, 64% of forward time)"
             line["kernels"] = k
         if world == 1 and not args.no_cpu_baseline:

@@ -113,6 +113,12 @@ mc_status mc_set_clip_fea(mc_engine* e, const void* clip_dev, mc_dtype dtype, in
  * change the scale only. */
 mc_status mc_set_vace_context(mc_engine* e, const float* vace_dev, float context_scale, mc_stream stream);
 
+/* Measurement hook: with profiling on, every SELF-attention launch of a forward is bracketed by a hipEvent pair on the
+ * launch stream (up to 8192 launches between reads); mc_profile_read waits for them, returns the summed kernel time
+ * and the launch count, and clears the log.  bench.py uses it for roofline.achieved over its timed region. */
+mc_status mc_profile_enable(mc_engine* e, int on);
+mc_status mc_profile_read(mc_engine* e, double* attn_ms_total, int* attn_launches);
+
 /* ---- the same forward in phases (sequence parallel: the caller runs the K/V all-gather between
  * pre_attn and post_attn of every layer with its own communicator, e.g. torch.distributed/RCCL) */
 mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,

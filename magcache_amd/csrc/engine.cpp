@@ -86,6 +86,10 @@ struct mc_engine {
   int img_rows = 0;     // 257 image tokens padded to a multiple of 64
   bool have_clip = false;
   int local_attn_layer = -1;  // layer whose local-shard attention already ran (two-phase SP attention)
+  // optional in-stream timing of the dominant kernel (self-attention): hipEvent pairs around every launch
+  bool profile = false;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_n = 0;  // events used
   // VACE (upstream wan/modules/vace_model.py VaceWanModel): n_vace extra blocks on a control stream c; block i feeds
   // main layer i * vace_stride through after_proj ("hint")
   std::vector<Layer> vlayers;
@@ -435,6 +439,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
 void mc_destroy(mc_engine* e) {
   if (!e) return;
   for (void* p : e->owned) (void)hipFree(p);
+  for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   delete e;
 }
 
@@ -755,7 +760,13 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
       }
       e->local_attn_layer = -1;
     }
+    const bool prof = e->profile && e->prof_n + 2 <= e->prof_ev.size();
+    if (prof) HIP_TRY(hipEventRecord(e->prof_ev[e->prof_n], s));
     HIP_TRY(mc::launch_attention(a, s));
+    if (prof) {
+      HIP_TRY(hipEventRecord(e->prof_ev[e->prof_n + 1], s));
+      e->prof_n += 2;
+    }
   }
   {  // x = x + o(attn) * e[2]
     mc::GemmParams p = gp(ao, d, l.wo, d, l.bo, Lp, d, d);
@@ -997,6 +1008,32 @@ mc_status mc_import_residual(mc_engine* e, int branch, const float* src_dev, mc_
     HIP_TRY(hipMemcpyAsync(dst, src_dev, (size_t)e->Lr * e->d * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
   e->have_res[branch] = true;
+  return MC_OK;
+}
+
+mc_status mc_profile_enable(mc_engine* e, int on) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (on && e->prof_ev.empty()) {
+    e->prof_ev.resize(2 * 8192);
+    for (auto& ev : e->prof_ev) HIP_TRY(hipEventCreate(&ev));
+  }
+  e->profile = on != 0;
+  e->prof_n = 0;
+  return MC_OK;
+}
+
+mc_status mc_profile_read(mc_engine* e, double* attn_ms_total, int* attn_launches) {
+  if (!e || !attn_ms_total || !attn_launches) return fail(MC_EINVAL, "null argument");
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < e->prof_n; i += 2) {
+    HIP_TRY(hipEventSynchronize(e->prof_ev[i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]));
+    tot += ms;
+  }
+  *attn_ms_total = tot;
+  *attn_launches = (int)(e->prof_n / 2);
+  e->prof_n = 0;
   return MC_OK;
 }
 

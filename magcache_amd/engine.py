@@ -173,6 +173,16 @@ class Engine:
         check(self.lib.mc_set_clip_fea(self.h, _ptr(c), MC_F32, c.shape[0], _stream()))
         torch.cuda.current_stream().synchronize()
 
+    def profile(self, on=True):
+        """bracket every self-attention launch with hipEvents on the launch stream (see mc_profile_read)"""
+        check(self.lib.mc_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        """(summed self-attention kernel ms, launches) since the last read"""
+        ms, n = C.c_double(), C.c_int()
+        check(self.lib.mc_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def set_vace_context(self, vace_context, scale=1.0):
         """Wan2.1 VACE: vace_context [96, F, H, W] (None: change the scale only) and vace_context_scale."""
         v = None if vace_context is None else vace_context.detach().to(self.device, torch.float32).contiguous()
