@@ -156,7 +156,14 @@ enum {
                             (magcache_flux.py:326-338)                                              */
   MC_RULE_WAN22_T2V = 3, /* [2]-slot, split_step gating (MagCache4Wan2.2/magcache_generate.py:294-303) */
   MC_RULE_WAN22_I2V = 4,
-  MC_RULE_WAN22_TI2V = 5
+  MC_RULE_WAN22_TI2V = 5,
+  /* model families outside BASELINE.json's configs, rule only */
+  MC_RULE_FRAMEPACK = 6,     /* scalar, cnt >= int(R*n) and cnt >= 1, '<=', |1 - ratio| <= 0.06, re-init at cnt == 0 */
+  MC_RULE_OMNIGEN2 = 7,      /* scalar (one rule object per cond / ref / uncond branch), cnt >= ceil(R*n), '<=',
+                                accumulated_steps starts at 3 */
+  MC_RULE_QWEN = 8,          /* Wan2.1 rule without the accumulator reset at wrap-around (Qwen-Image / -Edit) */
+  MC_RULE_EVAL_WAN = 9,      /* [2]-slot, t >= int(n*0.2), '<=', table index t - 10 (sqrt-smoothed ratios) */
+  MC_RULE_EVAL_OPENSORA = 10 /* scalar, t >= int(R*n), '<=', signed error 1 - acc, table index t - 1 */
 };
 mc_rule* mc_rule_create(int variant, int num_steps, double thresh, int K, double retention_ratio,
                         const double* mag_ratios, int n_ratios, int split_step);

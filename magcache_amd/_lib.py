@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libmagcache_hip.so")
 MC_OK, MC_EINVAL, MC_ENOMEM, MC_EHIP, MC_ESTATE = 0, 1, 2, 3, 4
 MC_F32, MC_BF16 = 0, 1
 MC_MODE_FULL, MC_MODE_SKIP, MC_MODE_CALIB = 0, 1, 2
-RULE_VARIANTS = {"wan21": 0, "hunyuan": 1, "flux": 2, "wan22_t2v": 3, "wan22_i2v": 4, "wan22_ti2v": 5}
+RULE_VARIANTS = {"wan21": 0, "hunyuan": 1, "flux": 2, "wan22_t2v": 3, "wan22_i2v": 4, "wan22_ti2v": 5, "framepack": 6,
+                 "omnigen2": 7, "qwen": 8, "eval_wan": 9, "eval_opensora": 10}
 
 
 class McConfig(C.Structure):

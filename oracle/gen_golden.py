@@ -129,7 +129,9 @@ def exec_rule_lines(path, first, last, fake, n_calls, tail_first, tail_last):
     code_tail = compile(tail, path + f":{tail_first}-{tail_last}", "exec")
     out = []
     for _ in range(n_calls):
-        ns = {"self": fake, "np": np, "skip_forward": False, "use_magcache": True, "torch": torch, "x": None}
+        import math
+        ns = {"self": fake, "np": np, "math": math, "skip_forward": False, "use_magcache": True, "torch": torch, "x": None,
+              "hidden_states": 0.0, "ori_hidden_states": 0.0}
         exec(code_body, ns)
         out.append(bool(ns["skip_forward"]))
         exec(code_tail, ns)
@@ -201,6 +203,76 @@ def main():
         sk = exec_rule_lines("MagCache4Wan2.2/magcache_generate.py", 290, 317, f, steps * 2, 331, 337)
         sched[f"{variant}|{key}|steps{steps}|E0.12|K2|R0.2|split{split}"] = [int(s) for s in sk]
         assert f.cnt == 0
+    # ---- model families outside BASELINE.json's configs: rule only (SURVEY.md section 8a matrix)
+    # FLUX-Kontext: decision :328-340, counter :433-438 of magcache_flux_kontext.py (the FLUX rule, own table)
+    for thresh, K, R in ((0.24, 5, 0.1), (0.12, 3, 0.2)):
+        f = Fake()
+        f.cnt, f.num_steps, f.retention_ratio, f.magcache_thresh, f.K = 0, 28, R, thresh, K
+        f.mag_ratios, f.previous_residual = TABLES["flux_kontext"], None
+        f.accumulated_ratio, f.accumulated_err, f.accumulated_steps = 1, 0, 0
+        sk = exec_rule_lines("MagCache4FLUX_Kontext/magcache_flux_kontext.py", 328, 340, f, 28, 433, 438)
+        sched[f"flux|flux_kontext|steps28|E{thresh}|K{K}|R{R}"] = [int(s) for s in sk]
+        assert f.cnt == 0
+    # FramePack: decision (with the cnt == 0 re-init) :253-271, counter :298-300; two sections back to back
+    for thresh, K, steps in ((0.1, 3, 25), (0.1, 2, 25), (0.2, 3, 20)):
+        f = Fake()
+        f.cnt, f.num_steps, f.retention_ratio, f.magcache_thresh, f.K = 0, steps, 0.2, thresh, K
+        tbl = TABLES["framepack"]
+        f.mag_ratios = tbl if steps == len(tbl) else ref.nearest_interp(tbl, steps)
+        f.previous_residual = 0.0
+        sk = exec_rule_lines("MagCache4FramePack/magcache_demo_gradio.py", 253, 271, f, 2 * steps, 298, 300)
+        sched[f"framepack|framepack|steps{steps}|E{thresh}|K{K}|R0.2|calls{2 * steps}"] = [int(s) for s in sk]
+        assert f.cnt == 0
+    # OmniGen2: one MagCacheParams per branch (accumulated_steps starts at 3, :44); decision :343-356, counter :368-376
+    for key, thresh in (("omnigen2_t2i_cond", 0.05), ("omnigen2_edit_ref", 0.05), ("omnigen2_t2i_uncond", 0.1)):
+        f = Fake()
+        f.num_steps, f.retention_ratio, f.magcache_thresh, f.K = 50, 0.2, thresh, 3              # :74-83
+        f.magcache_params = Fake()
+        mp = f.magcache_params
+        mp.mag_ratios, mp.previous_residual, mp.cnt = TABLES[key], 0.0, 0
+        mp.accumulated_ratio, mp.accumulated_err, mp.accumulated_steps = 1.0, 0.0, 3
+        sk = exec_rule_lines("MagCache4OmniGen2/magcache/magcache_utils.py", 343, 356, f, 100, 368, 376)
+        sched[f"omnigen2|{key}|steps50|E{thresh}|K3|R0.2|calls100"] = [int(s) for s in sk]
+        assert mp.cnt == 0
+    # Qwen-Image / -Edit: decision :206-219 / :208-222, counter :242-244 / :245-247 (no accumulator reset at wrap-around)
+    for key, path, d0, d1, t0, t1 in (("qwen_image", "MagCache4QwenImage/magcache_generate.py", 206, 219, 242, 244),
+                                     ("qwen_image_edit", "MagCache4QwenImageEdit/magcache_generate.py", 208, 222, 245, 247)):
+        f = Fake()
+        f.cnt, f.num_steps, f.retention_ratio, f.magcache_thresh, f.K = 0, 100, 0.2, 0.06, 2
+        f.mag_ratios = TABLES[key]
+        f.residual_cache = [0.0, 0.0]
+        f.accumulated_ratio, f.accumulated_err, f.accumulated_steps = [1.0, 1.0], [0.0, 0.0], [0, 0]
+        sk = exec_rule_lines(path, d0, d1, f, 200, t0, t1)
+        sched[f"qwen|{key}|steps50|E0.06|K2|R0.2|calls200"] = [int(s) for s in sk]
+        assert f.cnt == 0
+    # eval Wan (:770-786, :807-815): sqrt-smoothed table, index t - 10, '<='
+    for K in (2, 4):
+        f = Fake()
+        f.t, f.num_steps, f.magcache_thresh, f.magcache_K = 0, 100, 0.12, K
+        f.ratio = TABLES["eval_wan_t2v_1.3B_raw"] ** 0.5                                         # :1144
+        f.residual_cache = {0: np.zeros((1, 1)), 1: np.zeros((1, 1))}
+        f.accumulated_sim, f.accumulated_steps, f.accumulated_err, f.skip_steps = [1, 1], [0, 0], [0, 0], 0
+        sk = exec_rule_lines("eval/magcache/experiments/Wan2.1_EVAL/wan_magcache.py", 770, 786, f, 100, 807, 815)
+        sched[f"eval_wan|eval_wan_t2v_1.3B_raw|steps50|E0.12|K{K}|R0.2"] = [int(s) for s in sk]
+        assert f.t == 0
+    # eval Open-Sora (:297-308, :348-354): scalar, signed error, index t - 1, 30 steps hard-wired
+    f = Fake()
+    f.t, f.skip_time, f.magcache_thresh, f.K = 0, 6, 0.12, 3                                     # :420-424
+    f.ratio = TABLES["eval_opensora_raw"] ** 0.5                                                 # :433
+    f.residual_cache = np.zeros((1, 1))
+    f.accumulated_sim, f.accumulated_steps, f.accumulated_err, f.skip_steps = 1, 0, 0, 0
+    sk = exec_rule_lines("eval/magcache/experiments/opensora.py", 297, 308, f, 60, 348, 354)
+    sched["eval_opensora|eval_opensora_raw|steps30|E0.12|K3|R0.2|calls60"] = [int(s) for s in sk]
+    assert f.t == 0
+    # Qwen-Image's own nearest_interp (np.linspace form, :14-21) on its table
+    src = open(os.path.join(REF, "MagCache4QwenImage/magcache_generate.py")).read().split("\n")
+    qns = {"np": np}
+    exec(compile("\n".join(src[13:21]), "MagCache4QwenImage/magcache_generate.py:14-21", "exec"), qns)
+    for n in (50, 30, 20):
+        t = TABLES["qwen_image"]
+        con, ucon = qns["nearest_interp"](t[0::2], n), qns["nearest_interp"](t[1::2], n)
+        ni[f"qwen_image-cfg-linspace->{n}"] = np.concatenate([con.reshape(-1, 1), ucon.reshape(-1, 1)], axis=1).reshape(-1).tolist()
+    json.dump(ni, open(os.path.join(GOLD, "nearest_interp.json"), "w"))
     json.dump(sched, open(os.path.join(GOLD, "rule_schedules.json"), "w"))
 
     # ---------------------------------------------------------------- wrapper forward goldens

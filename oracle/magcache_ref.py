@@ -8,6 +8,8 @@ magcache_generate.py in this container and replays its nearest_interp / magcache
 magcache_calibration; tests/test_oracle_golden.py checks this file against those outputs
 (tests/golden/*.json, *.npz) and against the skip schedules SURVEY.md section 8c lists as known answers.
 """
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -42,15 +44,25 @@ class RuleState:
       'hunyuan'    scalar,   gate cnt >= int(R*n), '<='    MagCache4HunyuanVideo/magcache_sample_video.py:88-102
       'flux'       scalar,   gate cnt >= int(R*n+0.5), '<=', step 11 of 28 excluded  MagCache4FLUX/magcache_flux.py:326-338
       'wan22_t2v' / 'wan22_i2v' / 'wan22_ti2v'   MagCache4Wan2.2/magcache_generate.py:294-317
+      'framepack'  scalar, cnt >= int(R*n) and cnt >= 1, '<=', |1-ratio| <= 0.06, re-init at cnt == 0, counter only at
+                   wrap-around                               MagCache4FramePack/magcache_demo_gradio.py:253-271,298-300
+      'omnigen2'   scalar per branch, cnt >= ceil(R*n), '<=', accumulated_steps starts at 3
+                                                             MagCache4OmniGen2/magcache/magcache_utils.py:44,343-356,368-376
+      'qwen'       the wan21 rule, counter only at wrap-around  MagCache4QwenImage/magcache_generate.py:205-219,242-244
+      'eval_wan'   [2]-slot, t >= int(n*0.2), '<=', table[t-10]  eval/.../Wan2.1_EVAL/wan_magcache.py:770-787,807-815
+      'eval_opensora'  scalar, t >= int(R*n), '<=', err += 1 - acc (signed), table[t-1]  eval/.../opensora.py:297-309,348-354
     """
 
     def __init__(self, variant, num_steps, thresh, K, retention_ratio, mag_ratios, split_step=None):
         self.variant, self.num_steps, self.thresh, self.K = variant, num_steps, thresh, K
         self.retention_ratio, self.split_step = retention_ratio, split_step
         self.mag_ratios = np.asarray(mag_ratios, dtype=np.float64)
-        self.two = variant in ("wan21", "wan22_t2v", "wan22_i2v", "wan22_ti2v")
+        self.two = variant in ("wan21", "wan22_t2v", "wan22_i2v", "wan22_ti2v", "qwen", "eval_wan")
+        self.strict = variant in ("wan21", "wan22_t2v", "wan22_i2v", "wan22_ti2v", "qwen")
         self.cnt = 0
         self._reset()
+        if variant == "omnigen2":
+            self.acc_steps[0] = 3
 
     def _reset(self):
         self.acc_ratio, self.acc_err, self.acc_steps = [1.0, 1.0], [0.0, 0.0], [0, 0]
@@ -58,8 +70,16 @@ class RuleState:
     def _gate(self):
         n, R, c, sp = self.num_steps, self.retention_ratio, self.cnt, self.split_step
         v = self.variant
-        if v in ("wan21", "wan22_ti2v"):
+        if v in ("wan21", "wan22_ti2v", "qwen"):
             return c >= int(n * R)
+        if v == "framepack":
+            return c >= int(R * n) and c >= 1
+        if v == "omnigen2":
+            return c >= math.ceil(R * n)
+        if v == "eval_wan":
+            return c >= int(n * 0.2)
+        if v == "eval_opensora":
+            return c >= int(R * n)
         if v == "hunyuan":
             return c >= int(R * n)
         if v == "flux":
@@ -74,16 +94,22 @@ class RuleState:
         """One forward call -> (skip, branch).  Mutates state exactly like the reference."""
         p = self.cnt % 2 if self.two else 0
         skip = False
+        v = self.variant
+        if v == "framepack" and self.cnt == 0:
+            self.acc_ratio[0], self.acc_steps[0], self.acc_err[0] = 1.0, 0, 0.0
         if self._gate():
-            self.acc_ratio[p] = self.acc_ratio[p] * self.mag_ratios[self.cnt]
+            cur = self.mag_ratios[self.cnt - 10 if v == "eval_wan" else self.cnt - 1 if v == "eval_opensora" else self.cnt]
+            self.acc_ratio[p] = self.acc_ratio[p] * cur
             self.acc_steps[p] += 1
-            self.acc_err[p] += np.abs(1 - self.acc_ratio[p])
-            if self.two:
+            self.acc_err[p] += (1 - self.acc_ratio[p]) if v == "eval_opensora" else np.abs(1 - self.acc_ratio[p])
+            if self.strict:
                 ok = self.acc_err[p] < self.thresh and self.acc_steps[p] <= self.K
             else:
                 ok = self.acc_err[p] <= self.thresh and self.acc_steps[p] <= self.K
-                if self.variant == "flux":
+                if v == "flux":
                     ok = ok and np.round(self.cnt * ((28 - 1) / (self.num_steps - 1))).astype(int) != 11
+                if v == "framepack":
+                    ok = ok and np.abs(1 - cur) <= 0.06
             if ok:
                 skip = True
             else:
@@ -91,7 +117,8 @@ class RuleState:
         self.cnt += 1
         if self.cnt >= self.num_steps:
             self.cnt = 0
-            self._reset()
+            if v not in ("qwen", "framepack"):
+                self._reset()
         return skip, p
 
     def schedule(self, n_calls=None):

@@ -12,7 +12,7 @@ import pytest
 from magcache_amd import _lib
 from magcache_amd import model as M
 from magcache_amd.mag_ratios import TABLES
-from test_oracle_golden import parse_key, table_for
+from test_oracle_golden import TWO_SLOT, parse_key, table_for
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -53,16 +53,18 @@ def test_c_rule_matches_reference_schedules(golden_dir):
         assert r
         b = C.c_int()
         got, branches = [], []
-        for _ in range(n):
+        calls = d.get("calls", n)
+        for _ in range(calls):
             got.append(lib.mc_rule_step(r, C.byref(b)))
             branches.append(b.value)
         assert got == want, key
         assert lib.mc_rule_cnt(r) == 0
-        two = d["variant"] in ("wan21", "wan22_t2v", "wan22_i2v", "wan22_ti2v")
-        assert branches == [(i % 2 if two else 0) for i in range(n)]
+        two = d["variant"] in TWO_SLOT
+        assert branches == [(i % 2 if two else 0) for i in range(calls)]
         err, steps, ratio = (C.c_double * 2)(), (C.c_int * 2)(), (C.c_double * 2)()
         lib.mc_rule_state(r, err, steps, ratio)
-        assert list(err) == [0.0, 0.0] and list(steps) == [0, 0] and list(ratio) == [1.0, 1.0]
+        if d["variant"] not in ("qwen", "framepack"):       # these two only rewind the counter at wrap-around
+            assert list(err) == [0.0, 0.0] and list(steps) == [0, 0] and list(ratio) == [1.0, 1.0]
         lib.mc_rule_destroy(r)
 
 
@@ -77,7 +79,7 @@ def test_c_nearest_interp(golden_dir):
     lib = _lib.load()
     g = json.load(open(os.path.join(golden_dir, "nearest_interp.json")))
     for key, want in g.items():
-        if "-cfg->" in key:
+        if "-cfg" in key:
             continue
         name, n = key.split("->")
         src = TABLES[name]
@@ -90,8 +92,8 @@ def test_c_nearest_interp(golden_dir):
 def test_python_nearest_interp_and_table_selection(golden_dir):
     g = json.load(open(os.path.join(golden_dir, "nearest_interp.json")))
     for key, want in g.items():
-        if "-cfg->" in key:
-            name, n = key.split("-cfg->")
+        if "-cfg" in key:       # incl. Qwen-Image's np.linspace form: the same nearest indices
+            name, n = key.replace("-cfg-linspace->", "-cfg->").split("-cfg->")
             got = M.resample_cfg_table(TABLES[name], int(n))
         else:
             name, n = key.split("->")
@@ -333,7 +335,7 @@ def test_flux_and_hunyuan_shims_follow_the_reference_rules(golden_dir, capsys):
         m.engine, modes = FakeMMDiTEngine(), []
         cls._run = lambda self, *a: (modes.append(a[-1]) or "out")
         if d["variant"] == "flux":
-            MM.init_flux_magcache(m, d["steps"], d["thresh"], d["K"], d["R"])
+            MM.init_flux_magcache(m, d["steps"], d["thresh"], d["K"], d["R"], mag_ratios=TABLES[d["table"]])
             assert cls.forward is MM.flux_magcache_forward and cls.previous_residual is None
             call = lambda: m(hidden_states=None, return_dict=False)
             want_out = ("out",)

@@ -29,13 +29,21 @@ def parse_key(key):
             d["R"] = float(p[1:])
         elif p.startswith("split"):
             d["split"] = None if p[5:] == "None" else int(p[5:])
+        elif p.startswith("calls"):
+            d["calls"] = int(p[5:])
     return d
 
 
+TWO_SLOT = ("wan21", "wan22_t2v", "wan22_i2v", "wan22_ti2v", "qwen", "eval_wan")
+
+
 def table_for(d):
+    """(table as the script installs it, number of forward calls per sample)"""
     t = TABLES[d["table"]]
-    two = d["variant"] in ("wan21", "wan22_t2v", "wan22_i2v", "wan22_ti2v")
-    if two:
+    if d["variant"] in ("eval_wan", "eval_opensora"):
+        # the evaluation scripts take the square root at the patch site and index it with an offset
+        return t ** 0.5, d["steps"] * (2 if d["variant"] == "eval_wan" else 1)
+    if d["variant"] in TWO_SLOT:
         return MR.interp_cfg_table(t, d["steps"]), d["steps"] * 2
     return (t if len(t) == d["steps"] else MR.nearest_interp(t, d["steps"])), d["steps"]
 
@@ -49,7 +57,7 @@ def test_rule_schedules_match_reference(golden_dir):
         split = d.get("split")
         st = MR.RuleState(d["variant"], n, d["thresh"], d["K"], d["R"], table,
                           split_step=None if split is None else split * 2)
-        got = [int(s) for s, _ in st.schedule()]
+        got = [int(s) for s, _ in st.schedule(d.get("calls"))]      # "calls": more than one sample back to back
         assert got == want, key
         assert st.cnt == 0
 
@@ -81,7 +89,10 @@ def test_table_lengths():
 def test_nearest_interp(golden_dir):
     g = json.load(open(os.path.join(golden_dir, "nearest_interp.json")))
     for key, want in g.items():
-        if "-cfg->" in key:
+        if "-cfg-linspace->" in key:           # Qwen-Image's own np.linspace form (MagCache4QwenImage/...:14-21)
+            name, n = key.split("-cfg-linspace->")
+            got = MR.interp_cfg_table(TABLES[name], int(n))
+        elif "-cfg->" in key:
             name, n = key.split("-cfg->")
             got = MR.interp_cfg_table(TABLES[name], int(n))
         else:
