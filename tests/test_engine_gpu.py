@@ -385,24 +385,27 @@ def test_generate_entry_point_short_run(tmp_path):
     assert torch.equal(got, lat.cpu())
 
 
-@pytest.mark.parametrize("extra,par", [([], "cfg2 x sp1"), (["--no_cfg_parallel"], "sequence-parallel sp2")])
-def test_bench_two_ranks_one_gpu(extra, par):
+@pytest.mark.parametrize("nproc,extra,par", [(2, [], "cfg2 x sp1"), (2, ["--no_cfg_parallel"], "sequence-parallel sp2"),
+                                             (4, [], "cfg2 x sp2")])
+def test_bench_two_ranks_one_gpu(nproc, extra, par):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per process), here
-    with both ranks on cuda:0 over gloo: one JSON line from rank 0, the reference skip schedule, and the
-    same final-latent PSNR vs no-cache as a single process gets (the parallel layouts change no result)."""
+    with all ranks on cuda:0 over gloo: one JSON line from rank 0, the reference skip schedule, and the
+    same final-latent PSNR vs no-cache as a single process gets (the parallel layouts change no result).  The 4-rank
+    case is the layout of the driver's 4- and 8-GPU runs: CFG branches on two halves, sequence parallel inside a half
+    (sub-groups, pair exchange, local-shard-first attention with the log-sum-exp merge)."""
     env = dict(os.environ, PYTHONPATH=ROOT, MC_BENCH_BACKEND="gloo")
     base = [os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "0", "--no_cpu_baseline", "--no_kernels"]
     one = subprocess.run([sys.executable] + base + ["--gpus", "1"], env=env, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
     ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", "29551"] + base + ["--gpus", "2"] + extra
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29551 + nproc)] + base + ["--gpus", str(nproc)] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     got = json.loads(lines[0])
-    assert got["n_gpus"] == 2 and got["config"]["parallelism"].startswith(par)
+    assert got["n_gpus"] == nproc and got["config"]["parallelism"].startswith(par)
     assert got["forwards_skipped"] == ref["forwards_skipped"] and got["forwards_total"] == 20
     assert abs(got["psnr_vs_nocache_db"] - ref["psnr_vs_nocache_db"]) < 0.5
 
