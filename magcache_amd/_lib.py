@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmagcache_hip.so")
+# kernel A/B runs (tools/build_variants.py) point this at an alternative build of the same library
+LIB_PATH = os.environ.get("MAGCACHE_HIP_LIB", LIB_PATH)
 
 MC_OK, MC_EINVAL, MC_ENOMEM, MC_EHIP, MC_ESTATE = 0, 1, 2, 3, 4
 MC_F32, MC_BF16 = 0, 1

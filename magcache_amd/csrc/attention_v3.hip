@@ -240,12 +240,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
 
   // Two P values: exp2(S) of accumulator registers 2j, 2j+1 of S[kb] -> one packed bf16 pair,
   // the B-operand word 8*kb + j of the PV MFMA (key step ks = 2*kb + j/4); row sums in two chains.
+// (Measured and rejected, sustained regime: v_pk_add_f32 for the two chains, a one-position software skew of
+// exp vs add/pack, v_dot2c_f32_bf16 on the packed pair -- each trades 16 VALU issues for trans->VALU hazard
+// s_nops or a longer dependent chain and came out 3-6 % slower.)
+#ifndef MC_ABL
+#define MC_ABL 0  // timing ablations (tools/build_variants.py): 1 no exp2, 2 no row-sum adds, 4 no row maximum
+#endif
+#define MC_EXP2_(x) ((MC_ABL & 1) ? (x) : __builtin_amdgcn_exp2f(x))
 #define MC_FIN_PAIR(S, kb, j)                                                             \
   {                                                                                       \
-    const float e0_ = __builtin_amdgcn_exp2f(S[kb][2 * (j)]);                              \
-    const float e1_ = __builtin_amdgcn_exp2f(S[kb][2 * (j) + 1]);                          \
-    rs0 += e0_;                                                                           \
-    rs1 += e1_;                                                                           \
+    const float e0_ = MC_EXP2_(S[kb][2 * (j)]);                                            \
+    const float e1_ = MC_EXP2_(S[kb][2 * (j) + 1]);                                        \
+    if (!(MC_ABL & 2)) {                                                                  \
+      rs0 += e0_;                                                                         \
+      rs1 += e1_;                                                                         \
+    }                                                                                     \
     pk[8 * (kb) + (j)] = pack_bf16x2(e0_, e1_);                                           \
   }
   // pair number n = 0..15 in key-step order: ks = n/4
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
     o[(i) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(VC, __builtin_bit_cast(bf16x8, pw_), o[(i) & 3], 0, 0, 0); \
   }                                                                                                  \
   if ((i) < 6) MC_FIN_N(S_cur, 10 + (i))                                                             \
-  else if ((i) >= 8 && (i) < 12) MC_ROWMAX_PART(S_nxt, (i) - 8, rm_, mx)                             \
+  else if ((i) >= 8 && (i) < 12) { if (MC_ABL & 4) mx = 0.f; else MC_ROWMAX_PART(S_nxt, (i) - 8, rm_, mx) }                             \
   if ((i) == 6) dma1(vptr_, srcV[0], vdst_);                                                         \
   if ((i) == 12) dma1(vptr_, srcV[1], vdst_ + 1024);                                                 \
   MC_PIN();
