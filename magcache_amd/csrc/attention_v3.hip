@@ -58,6 +58,9 @@ __device__ __forceinline__ float rowmax32(const f32x16& a, const f32x16& b) {
   return half_swap_max(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
 }
 
+#ifndef MC_ABL
+#define MC_ABL 0  // timing ablations (tools/build_variants.py; results are wrong by construction): 1 no exp2,
+#endif            // 2 no row-sum adds, 4 no row maximum, 8 no V^T fragment reads, 16 no K fragment reads
 #define MC_PIN() __builtin_amdgcn_sched_barrier(0)
 
 __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int nqb, int tiles_per_shard) {
@@ -184,10 +187,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
   bool first = true;
 
   auto read_k = [&](const char* st, int ds, bf16x8& k0, bf16x8& k1) {  // keys l31 and 32 + l31
+    if ((MC_ABL & 16) && ds > 2) return;   // timing ablation: no K fragment traffic after the first reads
     k0 = *(const bf16x8*)(st + koff[ds]);
     k1 = *(const bf16x8*)(st + koff[ds] + 32 * 256);
   };
   auto read_v = [&](const char* st, int i, bf16x8& vf) {  // V^T fragment of PV micro-step i = 4*ks + db
+    if ((MC_ABL & 8) && i > 3) return;     // timing ablation: no V fragment traffic after the first reads
     const char* vp = st + voff[i & 3] + (i >> 2) * (16 * 256);
     const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp));
     const bf16x4 v1 =
@@ -243,9 +248,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
 // (Measured and rejected, sustained regime: v_pk_add_f32 for the two chains, a one-position software skew of
 // exp vs add/pack, v_dot2c_f32_bf16 on the packed pair -- each trades 16 VALU issues for trans->VALU hazard
 // s_nops or a longer dependent chain and came out 3-6 % slower.)
-#ifndef MC_ABL
-#define MC_ABL 0  // timing ablations (tools/build_variants.py): 1 no exp2, 2 no row-sum adds, 4 no row maximum
-#endif
 #define MC_EXP2_(x) ((MC_ABL & 1) ? (x) : __builtin_amdgcn_exp2f(x))
 #define MC_FIN_PAIR(S, kb, j)                                                             \
   {                                                                                       \
