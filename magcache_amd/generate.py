@@ -13,6 +13,10 @@ no VAE in this repository (out of scope).  So
     e.g. dumped from the upstream pipeline), or, without them, is a seeded synthetic stand-in;
   * DiT weights are loaded from `--ckpt_dir` if it holds the upstream `*.safetensors`, otherwise they are
     seeded random-init weights of the named architecture (a warning says so);
+  * i2v-14B takes `--clip_fea_file` ([257, 1280] CLIP features of the first frame) and `--y_file` ([20, F, H/8, W/8]:
+    mask + VAE latent of the conditioning frames), vace-* takes `--vace_context_file` ([96, F, H/8, W/8]) and
+    `--vace_context_scale`: the tensors the upstream pipeline computes with its CLIP / VAE before the sampling loop
+    (synthetic stand-ins without the files);
   * the result saved to `--save_file` is the final LATENT ([16, F, H/8, W/8] fp32, torch.save), which the
     upstream pipeline would hand to its VAE decoder.
 The flags that only concern those parts (--t5_cpu, --offload_model, prompt extension, FSDP, ...) are accepted
@@ -33,7 +37,9 @@ import time
 SIZE_CONFIGS = {"720*1280": (720, 1280), "1280*720": (1280, 720), "480*832": (480, 832), "832*480": (832, 480),
                 "1024*1024": (1024, 1024)}
 SUPPORTED_SIZES = {"t2v-14B": ("720*1280", "1280*720", "480*832", "832*480"), "t2v-1.3B": ("480*832", "832*480"),
-                   "t2i-14B": tuple(SIZE_CONFIGS.keys())}
+                   "t2i-14B": tuple(SIZE_CONFIGS.keys()),
+                   "i2v-14B": ("720*1280", "1280*720", "480*832", "832*480"),
+                   "vace-1.3B": ("480*832", "832*480"), "vace-14B": ("720*1280", "1280*720", "480*832", "832*480")}
 EXAMPLE_PROMPT = "Two anthropomorphic cats in comfy boxing gear and bright gloves fight intensely on a spotlighted stage."
 
 
@@ -85,6 +91,10 @@ def _parse_args(argv=None):
     # inputs that replace the absent text encoder
     p.add_argument("--context_file", type=str, default=None, help="torch tensor [len<=512, 4096]: T5 embedding of the prompt")
     p.add_argument("--context_null_file", type=str, default=None, help="the same for the negative prompt")
+    p.add_argument("--clip_fea_file", type=str, default=None, help="i2v: torch tensor [257, 1280] (CLIP visual features)")
+    p.add_argument("--y_file", type=str, default=None, help="i2v: torch tensor [20, F, H/8, W/8] (mask + conditioning latent)")
+    p.add_argument("--vace_context_file", type=str, default=None, help="vace: torch tensor [96, F, H/8, W/8]")
+    p.add_argument("--vace_context_scale", type=float, default=1.0)
     # accepted for command-line compatibility; they configure parts that are not in this repository
     for flag, kw in (("--offload_model", dict(type=str2bool, default=None)), ("--ulysses_size", dict(type=int, default=1)),
                      ("--ring_size", dict(type=int, default=1)), ("--t5_fsdp", dict(action="store_true")),
@@ -120,7 +130,8 @@ def generate(args):
     import torch.distributed as dist
     import magcache_amd as mca
     from magcache_amd import model as M
-    from magcache_amd.engine import WAN_T2V_1_3B, WAN_T2V_14B, synthetic_weights
+    from magcache_amd.engine import (WAN_I2V_14B, WAN_T2V_1_3B, WAN_T2V_14B, WAN_VACE_1_3B, WAN_VACE_14B,
+                                     synthetic_weights)
 
     rank, world = int(os.getenv("RANK", 0)), int(os.getenv("WORLD_SIZE", 1))
     local = int(os.getenv("LOCAL_RANK", 0))
@@ -141,7 +152,15 @@ def generate(args):
     if args.ulysses_size > 1 or args.ring_size > 1:
         logging.info("--ulysses_size/--ring_size are ignored: the token sequence is sharded over WORLD_SIZE ranks")
 
-    cfg = WAN_T2V_1_3B if "1.3B" in args.task else WAN_T2V_14B
+    is_i2v, is_vace = "i2v" in args.task, "vace" in args.task
+    if is_i2v:
+        cfg = WAN_I2V_14B
+    elif is_vace:
+        cfg = WAN_VACE_1_3B if "1.3B" in args.task else WAN_VACE_14B
+    else:
+        cfg = WAN_T2V_1_3B if "1.3B" in args.task else WAN_T2V_14B
+    if (is_i2v or is_vace) and world > 1:
+        raise SystemExit("i2v / vace tasks run on one GPU in this engine (the control / image branches are not sharded)")
     H, W = SIZE_CONFIGS[args.size][1], SIZE_CONFIGS[args.size][0]
     grid = ((args.frame_num - 1) // 4 + 1, H // 8, W // 8)
     logging.info(f"Generation job args: {args}")
@@ -166,20 +185,41 @@ def generate(args):
         name = args.ckpt_dir or ("Wan2.1-T2V-1.3B" if "1.3B" in args.task else "Wan2.1-T2V-14B")
         if "T2V-1.3B" not in name and "T2V-14B" not in name:
             name = "Wan2.1-T2V-1.3B" if "1.3B" in args.task else "Wan2.1-T2V-14B"
+        table = M.select_table(args.ckpt_dir or ("720P" if "720" in args.size else "480P"), task=args.task) \
+            if (is_i2v or is_vace) else None                                      # :1001-1004, :1141-1144
         mca.init_magcache(model, args.sample_steps, args.magcache_thresh, args.magcache_K, args.retention_ratio,
-                          ckpt_dir=name)                                         # :896-919
+                          ckpt_dir=name, mag_ratios=table)                        # :896-919
+        if is_vace:
+            type(model).forward = M.magcache_vace_forward                         # :1127
     if args.magcache_calibration:
         mca.init_magcache_calibration(model, args.sample_steps)                   # :921-928
+        if is_vace:
+            type(model).forward = M.magcache_vace_calibration                     # :1153
+    if is_vace and not (args.use_magcache or args.magcache_calibration):
+        type(model).forward = M.vace_plain_forward
 
     prompt = args.prompt or EXAMPLE_PROMPT
     ctx = _context(args.context_file, prompt, args.base_seed, cfg["text_dim"], device)
     ctx_null = _context(args.context_null_file, "", args.base_seed + 1, cfg["text_dim"], device)
     g = torch.Generator(device=device).manual_seed(args.base_seed)
     noise = torch.randn(16, *grid, dtype=torch.float32, device=device, generator=g)      # wan_magcache.py:243-251
+    extra = {}
+    if is_i2v:
+        gi = torch.Generator(device="cpu").manual_seed(args.base_seed + 2)
+        extra["clip_fea"] = (torch.load(args.clip_fea_file, map_location="cpu") if args.clip_fea_file
+                             else torch.randn(257, cfg["clip_dim"], generator=gi)).float().to(device)
+        extra["y"] = [(torch.load(args.y_file, map_location="cpu") if args.y_file
+                       else torch.randn(20, *grid, generator=gi)).float().to(device)]
+    if is_vace:
+        gi = torch.Generator(device="cpu").manual_seed(args.base_seed + 3)
+        extra["vace_context"] = [(torch.load(args.vace_context_file, map_location="cpu") if args.vace_context_file
+                                  else torch.randn(cfg["vace_in_dim"], *grid, generator=gi)).float().to(device)]
+        extra["vace_context_scale"] = args.vace_context_scale
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     latent = mca.sample(model, noise, ctx, ctx_null, sampling_steps=args.sample_steps, shift=args.sample_shift,
-                        guide_scale=args.sample_guide_scale, solver=args.sample_solver, layout=layout)
+                        guide_scale=args.sample_guide_scale, solver=args.sample_solver, layout=layout,
+                        model_kwargs=extra)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     logging.info(f"denoising: {dt:.2f} s, {args.sample_steps / dt:.3f} steps/s")

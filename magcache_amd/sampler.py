@@ -148,11 +148,14 @@ class FlowSolver:
 
 
 def sample(model, noise, context, context_null, sampling_steps=50, shift=5.0, guide_scale=5.0, seq_len=None,
-           callback=None, solver="euler", layout=None, lincomb=None):
+           callback=None, solver="euler", layout=None, lincomb=None, model_kwargs=None):
     """Run the denoising loop; returns the final latent (fp32 [C,F,H,W]).  `model` is called like the
     upstream model: model([latent], t=timestep, context=[ctx], seq_len=seq_len)[0].  `layout`
     (parallel.ParallelLayout) with cfg_size == 2: this rank runs one CFG branch per step and swaps the
-    prediction with its pair rank; every rank then applies the same update to its replica of the latent."""
+    prediction with its pair rank; every rank then applies the same update to its replica of the latent.
+    `model_kwargs`: extra conditioning passed to every call (i2v: clip_fea, y; vace: vace_context, vace_context_scale),
+    like upstream's arg_c / arg_null dictionaries."""
+    mk = model_kwargs or {}
     sig, ts = flow_timesteps(sampling_steps, shift)
     device = noise.device
     t_dev = torch.tensor(ts, dtype=torch.float32, device=device)
@@ -170,8 +173,8 @@ def sample(model, noise, context, context_null, sampling_steps=50, shift=5.0, gu
                                [context if layout.branch == 0 else context_null], seq_len)[0]
             eps_c, eps_u = layout.exchange(mine.contiguous())
         else:
-            eps_c = model([latent], t=timestep, context=[context], seq_len=seq_len)[0]
-            eps_u = model([latent], t=timestep, context=[context_null], seq_len=seq_len)[0]
+            eps_c = model([latent], t=timestep, context=[context], seq_len=seq_len, **mk)[0]
+            eps_u = model([latent], t=timestep, context=[context_null], seq_len=seq_len, **mk)[0]
         if fs is None and lincomb is None:
             cfg_euler_(latent, eps_c, eps_u, guide_scale, float(sig[i + 1] - sig[i]))
         elif fs is None:

@@ -385,6 +385,22 @@ def test_generate_entry_point_short_run(tmp_path):
     assert torch.equal(got, lat.cpu())
 
 
+def test_generate_entry_point_vace_task(tmp_path):
+    """python -m magcache_amd.generate --task vace-1.3B (5 frames, 6 steps): control blocks + hints + MagCache through the
+    CLI path, latent written"""
+    from magcache_amd import generate as G
+    out = tmp_path / "latent_vace.pt"
+    args = G._parse_args(["--task", "vace-1.3B", "--size", "832*480", "--frame_num", "5", "--sample_steps", "6",
+                          "--base_seed", "7", "--use_magcache", "--magcache_K", "2", "--sample_solver", "euler",
+                          "--vace_context_scale", "0.5", "--save_file", str(out)])
+    try:
+        lat = G.generate(args)
+    finally:
+        M.WanModelHIP.forward = M.plain_forward
+    got = torch.load(out)
+    assert tuple(got.shape) == (16, 2, 60, 104) and bool(torch.isfinite(got).all()) and torch.equal(got, lat.cpu())
+
+
 @pytest.mark.parametrize("nproc,extra,par", [(2, [], "cfg2 x sp1"), (2, ["--no_cfg_parallel"], "sequence-parallel sp2"),
                                              (4, [], "cfg2 x sp2")])
 def test_bench_two_ranks_one_gpu(nproc, extra, par):

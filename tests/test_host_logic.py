@@ -203,6 +203,16 @@ def test_skip_before_any_residual_is_an_error():
 
 
 # ----------------------------------------------------------------------------- generate.py CLI
+def test_generate_cli_accepts_i2v_and_vace_tasks():
+    from magcache_amd import generate as G
+    a = G._parse_args(["--task", "i2v-14B", "--size", "832*480", "--clip_fea_file", "c.pt", "--y_file", "y.pt"])
+    assert a.frame_num == 81 and a.clip_fea_file == "c.pt" and a.y_file == "y.pt"
+    a = G._parse_args(["--task", "vace-1.3B", "--size", "832*480", "--vace_context_scale", "0.7"])
+    assert a.vace_context_scale == 0.7 and a.sample_steps == 50
+    with pytest.raises(AssertionError):
+        G._parse_args(["--task", "vace-1.3B", "--size", "1280*720"])          # not a supported size of the 1.3B model
+
+
 def test_generate_cli_defaults_and_validation():
     """the flags, defaults and checks of the reference's _parse_args / _validate_args
     (MagCache4Wan2.1/magcache_generate.py:563-595, :598-775) for the hot-path arguments"""
