@@ -147,23 +147,53 @@ def make_experts(cfg, latent_grid, device="cuda:0", name="WanModelHIP22", **kw):
     return hi, lo
 
 
+def call_branch(model, step, branch, x, t, context, seq_len, **kw):
+    """One forward of ONE CFG branch at sampler step `step` (CFG-parallel layouts).  The class-shared counter runs over
+    both branches of both experts (cnt = 2*step + branch selects mag_ratios[cnt], the state slot and the split-step
+    gates, :290-317): it is positioned before the call, and after a cond call the sibling uncond call made by the
+    other half of the node is accounted for, so the end-of-video reset (:333-337) happens as in the sequential loop."""
+    cls = type(model)
+    has_state = getattr(cls, "forward", None) is magcache_forward
+    if has_state:
+        cls.cnt = 2 * step + branch
+    out = model(x, t=t, context=context, seq_len=seq_len, **kw)
+    if has_state and branch == 0:
+        cls.cnt = int(cls.cnt) + 1
+        if cls.cnt >= cls.num_steps:
+            cls.cnt = 0
+            cls.accumulated_ratio = [1.0, 1.0]
+            cls.accumulated_err = [0.0, 0.0]
+            cls.accumulated_steps = [0, 0]
+    return out
+
+
 def sample(high, low, noise, context, context_null, boundary, sampling_steps=40, shift=12.0, guide_scale=(3.0, 4.0),
-           y=None, seq_len=None, solver="euler"):
+           y=None, seq_len=None, solver="euler", layout=None, lincomb=None):
     """The two-expert denoising loop (upstream wan/text2video.py generate(): expert by timestep, guidance
-    scale per expert (low, high), cond call first, uncond second)."""
+    scale per expert (low, high), cond call first, uncond second).  `layout` (parallel.ParallelLayout): with
+    cfg_size == 2 this rank evaluates one CFG branch per step and swaps predictions with its pair rank; the experts'
+    engines are sharded over the sequence-parallel group they were created with (make_experts(..., sp_rank=, sp_size=,
+    sp_group=))."""
     from .sampler import FlowSolver, lincomb_hip
+    lincomb_hip = lincomb or lincomb_hip
     ts, sig = get_timesteps(shift, sampling_steps)
     device = noise.device
     t_dev = torch.tensor(ts, dtype=torch.float32, device=device)
     latent = noise.clone().float().contiguous()
     seq_len = seq_len or high.engine.seq_len
-    fs = FlowSolver(sig, solver)
+    fs = FlowSolver(sig, solver, lincomb=lincomb_hip)
     kw = {} if y is None else {"y": [y]}
+    cfg_par = layout is not None and layout.cfg_size == 2
     for i in range(sampling_steps):
         hi = ts[i] >= boundary * 1000
         model, g = (high, guide_scale[1]) if hi else (low, guide_scale[0])
-        eps_c = model([latent], t=t_dev[i:i + 1], context=[context], seq_len=seq_len, **kw)[0]
-        eps_u = model([latent], t=t_dev[i:i + 1], context=[context_null], seq_len=seq_len, **kw)[0]
+        if cfg_par:
+            mine = call_branch(model, i, layout.branch, [latent], t_dev[i:i + 1],
+                               [context if layout.branch == 0 else context_null], seq_len, **kw)[0]
+            eps_c, eps_u = layout.exchange(mine.contiguous())
+        else:
+            eps_c = model([latent], t=t_dev[i:i + 1], context=[context], seq_len=seq_len, **kw)[0]
+            eps_u = model([latent], t=t_dev[i:i + 1], context=[context_null], seq_len=seq_len, **kw)[0]
         v = lincomb_hip([1.0 - g, g], [eps_u.contiguous(), eps_c.contiguous()])
         latent = fs.step(i, latent, v)
     return latent

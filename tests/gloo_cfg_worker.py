@@ -74,6 +74,28 @@ def run(layout, steps, solver):
     return lat, m.engine.calls, (m.cnt, list(m.accumulated_err), list(m.accumulated_steps))
 
 
+def run22(layout, steps):
+    """Wan2.2: two experts of one class (class-shared MagCache state, residual handed across engines), t2v gates"""
+    from magcache_amd import wan22
+
+    class HostEngine22(HostEngine):
+        def import_residual(self, p, cached):
+            self.res[p] = cached.clone()
+
+    cls = type("HostModel22", (HostModel,), {})
+    hi, lo = cls(), cls()
+    hi.engine, lo.engine = HostEngine22(), HostEngine22()
+    shift, boundary = 12.0, 0.875
+    split = wan22.high_noise_steps(shift, steps, boundary)
+    wan22.init_magcache(hi, wan22.table_without_pad("wan2.2_t2v_A14B"), steps, 0.12, 2, 0.2, split_steps=split, mode="t2v")
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(16, 2, 4, 6, generator=g)
+    ctx, ctxn = torch.randn(7, 4, generator=g), torch.randn(5, 4, generator=g)
+    lat = wan22.sample(hi, lo, noise, ctx, ctxn, boundary, sampling_steps=steps, shift=shift, guide_scale=(3.0, 4.0),
+                       layout=layout, lincomb=lincomb_host)
+    return lat, hi.engine.calls + lo.engine.calls, (int(cls.cnt), list(cls.accumulated_err), list(cls.accumulated_steps))
+
+
 def main():
     out_path = sys.argv[1]
     dist.init_process_group("gloo")
@@ -87,6 +109,11 @@ def main():
         res[solver] = dict(equal=bool(torch.equal(got, want)), calls_match=(calls_par == mine),
                            skipped=sum(1 for c in calls_par if c[1] == MC_MODE_SKIP), state_par=state_par,
                            state_seq=state_seq)
+    want, calls_seq, state_seq = run22(None, 20)
+    got, calls_par, state_par = run22(layout, 20)
+    mine = sorted(c for c in calls_seq if c[0] == layout.branch)
+    res["wan22"] = dict(equal=bool(torch.equal(got, want)), calls_match=(sorted(calls_par) == mine),
+                        skipped=sum(1 for c in calls_par if c[1] == MC_MODE_SKIP), state_par=state_par, state_seq=state_seq)
     gathered = [None] * world
     dist.all_gather_object(gathered, res)
     if rank == 0:

@@ -46,3 +46,5 @@ def test_cfg_parallel_sampler_gloo(tmp_path, world, port):
             assert x[solver]["calls_match"], x
             assert x[solver]["skipped"] > 0, x
             assert x[solver]["state_par"][0] == 0 == x[solver]["state_seq"][0]   # cnt reset at the end (:306-311)
+        w = x["wan22"]      # Wan2.2 two-expert loop under the same layout (wan22.call_branch)
+        assert w["equal"] and w["calls_match"] and w["skipped"] > 0 and w["state_par"] == w["state_seq"], x
