@@ -9,13 +9,16 @@
 //   x    fp32 [S_pad, d]    joint residual stream.  Row order = the family's attention order: FLUX [text ; image],
 //                           HunyuanVideo [image ; text] -- the two streams of a double block are row ranges of it,
 //                           so the single blocks need no concatenation (reference cat: flux :389, hunyuan :122)
-//   x0   bf16 [img, d]      ori_hidden_states / ori_img (flux :351, hunyuan :104) for the residual and the skip path
+//   x0   bf16 [S_pad, d]    ori_hidden_states / ori_img (flux :351, hunyuan :104) for the residual and the skip path;
+//                           joint row index like x (only the image rows are meaningful)
 //   xn   bf16 [S_pad, d]    LayerNorm + modulation output (GEMM operand)
 //   qkv  bf16 [S_pad, 3d]   q | k | v of the joint sequence (attention reads it in place, strided)
 //   am   bf16 [S_pad, 5d]   columns [0,d): attention output; [d,5d): GELU(MLP-in) -- exactly the operand of the
 //                           single block's fused output projection (cat([attn, mlp]) upstream) with K = 5d
 //   emod fp32               every block's modulation vector, produced by ONE bf16-weight GEMV over silu(vec)
-//   residual0/1 fp32 [img, d]   MagCache residual cache (+ the previous one in calibration mode)
+//   residual0/1 fp32 [S_pad, d] MagCache residual cache (+ the previous one in calibration mode), joint row index: the
+//                           capture is the epilogue of the LAST block's output GEMM (R = x_new - x0 per row); the image
+//                           rows are the cache, the text rows are scratch
 // GEMMs over one stream use the exact row count (the 256^2 kernel guards a partial last tile), so neighbouring
 // rows of the other stream are never touched.
 #include <hip/hip_runtime.h>
@@ -121,7 +124,8 @@ struct mc_mmdit {
   T* buf(const char* name) const {
     return reinterpret_cast<T*>(ws + bufs.find(name)->second.off);
   }
-  float* residual(int i) const { return buf<float>(i ? "residual1" : "residual0"); }
+  float* residual_joint(int i) const { return buf<float>(i ? "residual1" : "residual0"); }
+  float* residual(int i) const { return residual_joint(i) + (size_t)img0 * d; }   // image rows
   size_t mod_double(int blk, int stream) const { return ((size_t)blk * 2 + stream) * 6 * d; }
   size_t mod_single(int blk) const { return (size_t)cfg.n_double * 12 * d + (size_t)blk * 3 * d; }
   size_t mod_final() const { return (size_t)cfg.n_double * 12 * d + (size_t)cfg.n_single * 3 * d; }
@@ -337,7 +341,7 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
   const size_t Sp = e->Sp, Li = e->Li;
   const size_t Ltp = align_up(e->Lt, 256);
   add_buf(e, cur, "x", Sp * d * 4);
-  add_buf(e, cur, "x0", Li * d * 2);
+  add_buf(e, cur, "x0", Sp * d * 2);
   add_buf(e, cur, "xn", Sp * d * 2);
   add_buf(e, cur, "qkv", Sp * 3 * d * 2);
   add_buf(e, cur, "am", Sp * 5 * d * 2);               // also the fp32 [img, d] head operand after the last block
@@ -347,8 +351,8 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
   add_buf(e, cur, "emod", e->mod_rows * 4);
   add_buf(e, cur, "vecs", 16 * d * 4 + (size_t)c.txt_dim * 4 + 1024);   // sinusoids, hidden vectors, vec, c, gates
   add_buf(e, cur, "head_tokens", Li * 64 * 4);
-  add_buf(e, cur, "residual0", Li * d * 4);
-  if (c.calibration) add_buf(e, cur, "residual1", Li * d * 4);
+  add_buf(e, cur, "residual0", Sp * d * 4);
+  if (c.calibration) add_buf(e, cur, "residual1", Sp * d * 4);
   add_buf(e, cur, "calib_partial", 1024 * 4 * 8);
   add_buf(e, cur, "calib_sums", 64);
   add_buf(e, cur, "calib_stats", 64);
@@ -378,11 +382,12 @@ mc_status mc_mmdit_set_workspace(mc_mmdit* e, void* ws_dev, size_t bytes) {
 mc_status mc_mmdit_buffer_info(const mc_mmdit* e, const char* name, size_t* offset, size_t* bytes) {
   if (!e || !name) return fail(MC_EINVAL, "null argument");
   std::string n(name);
-  if (n == "residual") n = e->res_cur ? "residual1" : "residual0";
+  const bool res = (n == "residual");      // the image rows of the slot that holds the cache
+  if (res) n = e->res_cur ? "residual1" : "residual0";
   auto it = e->bufs.find(n);
   if (it == e->bufs.end()) return fail(MC_EINVAL, "unknown buffer '%s'", name);
-  if (offset) *offset = it->second.off;
-  if (bytes) *bytes = it->second.bytes;
+  if (offset) *offset = it->second.off + (res ? (size_t)e->img0 * e->d * 4 : 0);
+  if (bytes) *bytes = res ? (size_t)e->Li * e->d * 4 : it->second.bytes;
   return MC_OK;
 }
 
@@ -549,7 +554,10 @@ mc_status stream_pre_attn(const mc_mmdit* e, const Stream& w, const float* mod, 
 }
 
 // ... and after it: output projection (+gated residual), LN + modulate, MLP (+gated residual)
-mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod, int row0, int rows, hipStream_t s) {
+// capture_to != null (image stream of the LAST block when there are no single blocks): MagCache residual capture
+// fused into the MLP-out epilogue, R = x_new - x0
+mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod, int row0, int rows, hipStream_t s,
+                           float* capture_to = nullptr) {
   const int d = e->d;
   float* x = e->buf<float>("x") + (size_t)row0 * d;
   bf16_t* xn = e->buf<bf16_t>("xn") + (size_t)row0 * d;
@@ -563,7 +571,13 @@ mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod,
   HIP_TRY(mc::launch_gemm_bf16(f1, mc::EPI_GELU_BF16, s));
   mc::GemmParams f2 = gp(am + d, 5 * d, w.w2, 4 * d, w.b2, rows, d, 4 * d);
   f2.X = x; f2.ldx = d; f2.gate = mod + 5 * d;
-  HIP_TRY(mc::launch_gemm_bf16(f2, mc::EPI_RESID_GATE, s));
+  if (capture_to) {
+    f2.X0 = e->buf<bf16_t>("x0") + (size_t)row0 * d; f2.ldx0 = d;
+    f2.R = capture_to + (size_t)row0 * d; f2.ldr = d;
+    HIP_TRY(mc::launch_gemm_bf16(f2, mc::EPI_RESID_CAPTURE, s));
+  } else {
+    HIP_TRY(mc::launch_gemm_bf16(f2, mc::EPI_RESID_GATE, s));
+  }
   return MC_OK;
 }
 
@@ -586,7 +600,8 @@ extern "C" mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double 
   if (mode == MC_MODE_CALIB && !c.calibration) return fail(MC_ESTATE, "engine was created without calibration");
   const int d = e->d, Li = e->Li, Lt = e->Lt, S = e->S, Sp = e->Sp;
   float* x = e->buf<float>("x");
-  bf16_t* x0 = e->buf<bf16_t>("x0");
+  bf16_t* x0j = e->buf<bf16_t>("x0");                 // joint row index
+  bf16_t* x0 = x0j + (size_t)e->img0 * e->d;          // image rows
   bf16_t* xn = e->buf<bf16_t>("xn");
   bf16_t* qkv = e->buf<bf16_t>("qkv");
   bf16_t* am = e->buf<bf16_t>("am");
@@ -641,6 +656,9 @@ extern "C" mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double 
       if (hy) MC_TRY(run_refiner(e, txt_dev, txt_valid, vecs, s));
     }
     const int n_valid = hy ? Li + txt_valid : S;
+    // MagCache residual capture (cur_residual = hidden_states - ori_hidden_states, flux :428, hunyuan :140) is the
+    // epilogue of the last block's output GEMM
+    const int dst = (mode == MC_MODE_CALIB && e->have_res) ? 1 - e->res_cur : e->res_cur;
     // ---- double-stream blocks
     for (int i = 0; i < c.n_double; ++i) {
       const float* mi = emod + e->mod_double(i, 0);
@@ -648,7 +666,8 @@ extern "C" mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double 
       MC_TRY(stream_pre_attn(e, e->dimg[i], mi, e->img0, Li, s));
       MC_TRY(stream_pre_attn(e, e->dtxt[i], mt, e->txt0, Lt, s));
       MC_TRY(joint_attention(e, Sp, n_valid, s));
-      MC_TRY(stream_post_attn(e, e->dimg[i], mi, e->img0, Li, s));
+      MC_TRY(stream_post_attn(e, e->dimg[i], mi, e->img0, Li, s,
+                              (c.n_single == 0 && i == c.n_double - 1) ? e->residual_joint(dst) : nullptr));
       MC_TRY(stream_post_attn(e, e->dtxt[i], mt, e->txt0, Lt, s));
     }
     // ---- single-stream blocks on the joint sequence
@@ -666,11 +685,13 @@ extern "C" mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double 
       MC_TRY(joint_attention(e, Sp, n_valid, s));
       mc::GemmParams o = gp(am, 5 * d, g.w_out, 5 * d, g.b_out, S, d, 5 * d);
       o.X = x; o.ldx = d; o.gate = m + 2 * d;
-      HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+      if (i == c.n_single - 1) {   // last block: the text rows of R are scratch (they subtract unset x0 rows)
+        o.X0 = x0j; o.ldx0 = d; o.R = e->residual_joint(dst); o.ldr = d;
+        HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_CAPTURE, s));
+      } else {
+        HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+      }
     }
-    // ---- MagCache residual capture: cur_residual = hidden_states - ori_hidden_states   (flux :428, hunyuan :140)
-    const int dst = (mode == MC_MODE_CALIB && e->have_res) ? 1 - e->res_cur : e->res_cur;
-    HIP_TRY(mc::launch_residual_sub(x + (size_t)e->img0 * d, d, x0, d, e->residual(dst), d, Li, d, s));
     if (mode == MC_MODE_CALIB && e->have_res) {
       HIP_TRY(mc::launch_calib_stats(e->residual(dst), d, e->residual(e->res_cur), d, Li, d,
                                      e->buf<double>("calib_partial"), 1024, e->buf<double>("calib_sums"),
