@@ -48,6 +48,8 @@ typedef struct {
   int latent_f, latent_h, latent_w; /* HunyuanVideo latent [16, F, H, W]; FLUX: ignored */
   int refiner_depth;        /* HunyuanVideo txt_in blocks (2); FLUX: 0 */
   int calibration;          /* reserve the second residual slot calibration mode needs */
+  int sp_rank, sp_size;     /* sequence parallel: this rank owns image tokens [rank, rank+1) * img_tokens / sp_size; the
+                               text tokens are replicated.  0, 1 (or 0, 0) for one GPU */
 } mc_mmdit_config;
 
 mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out);
@@ -75,6 +77,18 @@ mc_status mc_mmdit_set_rope(mc_mmdit* e, const float* cos_dev, const float* sin_
  *   out_dev    FLUX: [img_tokens, out_channels] fp32; HunyuanVideo: [16, F, H, W] fp32 */
 mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double timestep, double guidance, const float* txt_dev,
                            int txt_valid, const float* vec_dev, mc_mode mode, float* out_dev, mc_stream stream);
+/* The same forward in phases, for sequence parallelism: after every mc_mmdit_block_pre the caller all-gathers
+ * "kv_gather" ([sp_size][Lr_pad][2*dim] bf16; this rank's image K|V rows were put into slot sp_rank) with its own
+ * communicator (torch.distributed / RCCL), then calls mc_mmdit_block_post, which attends the local queries over all
+ * image shards and then the (replicated) text keys, merging the two by their log-sum-exp.  Blocks: 0..n_double-1
+ * double-stream, then the single-stream ones; skipped steps (MC_MODE_SKIP) go begin -> end.  mc_mmdit_end: see
+ * mmdit_engine.cpp for where the sharded output lands; img_dev / the RoPE tables are always the FULL inputs. */
+mc_status mc_mmdit_begin(mc_mmdit* e, const float* img_dev, double timestep, double guidance, const float* txt_dev,
+                         int txt_valid, const float* vec_dev, mc_mode mode, mc_stream stream);
+mc_status mc_mmdit_block_pre(mc_mmdit* e, int block, mc_stream stream);
+mc_status mc_mmdit_block_post(mc_mmdit* e, int block, mc_stream stream);
+mc_status mc_mmdit_end(mc_mmdit* e, float* out_dev, mc_stream stream);
+mc_status mc_mmdit_unpatchify(mc_mmdit* e, const float* tokens_dev, float* out_dev, mc_stream stream);
 /* norm_ratio, norm_std, cos_dis of the last MC_MODE_CALIB forward (host sync) */
 mc_status mc_mmdit_calib_stats(mc_mmdit* e, float out[3], mc_stream stream);
 mc_status mc_mmdit_state_reset(mc_mmdit* e);

@@ -93,6 +93,11 @@ SIGNATURES = {
     "mc_mmdit_weights_missing": (_i, [_vp, C.c_char_p, _sz]),
     "mc_mmdit_set_rope": (_i, [_vp, _vp, _vp, _i, _vp]),
     "mc_mmdit_forward": (_i, [_vp, _vp, _d, _d, _vp, _i, _vp, _i, _vp, _vp]),
+    "mc_mmdit_begin": (_i, [_vp, _vp, _d, _d, _vp, _i, _vp, _i, _vp]),
+    "mc_mmdit_block_pre": (_i, [_vp, _i, _vp]),
+    "mc_mmdit_block_post": (_i, [_vp, _i, _vp]),
+    "mc_mmdit_end": (_i, [_vp, _vp, _vp]),
+    "mc_mmdit_unpatchify": (_i, [_vp, _vp, _vp, _vp]),
     "mc_mmdit_calib_stats": (_i, [_vp, C.POINTER(C.c_float), _vp]),
     "mc_mmdit_state_reset": (_i, [_vp]),
 }
@@ -101,7 +106,7 @@ SIGNATURES = {
 class McMmditConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("family", "dim", "num_heads", "n_double", "n_single", "in_channels", "out_channels",
                                        "txt_dim", "txt_len", "vec_dim", "img_tokens", "latent_f", "latent_h", "latent_w",
-                                       "refiner_depth", "calibration")]
+                                       "refiner_depth", "calibration", "sp_rank", "sp_size")]
 
 
 MC_FAMILY_FLUX, MC_FAMILY_HUNYUAN = 0, 1

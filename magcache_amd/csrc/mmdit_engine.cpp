@@ -103,7 +103,11 @@ mc::GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, const fl
 
 struct mc_mmdit {
   mc_mmdit_config cfg;
-  int d, H, Li, Lt, S, Sp, Kin, Kp, img0, txt0, out_feat;
+  int d, H, Li, Lt, S, Sp, Kin, Kp, img0, txt0, out_feat;   // Li = image tokens of THIS rank; S = Lt + Li
+  int P = 1, rank = 0, tok0 = 0, Lrp = 0;                    // sequence parallel: image shard [tok0, tok0 + Li)
+  mc_mode mode = MC_MODE_FULL;                               // of the forward in progress (begin .. end)
+  int txt_valid = 0, dst = 0;
+  bool begun = false;
   size_t mod_rows = 0;  // rows of the fused modulation matrix
   std::vector<Stream> dimg, dtxt;
   std::vector<Single> singles;
@@ -206,7 +210,15 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
   }
   mc_mmdit* e = new mc_mmdit();
   e->cfg = c;
-  e->d = c.dim; e->H = c.num_heads; e->Li = c.img_tokens; e->Lt = c.txt_len;
+  e->P = c.sp_size > 0 ? c.sp_size : 1;
+  e->rank = c.sp_rank;
+  if (e->rank < 0 || e->rank >= e->P || (c.img_tokens % e->P) != 0) {
+    delete e;
+    return fail(MC_EINVAL, "bad sequence-parallel geometry: rank %d of %d, %d image tokens", c.sp_rank, c.sp_size, c.img_tokens);
+  }
+  e->d = c.dim; e->H = c.num_heads; e->Li = c.img_tokens / e->P; e->Lt = c.txt_len;
+  e->tok0 = e->rank * e->Li;
+  e->Lrp = (int)align_up(e->Li, 256);
   e->S = e->Li + e->Lt;
   e->Sp = (int)align_up(e->S, 256);
   e->Kin = hy ? c.in_channels * 4 : c.in_channels;
@@ -343,7 +355,11 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
   add_buf(e, cur, "x", Sp * d * 4);
   add_buf(e, cur, "x0", Sp * d * 2);
   add_buf(e, cur, "xn", Sp * d * 2);
-  add_buf(e, cur, "qkv", Sp * 3 * d * 2);
+  add_buf(e, cur, "qkv", (Sp + 64) * 3 * d * 2);        // + one key tile of slack behind the text rows
+  if (e->P > 1) {
+    add_buf(e, cur, "kv_gather", (size_t)e->P * e->Lrp * 2 * d * 2);   // image K|V of every rank
+    add_buf(e, cur, "attn_lse", (size_t)e->H * Sp * 4);
+  }
   add_buf(e, cur, "am", Sp * 5 * d * 2);               // also the fp32 [img, d] head operand after the last block
   add_buf(e, cur, "tokens", align_up(Li, 256) * e->Kp * 2);
   add_buf(e, cur, "txt_in", Ltp * c.txt_dim * 2);
@@ -454,9 +470,14 @@ int mc_mmdit_weights_missing(const mc_mmdit* e, char* buf, size_t buflen) {
 mc_status mc_mmdit_set_rope(mc_mmdit* e, const float* cos_dev, const float* sin_dev, int n_rows, mc_stream stream) {
   if (!e || !cos_dev || !sin_dev) return fail(MC_EINVAL, "null argument");
   const bool hy = e->cfg.family == MC_FAMILY_HUNYUAN;
-  const int want = hy ? e->Li : e->S;
+  const int want = hy ? e->cfg.img_tokens : e->Lt + e->cfg.img_tokens;   // the table of the FULL sequence
   if (n_rows != want) return fail(MC_EINVAL, "RoPE table has %d rows, %d expected", n_rows, want);
-  HIP_TRY(mc::launch_rope_table_from_cos_sin(cos_dev, sin_dev, 128, n_rows, e->cs, (hipStream_t)stream));
+  hipStream_t s = (hipStream_t)stream;
+  // image rows of this rank's shard (global token positions), then -- FLUX -- the text rows
+  const size_t img_src = (size_t)(hy ? 0 : e->Lt) + e->tok0;
+  HIP_TRY(mc::launch_rope_table_from_cos_sin(cos_dev + img_src * 128, sin_dev + img_src * 128, 128, e->Li,
+                                             e->cs + (size_t)e->img0 * 128, s));
+  if (!hy) HIP_TRY(mc::launch_rope_table_from_cos_sin(cos_dev, sin_dev, 128, e->Lt, e->cs + (size_t)e->txt0 * 128, s));
   return MC_OK;
 }
 
@@ -583,39 +604,44 @@ mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod,
 
 }  // namespace
 
-extern "C" mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double timestep, double guidance,
-                                      const float* txt_dev, int txt_valid, const float* vec_dev, mc_mode mode,
-                                      float* out_dev, mc_stream stream_) {
+// ================================================================================================ forward, in phases
+// begin (conditioning, embeds) -> for every block: block_pre, [caller: all-gather of the image K|V shards], block_post
+// -> end (final layer).  mc_mmdit_forward runs them back to back on one GPU.
+extern "C" {
+
+mc_status mc_mmdit_begin(mc_mmdit* e, const float* img_dev, double timestep, double guidance, const float* txt_dev,
+                         int txt_valid, const float* vec_dev, mc_mode mode, mc_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!e) return fail(MC_EINVAL, "null engine");
   if (!e->ws) return fail(MC_ESTATE, "workspace not set (mc_mmdit_set_workspace)");
   for (auto& kv : e->slots)
     if (!kv.second.loaded) return fail(MC_ESTATE, "weight '%s' was never set", kv.first.c_str());
-  if (!img_dev || !txt_dev || !vec_dev || !out_dev) return fail(MC_EINVAL, "null input / output");
+  if (!img_dev || !txt_dev || !vec_dev) return fail(MC_EINVAL, "null input");
   const mc_mmdit_config& c = e->cfg;
   const bool hy = c.family == MC_FAMILY_HUNYUAN;
   if (hy && (txt_valid <= 0 || txt_valid > e->Lt)) return fail(MC_EINVAL, "txt_valid %d out of (0, %d]", txt_valid, e->Lt);
   if (mode == MC_MODE_SKIP && !e->have_res)
     return fail(MC_ESTATE, "skip requested but the residual cache is empty");
   if (mode == MC_MODE_CALIB && !c.calibration) return fail(MC_ESTATE, "engine was created without calibration");
+  if (mode == MC_MODE_CALIB && e->P > 1) return fail(MC_ESTATE, "calibration runs on one GPU in this engine");
+  e->mode = mode;
+  e->txt_valid = hy ? txt_valid : e->Lt;
+  e->begun = true;
+  e->dst = (mode == MC_MODE_CALIB && e->have_res) ? 1 - e->res_cur : e->res_cur;
   const int d = e->d, Li = e->Li, Lt = e->Lt, S = e->S, Sp = e->Sp;
   float* x = e->buf<float>("x");
-  bf16_t* x0j = e->buf<bf16_t>("x0");                 // joint row index
-  bf16_t* x0 = x0j + (size_t)e->img0 * e->d;          // image rows
-  bf16_t* xn = e->buf<bf16_t>("xn");
+  bf16_t* x0 = e->buf<bf16_t>("x0") + (size_t)e->img0 * d;   // image rows of the joint-indexed copy
   bf16_t* qkv = e->buf<bf16_t>("qkv");
-  bf16_t* am = e->buf<bf16_t>("am");
   float* vecs = e->buf<float>("vecs");
   float* emod = e->buf<float>("emod");
   float *sin_t = vecs, *sin_g = vecs + d, *hid = vecs + 2 * d, *vec = vecs + 3 * d;
   if (!e->pads_clean) {
     // rows [S, S_pad) are read by the attention kernel (masked keys, ignored queries) and never written by a GEMM
-    HIP_TRY(hipMemsetAsync(qkv + (size_t)S * 3 * d, 0, (size_t)(Sp - S) * 3 * d * 2, s));
+    HIP_TRY(hipMemsetAsync(qkv, 0, e->bufs["qkv"].bytes, s));
     HIP_TRY(hipMemsetAsync(x + (size_t)S * d, 0, (size_t)(Sp - S) * d * 4, s));
-    if (hy) HIP_TRY(hipMemsetAsync(qkv, 0, (size_t)Sp * 3 * d * 2, s));   // refiner: rows [Lt, Ltp) of its own pass
+    if (e->P > 1) HIP_TRY(hipMemsetAsync(e->buf<bf16_t>("kv_gather"), 0, e->bufs["kv_gather"].bytes, s));
     e->pads_clean = true;
   }
-
   // ---- conditioning vector: time + guidance + pooled text   (flux :303-313, hunyuan :53-67)
   HIP_TRY(mc::launch_sinusoid(nullptr, timestep, 256, sin_t, s));
   HIP_TRY(mc::launch_sinusoid(nullptr, guidance, 256, sin_g, s));
@@ -629,99 +655,193 @@ extern "C" mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double 
   } else {
     HIP_TRY(mc::launch_gemv_bf16w(e->w_mod, vec, e->b_mod, emod, (int)e->mod_rows, d, 1, 0, 0, s));
   }
-
-  // ---- image embedding: x_img = x_embedder(tokens) / img_in(latent); ori copy for MagCache
+  // ---- image embedding of THIS rank's tokens: x_img = x_embedder(tokens) / img_in(latent); ori copy for MagCache
   {
     bf16_t* tokens = e->buf<bf16_t>("tokens");
     if (hy) {
       if (e->Kp != e->Kin) HIP_TRY(hipMemsetAsync(tokens, 0, (size_t)align_up(Li, 256) * e->Kp * 2, s));
-      HIP_TRY(mc::launch_patchify(img_dev, c.in_channels, c.latent_f, c.latent_h, c.latent_w, 0, Li, Li, tokens,
+      HIP_TRY(mc::launch_patchify(img_dev, c.in_channels, c.latent_f, c.latent_h, c.latent_w, e->tok0, Li, Li, tokens,
                                   e->Kp, s));
     } else {
-      HIP_TRY(mc::launch_cast_pad_bf16(img_dev, e->Kin, Li, Li, e->Kin, tokens, e->Kp, s));
+      HIP_TRY(mc::launch_cast_pad_bf16(img_dev + (size_t)e->tok0 * e->Kin, e->Kin, Li, Li, e->Kin, tokens, e->Kp, s));
     }
     mc::GemmParams p = gp(tokens, e->Kp, e->w_in, e->Kp, e->b_in, Li, d, e->Kp);
     p.X = x + (size_t)e->img0 * d; p.ldx = d; p.X0out = x0; p.ldx0out = d; p.m_valid = Li;
     HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
   }
-
   if (mode != MC_MODE_SKIP) {
-    // ---- text embedding -> text rows of x   (flux :314; hunyuan :72-78 incl. the token refiner)
-    {
-      bf16_t* tin = e->buf<bf16_t>("txt_in");
-      HIP_TRY(mc::launch_cast_pad_bf16(txt_dev, c.txt_dim, Lt, Lt, c.txt_dim, tin, c.txt_dim, s));
-      mc::GemmParams p = gp(tin, c.txt_dim, e->w_ctx, c.txt_dim, e->b_ctx, Lt, d, c.txt_dim);
-      p.X = x + (size_t)e->txt0 * d; p.ldx = d; p.X0out = e->buf<bf16_t>("txt_e"); p.ldx0out = d; p.m_valid = Lt;
-      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
-      if (hy) MC_TRY(run_refiner(e, txt_dev, txt_valid, vecs, s));
+    // ---- text embedding -> text rows of x   (flux :314; hunyuan :72-78 incl. the token refiner); replicated per rank
+    bf16_t* tin = e->buf<bf16_t>("txt_in");
+    HIP_TRY(mc::launch_cast_pad_bf16(txt_dev, c.txt_dim, Lt, Lt, c.txt_dim, tin, c.txt_dim, s));
+    mc::GemmParams p = gp(tin, c.txt_dim, e->w_ctx, c.txt_dim, e->b_ctx, Lt, d, c.txt_dim);
+    p.X = x + (size_t)e->txt0 * d; p.ldx = d; p.X0out = e->buf<bf16_t>("txt_e"); p.ldx0out = d; p.m_valid = Lt;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
+    if (hy) MC_TRY(run_refiner(e, txt_dev, txt_valid, vecs, s));
+  }
+  return MC_OK;
+}
+
+// block index: 0 .. n_double-1 double-stream blocks, then the single-stream blocks
+mc_status mc_mmdit_block_pre(mc_mmdit* e, int blk, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e || !e->begun) return fail(MC_ESTATE, "mc_mmdit_begin must run first");
+  const mc_mmdit_config& c = e->cfg;
+  if (blk < 0 || blk >= c.n_double + c.n_single) return fail(MC_EINVAL, "block %d out of range", blk);
+  const int d = e->d, Li = e->Li, Lt = e->Lt, S = e->S;
+  const float* emod = e->buf<float>("emod");
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  if (blk < c.n_double) {
+    MC_TRY(stream_pre_attn(e, e->dimg[blk], emod + e->mod_double(blk, 0), e->img0, Li, s));
+    MC_TRY(stream_pre_attn(e, e->dtxt[blk], emod + e->mod_double(blk, 1), e->txt0, Lt, s));
+  } else {
+    const int i = blk - c.n_double;
+    const Single& g = e->singles[i];
+    const float* m = emod + e->mod_single(i);
+    float* x = e->buf<float>("x");
+    bf16_t* xn = e->buf<bf16_t>("xn");
+    bf16_t* am = e->buf<bf16_t>("am");
+    HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, m + d, m, 0, 1e-6f, xn, d, nullptr, 0, S, d, s));
+    mc::GemmParams p = gp(xn, d, g.w_in, d, g.b_in, S, 3 * d, d);
+    p.Cb = qkv; p.ldc = 3 * d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    mc::GemmParams q = gp(xn, d, g.w_in + (size_t)3 * d * d, d, g.b_in + 3 * d, S, 4 * d, d);
+    q.Cb = am + d; q.ldc = 5 * d;
+    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_GELU_BF16, s));
+    HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, g.qn, g.kn, 1e-6f, e->cs, 0, S, e->H, s));
+  }
+  if (e->P > 1) {
+    // this rank's image K|V rows -> its slot of the gather buffer ([P][Lr_pad][2d]; the caller all-gathers it)
+    bf16_t* slot = e->buf<bf16_t>("kv_gather") + (size_t)e->rank * e->Lrp * 2 * d;
+    HIP_TRY(hipMemcpy2DAsync(slot, (size_t)2 * d * 2, qkv + (size_t)e->img0 * 3 * d + d, (size_t)3 * d * 2, (size_t)2 * d * 2,
+                             Li, hipMemcpyDeviceToDevice, s));
+  }
+  return MC_OK;
+}
+
+mc_status mc_mmdit_block_post(mc_mmdit* e, int blk, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e || !e->begun) return fail(MC_ESTATE, "mc_mmdit_begin must run first");
+  const mc_mmdit_config& c = e->cfg;
+  const int nb = c.n_double + c.n_single;
+  if (blk < 0 || blk >= nb) return fail(MC_EINVAL, "block %d out of range", blk);
+  const int d = e->d, Li = e->Li, Lt = e->Lt, S = e->S, Sp = e->Sp;
+  const float* emod = e->buf<float>("emod");
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  // ---- joint attention of the local queries over [all image tokens ; valid text tokens]
+  if (e->P == 1) {
+    const bool hy = c.family == MC_FAMILY_HUNYUAN;
+    MC_TRY(joint_attention(e, Sp, hy ? Li + e->txt_valid : S, s));
+  } else {
+    // (1) the image keys of every rank (gathered shards of Li rows), (2) the text keys (replicated, local rows of qkv),
+    // merged with the log-sum-exp of (1) in the kernel epilogue
+    mc::AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.Q = qkv; a.ldq = 3 * d;
+    a.O = e->buf<bf16_t>("am"); a.ldo = 5 * d;
+    a.Lq_pad = Sp; a.n_heads = e->H; a.scale = 1.0f / std::sqrt(128.0f);
+    bf16_t* kvg = e->buf<bf16_t>("kv_gather");
+    mc::AttnParams i1 = a;
+    i1.K = kvg; i1.ldk = 2 * d; i1.k_shard_stride = (long)e->Lrp * 2 * d;
+    i1.V = kvg + d; i1.ldv = 2 * d; i1.v_shard_stride = (long)e->Lrp * 2 * d;
+    i1.shard_rows = e->Lrp; i1.shard_valid = Li; i1.n_shards = e->P;
+    i1.lse_out = e->buf<float>("attn_lse");
+    HIP_TRY(mc::launch_attention(i1, s));
+    mc::AttnParams t2 = a;
+    t2.K = qkv + (size_t)e->txt0 * 3 * d + d; t2.ldk = 3 * d;
+    t2.V = qkv + (size_t)e->txt0 * 3 * d + 2 * d; t2.ldv = 3 * d;
+    t2.shard_rows = (int)align_up(Lt, 64); t2.shard_valid = e->txt_valid; t2.n_shards = 1;
+    t2.lse_in = e->buf<float>("attn_lse");
+    HIP_TRY(mc::launch_attention(t2, s));
+  }
+  const bool last = (blk == nb - 1);
+  if (blk < c.n_double) {
+    MC_TRY(stream_post_attn(e, e->dimg[blk], emod + e->mod_double(blk, 0), e->img0, Li, s,
+                            last ? e->residual_joint(e->dst) : nullptr));
+    MC_TRY(stream_post_attn(e, e->dtxt[blk], emod + e->mod_double(blk, 1), e->txt0, Lt, s));
+  } else {
+    const int i = blk - c.n_double;
+    const Single& g = e->singles[i];
+    const float* m = emod + e->mod_single(i);
+    mc::GemmParams o = gp(e->buf<bf16_t>("am"), 5 * d, g.w_out, 5 * d, g.b_out, S, d, 5 * d);
+    o.X = e->buf<float>("x"); o.ldx = d; o.gate = m + 2 * d;
+    if (last) {   // MagCache residual capture (flux :428, hunyuan :140); the text rows of R are scratch
+      o.X0 = e->buf<bf16_t>("x0"); o.ldx0 = d; o.R = e->residual_joint(e->dst); o.ldr = d;
+      HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_CAPTURE, s));
+    } else {
+      HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
     }
-    const int n_valid = hy ? Li + txt_valid : S;
-    // MagCache residual capture (cur_residual = hidden_states - ori_hidden_states, flux :428, hunyuan :140) is the
-    // epilogue of the last block's output GEMM
-    const int dst = (mode == MC_MODE_CALIB && e->have_res) ? 1 - e->res_cur : e->res_cur;
-    // ---- double-stream blocks
-    for (int i = 0; i < c.n_double; ++i) {
-      const float* mi = emod + e->mod_double(i, 0);
-      const float* mt = emod + e->mod_double(i, 1);
-      MC_TRY(stream_pre_attn(e, e->dimg[i], mi, e->img0, Li, s));
-      MC_TRY(stream_pre_attn(e, e->dtxt[i], mt, e->txt0, Lt, s));
-      MC_TRY(joint_attention(e, Sp, n_valid, s));
-      MC_TRY(stream_post_attn(e, e->dimg[i], mi, e->img0, Li, s,
-                              (c.n_single == 0 && i == c.n_double - 1) ? e->residual_joint(dst) : nullptr));
-      MC_TRY(stream_post_attn(e, e->dtxt[i], mt, e->txt0, Lt, s));
-    }
-    // ---- single-stream blocks on the joint sequence
-    for (int i = 0; i < c.n_single; ++i) {
-      const Single& g = e->singles[i];
-      const float* m = emod + e->mod_single(i);
-      HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, m + d, m, 0, 1e-6f, xn, d, nullptr, 0, S, d, s));
-      mc::GemmParams p = gp(xn, d, g.w_in, d, g.b_in, S, 3 * d, d);
-      p.Cb = qkv; p.ldc = 3 * d;
-      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
-      mc::GemmParams q = gp(xn, d, g.w_in + (size_t)3 * d * d, d, g.b_in + 3 * d, S, 4 * d, d);
-      q.Cb = am + d; q.ldc = 5 * d;
-      HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_GELU_BF16, s));
-      HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, g.qn, g.kn, 1e-6f, e->cs, 0, S, e->H, s));
-      MC_TRY(joint_attention(e, Sp, n_valid, s));
-      mc::GemmParams o = gp(am, 5 * d, g.w_out, 5 * d, g.b_out, S, d, 5 * d);
-      o.X = x; o.ldx = d; o.gate = m + 2 * d;
-      if (i == c.n_single - 1) {   // last block: the text rows of R are scratch (they subtract unset x0 rows)
-        o.X0 = x0j; o.ldx0 = d; o.R = e->residual_joint(dst); o.ldr = d;
-        HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_CAPTURE, s));
-      } else {
-        HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
-      }
-    }
-    if (mode == MC_MODE_CALIB && e->have_res) {
-      HIP_TRY(mc::launch_calib_stats(e->residual(dst), d, e->residual(e->res_cur), d, Li, d,
+  }
+  if (last) {
+    if (e->mode == MC_MODE_CALIB && e->have_res) {
+      HIP_TRY(mc::launch_calib_stats(e->residual(e->dst), d, e->residual(e->res_cur), d, Li, d,
                                      e->buf<double>("calib_partial"), 1024, e->buf<double>("calib_sums"),
                                      e->buf<float>("calib_stats"), s));
       e->have_stats = true;
     }
-    e->res_cur = dst;
+    e->res_cur = e->dst;
     e->have_res = true;
-  }
-
-  // ---- final layer on the image tokens: AdaLN (no affine) + Linear   (flux :431-432, hunyuan :144)
-  {
-    const float* mf = emod + e->mod_final();
-    const float* scale = hy ? mf + d : mf;   // hunyuan: (shift, scale); flux AdaLayerNormContinuous: (scale, shift)
-    const float* shift = hy ? mf : mf + d;
-    float* hn = reinterpret_cast<float*>(am);
-    if (mode == MC_MODE_SKIP) {
-      // hidden_states = ori + cur_residual (flux :348, hunyuan :102) folded into the LayerNorm load
-      HIP_TRY(mc::launch_ln_modulate(e->residual(e->res_cur), d, x0, d, scale, shift, 0, 1e-6f, nullptr, 0, hn, d, Li, d, s));
-    } else {
-      HIP_TRY(mc::launch_ln_modulate(x + (size_t)e->img0 * d, d, nullptr, 0, scale, shift, 0, 1e-6f, nullptr, 0, hn, d,
-                                     Li, d, s));
-    }
-    if (hy) {
-      float* ht = e->buf<float>("head_tokens");
-      HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, ht, 64, Li, e->out_feat, d, s));
-      HIP_TRY(mc::launch_unpatchify(ht, 64, c.out_channels, c.latent_f, c.latent_h, c.latent_w, 0, Li, out_dev, s));
-    } else {
-      HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, out_dev, e->out_feat, Li, e->out_feat, d, s));
-    }
   }
   return MC_OK;
 }
+
+// final layer on this rank's image tokens: AdaLN (no affine) + Linear   (flux :431-432, hunyuan :144).
+// One GPU: out_dev = FLUX [img_tokens, out_channels] / HunyuanVideo [C, F, H, W].  sp_size > 1: FLUX writes its
+// [img_tokens / P, out_channels] rows to out_dev; HunyuanVideo leaves its rows in "head_tokens" ([.., 64] fp32) for the
+// caller to gather and hand to mc_mmdit_unpatchify (out_dev may be NULL).
+mc_status mc_mmdit_end(mc_mmdit* e, float* out_dev, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e || !e->begun) return fail(MC_ESTATE, "mc_mmdit_begin must run first");
+  const mc_mmdit_config& c = e->cfg;
+  const bool hy = c.family == MC_FAMILY_HUNYUAN;
+  if (!out_dev && !(hy && e->P > 1)) return fail(MC_EINVAL, "null output");
+  const int d = e->d, Li = e->Li;
+  const float* mf = e->buf<float>("emod") + e->mod_final();
+  const float* scale = hy ? mf + d : mf;   // hunyuan: (shift, scale); flux AdaLayerNormContinuous: (scale, shift)
+  const float* shift = hy ? mf : mf + d;
+  float* hn = reinterpret_cast<float*>(e->buf<bf16_t>("am"));
+  bf16_t* x0 = e->buf<bf16_t>("x0") + (size_t)e->img0 * d;
+  if (e->mode == MC_MODE_SKIP) {
+    // hidden_states = ori + cur_residual (flux :348, hunyuan :102) folded into the LayerNorm load
+    HIP_TRY(mc::launch_ln_modulate(e->residual(e->res_cur), d, x0, d, scale, shift, 0, 1e-6f, nullptr, 0, hn, d, Li, d, s));
+  } else {
+    HIP_TRY(mc::launch_ln_modulate(e->buf<float>("x") + (size_t)e->img0 * d, d, nullptr, 0, scale, shift, 0, 1e-6f,
+                                   nullptr, 0, hn, d, Li, d, s));
+  }
+  if (hy) {
+    float* ht = e->buf<float>("head_tokens");
+    HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, ht, 64, Li, e->out_feat, d, s));
+    if (e->P == 1)
+      HIP_TRY(mc::launch_unpatchify(ht, 64, c.out_channels, c.latent_f, c.latent_h, c.latent_w, 0, Li, out_dev, s));
+  } else {
+    HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, out_dev, e->out_feat, Li, e->out_feat, d, s));
+  }
+  e->begun = false;
+  return MC_OK;
+}
+
+// HunyuanVideo, sp_size > 1: tokens_dev = the gathered head tokens [img_tokens, 64] fp32 -> out_dev [C, F, H, W]
+mc_status mc_mmdit_unpatchify(mc_mmdit* e, const float* tokens_dev, float* out_dev, mc_stream stream_) {
+  if (!e || !tokens_dev || !out_dev) return fail(MC_EINVAL, "null argument");
+  const mc_mmdit_config& c = e->cfg;
+  if (c.family != MC_FAMILY_HUNYUAN) return fail(MC_EINVAL, "FLUX returns tokens; there is nothing to unpatchify");
+  HIP_TRY(mc::launch_unpatchify(tokens_dev, 64, c.out_channels, c.latent_f, c.latent_h, c.latent_w, 0, c.img_tokens,
+                                out_dev, (hipStream_t)stream_));
+  return MC_OK;
+}
+
+mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double timestep, double guidance, const float* txt_dev,
+                           int txt_valid, const float* vec_dev, mc_mode mode, float* out_dev, mc_stream stream) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (e->P != 1) return fail(MC_ESTATE, "mc_mmdit_forward is single-GPU; drive a sharded engine through the phase calls");
+  if (!out_dev) return fail(MC_EINVAL, "null output");
+  MC_TRY(mc_mmdit_begin(e, img_dev, timestep, guidance, txt_dev, txt_valid, vec_dev, mode, stream));
+  if (mode != MC_MODE_SKIP) {
+    for (int b = 0; b < e->cfg.n_double + e->cfg.n_single; ++b) {
+      MC_TRY(mc_mmdit_block_pre(e, b, stream));
+      MC_TRY(mc_mmdit_block_post(e, b, stream));
+    }
+  }
+  return mc_mmdit_end(e, out_dev, stream);
+}
+
+}  // extern "C"

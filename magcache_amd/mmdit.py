@@ -49,7 +49,8 @@ class MMDiTEngine:
     """One MM-DiT engine on one device.  PyTorch-ROCm owns the workspace and the stream, the library the rest."""
 
     def __init__(self, family, dim, num_heads, n_double, n_single, in_channels, out_channels, txt_dim, txt_len, vec_dim,
-                 img_tokens, latent_grid=(0, 0, 0), refiner_depth=0, calibration=False, device="cuda:0"):
+                 img_tokens, latent_grid=(0, 0, 0), refiner_depth=0, calibration=False, device="cuda:0", sp_rank=0,
+                 sp_size=1):
         if not torch.cuda.is_available():
             raise RuntimeError("magcache_amd.MMDiTEngine needs a ROCm device; there is no CPU fallback")
         self.lib = _lib.load()
@@ -57,10 +58,13 @@ class MMDiTEngine:
         torch.cuda.set_device(self.device)
         self.family, self.dim, self.img_tokens, self.txt_len = family, dim, img_tokens, txt_len
         self.out_channels, self.latent_grid = out_channels, tuple(latent_grid)
+        self.sp_rank, self.sp_size, self.n_blocks = sp_rank, sp_size, n_double + n_single
+        self.tokens_per_rank = img_tokens // sp_size
         c = McMmditConfig(family=family, dim=dim, num_heads=num_heads, n_double=n_double, n_single=n_single,
                           in_channels=in_channels, out_channels=out_channels, txt_dim=txt_dim, txt_len=txt_len,
                           vec_dim=vec_dim, img_tokens=img_tokens, latent_f=latent_grid[0], latent_h=latent_grid[1],
-                          latent_w=latent_grid[2], refiner_depth=refiner_depth, calibration=int(calibration))
+                          latent_w=latent_grid[2], refiner_depth=refiner_depth, calibration=int(calibration),
+                          sp_rank=sp_rank, sp_size=sp_size)
         h = C.c_void_p()
         check(self.lib.mc_mmdit_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -112,8 +116,8 @@ class MMDiTEngine:
         return self.ws[off.value:off.value + nb.value].view(dtype)
 
     def residual(self):
-        """fp32 [img_tokens, dim] view of the cached residual (reference previous_residual / residual_cache)."""
-        return self.buffer("residual", torch.float32).view(-1, self.dim)[:self.img_tokens]
+        """fp32 [img_tokens / sp_size, dim] view of the cached residual (reference previous_residual / residual_cache)."""
+        return self.buffer("residual", torch.float32).view(-1, self.dim)[:self.tokens_per_rank]
 
     def set_rope(self, cos, sin):
         """upstream use_real tables [n, 128]; uploaded only when their CONTENT changes (constant over a sample)"""
@@ -135,6 +139,25 @@ class MMDiTEngine:
                                         _ptr(vec), mode, _ptr(out), _stream()))
         return out
 
+    # ---- the same forward in phases (sequence parallel; see MMDiTSequenceParallel)
+    def begin(self, img, timestep, guidance, txt, txt_valid, vec, mode):
+        img, txt, vec = _f32(img, self.device), _f32(txt, self.device), _f32(vec, self.device)
+        self._keep = (img, txt, vec)          # the launches are asynchronous: keep the staging tensors alive
+        check(self.lib.mc_mmdit_begin(self.h, _ptr(img), float(timestep), float(guidance), _ptr(txt), int(txt_valid),
+                                      _ptr(vec), mode, _stream()))
+
+    def block_pre(self, blk):
+        check(self.lib.mc_mmdit_block_pre(self.h, blk, _stream()))
+
+    def block_post(self, blk):
+        check(self.lib.mc_mmdit_block_post(self.h, blk, _stream()))
+
+    def end(self, out=None):
+        check(self.lib.mc_mmdit_end(self.h, _ptr(out) if out is not None else C.c_void_p(0), _stream()))
+
+    def unpatchify(self, tokens, out):
+        check(self.lib.mc_mmdit_unpatchify(self.h, _ptr(tokens), _ptr(out), _stream()))
+
     def calib_stats(self):
         out = (C.c_float * 3)()
         check(self.lib.mc_mmdit_calib_stats(self.h, out, _stream()))
@@ -142,6 +165,65 @@ class MMDiTEngine:
 
     def reset(self):
         check(self.lib.mc_mmdit_state_reset(self.h))
+
+
+class MMDiTSequenceParallel:
+    """Sequence-parallel MM-DiT forward: the IMAGE tokens are sharded across the ranks of `group` (contiguous chunks,
+    global RoPE positions), the text tokens and the conditioning are replicated, and the only data-path collective is
+    the per-block all-gather of the image K|V rows ("kv_gather", RCCL over xGMI through torch.distributed).  Each rank
+    then attends its queries over all image shards and over the text keys and merges the two partial softmaxes by their
+    log-sum-exp inside the attention kernel.  The MagCache residual cache and skip path are shard-local; the decision
+    is host arithmetic on identical state, so all ranks take the same branch."""
+
+    def __init__(self, engine, group=None):
+        import torch.distributed as dist
+        self.dist, self.e, self.group = dist, engine, group
+        self.P, self.rank = engine.sp_size, engine.sp_rank
+        assert dist.is_initialized() and dist.get_world_size(group) == self.P
+        self.inplace = dist.get_backend(group) == "nccl"
+        self.kv = engine.buffer("kv_gather", torch.bfloat16).view(self.P, -1)
+        self.Lr = engine.tokens_per_rank
+        hy = engine.family == MC_FAMILY_HUNYUAN
+        self.cols = 64 if hy else engine.out_channels
+        self.full = torch.empty(engine.img_tokens, self.cols, dtype=torch.float32, device=engine.device)
+
+    def _gather(self, full, mine):
+        if self.inplace:
+            self.dist.all_gather_into_tensor(full.view(-1), mine.reshape(-1), group=self.group)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.P)]
+            self.dist.all_gather(parts, mine.contiguous(), group=self.group)
+            for r, p_ in enumerate(parts):
+                full.view(self.P, -1)[r].copy_(p_.reshape(-1))
+
+    def forward(self, img, timestep, guidance, txt, txt_valid, vec, mode):
+        e = self.e
+        e.begin(img, timestep, guidance, txt, txt_valid, vec, mode)
+        if mode != MC_MODE_SKIP:
+            for blk in range(e.n_blocks):
+                e.block_pre(blk)
+                self._gather(self.kv, self.kv[self.rank].clone() if not self.inplace else self.kv[self.rank])
+                e.block_post(blk)
+        if e.family == MC_FAMILY_HUNYUAN:
+            e.end(None)
+            local = e.buffer("head_tokens", torch.float32).view(-1, 64)[:self.Lr]
+            self._gather(self.full, local)
+            out = torch.empty((e.out_channels,) + e.latent_grid, dtype=torch.float32, device=e.device)
+            e.unpatchify(self.full, out)
+            return out
+        local = torch.empty(self.Lr, self.cols, dtype=torch.float32, device=e.device)
+        e.end(local)
+        self._gather(self.full, local)
+        return self.full.clone()
+
+
+def _engine_forward(model, img, t, g, txt, txt_valid, vec, mode):
+    e = model.engine
+    if e.sp_size > 1:
+        if getattr(model, "_sp", None) is None:
+            model._sp = MMDiTSequenceParallel(e, group=model.sp_group)
+        return model._sp.forward(img, t, g, txt, txt_valid, vec, mode)
+    return e.forward(img, t, g, txt, txt_valid, vec, mode)
 
 
 def _dispatch(self, *args, **kwargs):
@@ -164,7 +246,8 @@ def flux_rope(ids, axes_dim=(16, 56, 56), theta=10000.0):
 class FluxTransformer2DModelHIP:
     """Stands where diffusers' FluxTransformer2DModel stands.  One (image tokens, text length) geometry per instance."""
 
-    def __init__(self, cfg, img_tokens, txt_len=512, device="cuda:0", calibration=True, engine=None):
+    def __init__(self, cfg, img_tokens, txt_len=512, device="cuda:0", calibration=True, engine=None, sp_rank=0,
+                 sp_size=1, sp_group=None):
         self.config = SimpleNamespace(**cfg)
         self.cfg = dict(cfg)
         dim = cfg["attention_head_dim"] * cfg["num_attention_heads"]
@@ -173,8 +256,9 @@ class FluxTransformer2DModelHIP:
         self.engine = engine or MMDiTEngine(MC_FAMILY_FLUX, dim, cfg["num_attention_heads"], cfg["num_layers"],
                                             cfg["num_single_layers"], cfg["in_channels"], cfg["in_channels"],
                                             cfg["joint_attention_dim"], txt_len, cfg["pooled_projection_dim"], img_tokens,
-                                            calibration=calibration, device=device)
+                                            calibration=calibration, device=device, sp_rank=sp_rank, sp_size=sp_size)
         self.device = self.engine.device
+        self.sp_group = sp_group
         self._ids_key = None
 
     def load_state_dict(self, sd):
@@ -198,7 +282,7 @@ class FluxTransformer2DModelHIP:
         if self._ids_key is None or self._ids_key.shape != ids.shape or not torch.equal(self._ids_key, ids):
             self.engine.set_rope(*flux_rope(ids, tuple(self.cfg["axes_dims_rope"])))
             self._ids_key = ids
-        out = self.engine.forward(hidden_states[0], t, g, encoder_hidden_states[0], self.txt_len, pooled_projections[0], mode)
+        out = _engine_forward(self, hidden_states[0], t, g, encoder_hidden_states[0], self.txt_len, pooled_projections[0], mode)
         return out.unsqueeze(0).to(hidden_states.dtype)
 
     __call__ = _dispatch
@@ -306,8 +390,10 @@ def init_flux_magcache(model, num_inference_steps=28, magcache_thresh=0.24, K=5,
 class HYVideoDiffusionTransformerHIP:
     """Stands where hyvideo's HYVideoDiffusionTransformer stands.  One latent grid / text length per instance."""
 
-    def __init__(self, cfg, latent_grid, txt_len=256, device="cuda:0", calibration=True, engine=None):
+    def __init__(self, cfg, latent_grid, txt_len=256, device="cuda:0", calibration=True, engine=None, sp_rank=0,
+                 sp_size=1, sp_group=None):
         self.cfg = dict(cfg)
+        self.sp_group = sp_group
         self.patch_size = tuple(cfg.get("patch_size", (1, 2, 2)))
         assert self.patch_size == (1, 2, 2)
         self.hidden_size, self.heads_num = cfg["hidden_size"], cfg["heads_num"]
@@ -320,7 +406,7 @@ class HYVideoDiffusionTransformerHIP:
                                             cfg["mm_double_blocks_depth"], cfg["mm_single_blocks_depth"], cfg["in_channels"],
                                             cfg["out_channels"], cfg["text_states_dim"], txt_len, cfg["text_states_dim_2"],
                                             self.img_tokens, latent_grid=self.latent_grid, refiner_depth=2,
-                                            calibration=calibration, device=device)
+                                            calibration=calibration, device=device, sp_rank=sp_rank, sp_size=sp_size)
         self.device = self.engine.device
 
     def load_state_dict(self, sd):
@@ -337,8 +423,8 @@ class HYVideoDiffusionTransformerHIP:
         n_valid = int(m.sum())
         assert n_valid > 0 and bool(m[:n_valid].all()), "text_mask must be a prefix mask (tokenizer right padding)"
         self.engine.set_rope(freqs_cos, freqs_sin)
-        out = self.engine.forward(x[0], float(t.reshape(-1)[0]), float(guidance.reshape(-1)[0]), text_states[0], n_valid,
-                                  text_states_2[0], mode)
+        out = _engine_forward(self, x[0], float(t.reshape(-1)[0]), float(guidance.reshape(-1)[0]), text_states[0], n_valid,
+                              text_states_2[0], mode)
         return out.unsqueeze(0).to(x.dtype)
 
     __call__ = _dispatch

@@ -220,6 +220,27 @@ def test_hunyuan_calibration_vs_reference_golden(hunyuan):
     cls.cnt = 0
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_mmdit_sequence_parallel_ranks_on_one_gpu(tmp_path, world):
+    """FLUX and HunyuanVideo with the image tokens sharded over `world` ranks (gloo, all on cuda:0): begin / block_pre /
+    all-gather of the image K|V / block_post (image shards + text keys merged by log-sum-exp) / end must reproduce the
+    1-rank engine for full and skipped forwards.  Tolerance as for the Wan sequence-parallel test: the partial attention
+    result passes through bf16 once more before the merge."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "mmdit_sp.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29570 + world), os.path.join(root, "tests", "mmdit_sp_worker.py"), str(out)]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.path.join(root, "tests"))
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert len(res) == world
+    for x in res:
+        assert max(x["flux"]) < 4e-3 and max(x["hunyuan"]) < 4e-3, res
+
+
 def test_mmdit_full_width_block_shapes():
     """FLUX.1-dev / HunyuanVideo real widths (d = 3072, 24 heads, mlp 12288, fused 5d output projection) on a short
     sequence with 1 + 1 blocks: engine vs the fp32 oracle, same tolerance as the tiny geometry."""
