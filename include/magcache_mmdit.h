@@ -86,6 +86,9 @@ mc_status mc_mmdit_forward(mc_mmdit* e, const float* img_dev, double timestep, d
 mc_status mc_mmdit_begin(mc_mmdit* e, const float* img_dev, double timestep, double guidance, const float* txt_dev,
                          int txt_valid, const float* vec_dev, mc_mode mode, mc_stream stream);
 mc_status mc_mmdit_block_pre(mc_mmdit* e, int block, mc_stream stream);
+/* optional: attention over this rank's own image shard + the text keys, to overlap the all-gather (then block_post
+ * attends the remote shards only) */
+mc_status mc_mmdit_block_attn_local(mc_mmdit* e, int block, mc_stream stream);
 mc_status mc_mmdit_block_post(mc_mmdit* e, int block, mc_stream stream);
 mc_status mc_mmdit_end(mc_mmdit* e, float* out_dev, mc_stream stream);
 mc_status mc_mmdit_unpatchify(mc_mmdit* e, const float* tokens_dev, float* out_dev, mc_stream stream);

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mc_mmdit_forward": (_i, [_vp, _vp, _d, _d, _vp, _i, _vp, _i, _vp, _vp]),
     "mc_mmdit_begin": (_i, [_vp, _vp, _d, _d, _vp, _i, _vp, _i, _vp]),
     "mc_mmdit_block_pre": (_i, [_vp, _i, _vp]),
+    "mc_mmdit_block_attn_local": (_i, [_vp, _i, _vp]),
     "mc_mmdit_block_post": (_i, [_vp, _i, _vp]),
     "mc_mmdit_end": (_i, [_vp, _vp, _vp]),
     "mc_mmdit_unpatchify": (_i, [_vp, _vp, _vp, _vp]),

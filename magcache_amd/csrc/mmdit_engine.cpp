@@ -106,7 +106,7 @@ struct mc_mmdit {
   int d, H, Li, Lt, S, Sp, Kin, Kp, img0, txt0, out_feat;   // Li = image tokens of THIS rank; S = Lt + Li
   int P = 1, rank = 0, tok0 = 0, Lrp = 0;                    // sequence parallel: image shard [tok0, tok0 + Li)
   mc_mode mode = MC_MODE_FULL;                               // of the forward in progress (begin .. end)
-  int txt_valid = 0, dst = 0;
+  int txt_valid = 0, dst = 0, local_attn_blk = -1;
   bool begun = false;
   size_t mod_rows = 0;  // rows of the fused modulation matrix
   std::vector<Stream> dimg, dtxt;
@@ -718,6 +718,38 @@ mc_status mc_mmdit_block_pre(mc_mmdit* e, int blk, mc_stream stream_) {
   return MC_OK;
 }
 
+// optional, sp_size > 1: attention of the local queries over THIS rank's image shard and the (replicated) text keys --
+// everything that needs nothing from the other ranks -- to be launched while the all-gather is in flight; the
+// following mc_mmdit_block_post then attends the remote image shards only and merges.
+mc_status mc_mmdit_block_attn_local(mc_mmdit* e, int blk, mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!e || !e->begun) return fail(MC_ESTATE, "mc_mmdit_begin must run first");
+  if (e->P < 2) return fail(MC_ESTATE, "mc_mmdit_block_attn_local needs sp_size > 1");
+  const int d = e->d, Li = e->Li, Lt = e->Lt;
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  mc::AttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.Q = qkv; a.ldq = 3 * d;
+  a.O = e->buf<bf16_t>("am"); a.ldo = 5 * d;
+  a.Lq_pad = e->Sp; a.n_heads = e->H; a.scale = 1.0f / std::sqrt(128.0f);
+  a.n_shards = 1;
+  float* lse = e->buf<float>("attn_lse");
+  mc::AttnParams li = a;   // local image keys: rows [img0, img0 + Li) of the local qkv
+  li.K = qkv + (size_t)e->img0 * 3 * d + d; li.ldk = 3 * d;
+  li.V = qkv + (size_t)e->img0 * 3 * d + 2 * d; li.ldv = 3 * d;
+  li.shard_rows = (int)align_up(Li, 64); li.shard_valid = Li;
+  li.lse_out = lse;
+  HIP_TRY(mc::launch_attention(li, s));
+  mc::AttnParams tx = a;   // text keys
+  tx.K = qkv + (size_t)e->txt0 * 3 * d + d; tx.ldk = 3 * d;
+  tx.V = qkv + (size_t)e->txt0 * 3 * d + 2 * d; tx.ldv = 3 * d;
+  tx.shard_rows = (int)align_up(Lt, 64); tx.shard_valid = e->txt_valid;
+  tx.lse_in = lse; tx.lse_out = lse;
+  HIP_TRY(mc::launch_attention(tx, s));
+  e->local_attn_blk = blk;
+  return MC_OK;
+}
+
 mc_status mc_mmdit_block_post(mc_mmdit* e, int blk, mc_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!e || !e->begun) return fail(MC_ESTATE, "mc_mmdit_begin must run first");
@@ -744,14 +776,21 @@ mc_status mc_mmdit_block_post(mc_mmdit* e, int blk, mc_stream stream_) {
     i1.K = kvg; i1.ldk = 2 * d; i1.k_shard_stride = (long)e->Lrp * 2 * d;
     i1.V = kvg + d; i1.ldv = 2 * d; i1.v_shard_stride = (long)e->Lrp * 2 * d;
     i1.shard_rows = e->Lrp; i1.shard_valid = Li; i1.n_shards = e->P;
-    i1.lse_out = e->buf<float>("attn_lse");
-    HIP_TRY(mc::launch_attention(i1, s));
-    mc::AttnParams t2 = a;
-    t2.K = qkv + (size_t)e->txt0 * 3 * d + d; t2.ldk = 3 * d;
-    t2.V = qkv + (size_t)e->txt0 * 3 * d + 2 * d; t2.ldv = 3 * d;
-    t2.shard_rows = (int)align_up(Lt, 64); t2.shard_valid = e->txt_valid; t2.n_shards = 1;
-    t2.lse_in = e->buf<float>("attn_lse");
-    HIP_TRY(mc::launch_attention(t2, s));
+    if (e->local_attn_blk == blk) {   // local image shard + text keys are done: the remote shards only, merged
+      e->local_attn_blk = -1;
+      i1.skip_shard_p1 = e->rank + 1;
+      i1.lse_in = e->buf<float>("attn_lse");
+      HIP_TRY(mc::launch_attention(i1, s));
+    } else {
+      i1.lse_out = e->buf<float>("attn_lse");
+      HIP_TRY(mc::launch_attention(i1, s));
+      mc::AttnParams t2 = a;
+      t2.K = qkv + (size_t)e->txt0 * 3 * d + d; t2.ldk = 3 * d;
+      t2.V = qkv + (size_t)e->txt0 * 3 * d + 2 * d; t2.ldv = 3 * d;
+      t2.shard_rows = (int)align_up(Lt, 64); t2.shard_valid = e->txt_valid; t2.n_shards = 1;
+      t2.lse_in = e->buf<float>("attn_lse");
+      HIP_TRY(mc::launch_attention(t2, s));
+    }
   }
   const bool last = (blk == nb - 1);
   if (blk < c.n_double) {

@@ -149,6 +149,9 @@ class MMDiTEngine:
     def block_pre(self, blk):
         check(self.lib.mc_mmdit_block_pre(self.h, blk, _stream()))
 
+    def block_attn_local(self, blk):
+        check(self.lib.mc_mmdit_block_attn_local(self.h, blk, _stream()))
+
     def block_post(self, blk):
         check(self.lib.mc_mmdit_block_post(self.h, blk, _stream()))
 
@@ -172,7 +175,8 @@ class MMDiTSequenceParallel:
     global RoPE positions), the text tokens and the conditioning are replicated, and the only data-path collective is
     the per-block all-gather of the image K|V rows ("kv_gather", RCCL over xGMI through torch.distributed).  Each rank
     then attends its queries over all image shards and over the text keys and merges the two partial softmaxes by their
-    log-sum-exp inside the attention kernel.  The MagCache residual cache and skip path are shard-local; the decision
+    log-sum-exp inside the attention kernel (local image shard + text keys first, while the gather is in flight; the
+    remote shards after it).  The MagCache residual cache and skip path are shard-local; the decision
     is host arithmetic on identical state, so all ranks take the same branch."""
 
     def __init__(self, engine, group=None):
@@ -187,9 +191,9 @@ class MMDiTSequenceParallel:
         self.cols = 64 if hy else engine.out_channels
         self.full = torch.empty(engine.img_tokens, self.cols, dtype=torch.float32, device=engine.device)
 
-    def _gather(self, full, mine):
+    def _gather(self, full, mine, async_op=False):
         if self.inplace:
-            self.dist.all_gather_into_tensor(full.view(-1), mine.reshape(-1), group=self.group)
+            return self.dist.all_gather_into_tensor(full.view(-1), mine.reshape(-1), group=self.group, async_op=async_op)
         else:
             parts = [torch.empty_like(mine) for _ in range(self.P)]
             self.dist.all_gather(parts, mine.contiguous(), group=self.group)
@@ -202,7 +206,13 @@ class MMDiTSequenceParallel:
         if mode != MC_MODE_SKIP:
             for blk in range(e.n_blocks):
                 e.block_pre(blk)
-                self._gather(self.kv, self.kv[self.rank].clone() if not self.inplace else self.kv[self.rank])
+                # RCCL: asynchronous gather on its own stream, overlapped with the attention over the local image
+                # shard and the text keys; block_post then attends the remote shards and merges
+                work = self._gather(self.kv, self.kv[self.rank].clone() if not self.inplace else self.kv[self.rank],
+                                    async_op=True)
+                e.block_attn_local(blk)
+                if work is not None:
+                    work.wait()
                 e.block_post(blk)
         if e.family == MC_FAMILY_HUNYUAN:
             e.end(None)
