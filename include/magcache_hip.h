@@ -129,6 +129,10 @@ mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream);  /* LN+m
  * layer then attends the remaining shards only and merges both parts (log-sum-exp weights) */
 mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream);
 mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream);
+/* VACE under sequence parallelism: control block i in the same two phases (K/V all-gather between them); call them
+ * after mc_block_post_attn of main layer i * vace_stride, vace_block_post adds the hint to the main stream */
+mc_status mc_vace_block_pre(mc_engine* e, int i, mc_stream stream);
+mc_status mc_vace_block_post(mc_engine* e, int i, int branch, mc_mode mode, mc_stream stream);
 mc_status mc_head(mc_engine* e, int branch, mc_mode mode, mc_stream stream); /* -> "head_tokens" */
 /* tokens_dev: fp32 [n_tok, 4*out_dim] for tokens tok0..tok0+n_tok-1 -> out_dev [out_dim,F,H,W] */
 mc_status mc_unpatchify(mc_engine* e, const float* tokens_dev, int tok0, int n_tok, float* out_dev,

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mc_block_pre_attn": (_i, [_vp, _i, _vp]),
     "mc_block_attn_local": (_i, [_vp, _i, _vp]),
     "mc_block_post_attn": (_i, [_vp, _i, _i, _i, _vp]),
+    "mc_vace_block_pre": (_i, [_vp, _i, _vp]),
+    "mc_vace_block_post": (_i, [_vp, _i, _i, _i, _vp]),
     "mc_head": (_i, [_vp, _i, _i, _vp]),
     "mc_unpatchify": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mc_calib_ready": (_i, [_vp, _i, C.POINTER(_i)]),

@@ -225,7 +225,8 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     return fail(MC_EINVAL, "bad VACE geometry: %d blocks, stride %d, in_dim %d", c.vace_layers, c.vace_stride, c.vace_in_dim);
   if (c.fp8_linear && ((c.dim % 256) || (c.ffn_dim % 256) || c.dim < 512 || c.ffn_dim < 512))
     return fail(MC_EINVAL, "fp8_linear needs dim and ffn_dim to be multiples of 256 and >= 512");
-  if (c.vace_layers > 0 && c.sp_size > 1) return fail(MC_EINVAL, "VACE is single-GPU in this engine (sp_size must be 1)");
+  if (c.vace_layers > 0 && c.sp_size > 1 && (c.vace_layers - 1) * c.vace_stride == c.num_layers - 1)
+    return fail(MC_EINVAL, "VACE with a hint on the last layer is single-GPU in this engine");
 
   mc_engine* e = new mc_engine();
   e->cfg = c;
@@ -875,12 +876,9 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
 
 // VACE: control block i on the stream c, then x += after_proj(c) * context_scale (the "hint" of main layer
 // i * vace_stride; upstream VaceWanAttentionBlock / BaseWanAttentionBlock, reference call site :544-549)
-static mc_status vace_block(mc_engine* e, int i, int branch, mc_mode mode, hipStream_t s) {
+static mc_status vace_pre(mc_engine* e, int i, hipStream_t s) {
   const int d = e->d, Lp = e->Lp;
   float* xc = e->buf<float>("xc");
-  float* x = e->buf<float>("x");
-  const Layer& l = e->vlayers[i];
-  const float* em = e->buf<float>("emod") + (size_t)(e->NL + i) * 6 * d;
   if (i == 0) {
     // c = before_proj(c0) + x, x = the embedded latent (ori_x, bf16 under autocast)
     HIP_TRY(hipMemsetAsync(xc, 0, (size_t)Lp * d * 4, s));
@@ -889,17 +887,43 @@ static mc_status vace_block(mc_engine* e, int i, int branch, mc_mode mode, hipSt
     p.X = xc; p.ldx = d; p.gate = nullptr;
     HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_RESID_GATE, s));
   }
-  mc_status st = block_pre(e, l, em, xc, s);
-  if (st != MC_OK) return st;
-  st = block_post(e, l, em, xc, -1, false, branch, mode, s);
+  return block_pre(e, e->vlayers[i], e->buf<float>("emod") + (size_t)(e->NL + i) * 6 * d, xc, s);
+}
+
+static mc_status vace_post(mc_engine* e, int i, int branch, mc_mode mode, hipStream_t s) {
+  const int d = e->d, Lp = e->Lp;
+  float* xc = e->buf<float>("xc");
+  mc_status st = block_post(e, e->vlayers[i], e->buf<float>("emod") + (size_t)(e->NL + i) * 6 * d, xc, -1, false, branch,
+                            mode, s);
   if (st != MC_OK) return st;
   // hint: after_proj(c) needs bf16 rows of c; the LayerNorm scratch xn is free here
   bf16_t* xn = e->buf<bf16_t>("xn");
   HIP_TRY(mc::launch_cast_bf16(xc, xn, (size_t)Lp * d, s));
   mc::GemmParams h = gp(xn, d, e->w_after[i], d, e->b_after[i], Lp, d, d);
-  h.X = x; h.ldx = d; h.gate = e->vscale;
+  h.X = e->buf<float>("x"); h.ldx = d; h.gate = e->vscale;
   HIP_TRY(mc::launch_gemm_bf16(h, mc::EPI_RESID_GATE, s));
   return MC_OK;
+}
+
+static mc_status vace_block(mc_engine* e, int i, int branch, mc_mode mode, hipStream_t s) {
+  mc_status st = vace_pre(e, i, s);
+  return st != MC_OK ? st : vace_post(e, i, branch, mode, s);
+}
+
+// Sequence parallel: control block i in two phases, like the main blocks (the caller all-gathers "kv_gather" between
+// them).  Main layer i * vace_stride must have completed its block_post before vace_block_post(i) adds the hint.
+mc_status mc_vace_block_pre(mc_engine* e, int i, mc_stream stream) {
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (i < 0 || i >= e->NV) return fail(MC_EINVAL, "VACE block %d out of range", i);
+  if (!e->have_vace) return fail(MC_ESTATE, "mc_set_vace_context must run first");
+  return vace_pre(e, i, (hipStream_t)stream);
+}
+
+mc_status mc_vace_block_post(mc_engine* e, int i, int branch, mc_mode mode, mc_stream stream) {
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (i < 0 || i >= e->NV) return fail(MC_EINVAL, "VACE block %d out of range", i);
+  if (branch < 0 || branch >= e->cfg.n_branches) return fail(MC_EINVAL, "branch %d out of range", branch);
+  return vace_post(e, i, branch, mode, (hipStream_t)stream);
 }
 
 // residual capture + calibration statistics as separate kernels (only when the last layer carries a VACE hint)

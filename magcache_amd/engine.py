@@ -114,6 +114,7 @@ class Engine:
                      vace_in_dim=cfg.get("vace_in_dim", 0) if vace_geometry(cfg)[0] else 0,
                      fp8_linear=int(bool(cfg.get("fp8_linear", False))))
         self.sp_rank, self.sp_size, self.n_branches = sp_rank, sp_size, n_branches
+        self.vace_layers, self.vace_stride = vace_geometry(cfg)
         h = C.c_void_p()
         check(self.lib.mc_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -231,6 +232,12 @@ class Engine:
 
     def block_post_attn(self, layer, branch, mode):
         check(self.lib.mc_block_post_attn(self.h, layer, branch, mode, _stream()))
+
+    def vace_block_pre(self, i):
+        check(self.lib.mc_vace_block_pre(self.h, i, _stream()))
+
+    def vace_block_post(self, i, branch, mode):
+        check(self.lib.mc_vace_block_post(self.h, i, branch, mode, _stream()))
 
     def head(self, branch, mode):
         check(self.lib.mc_head(self.h, branch, mode, _stream()))

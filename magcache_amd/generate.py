@@ -159,8 +159,6 @@ def generate(args):
         cfg = WAN_VACE_1_3B if "1.3B" in args.task else WAN_VACE_14B
     else:
         cfg = WAN_T2V_1_3B if "1.3B" in args.task else WAN_T2V_14B
-    if (is_i2v or is_vace) and world > 1:
-        raise SystemExit("i2v / vace tasks run on one GPU in this engine (the control / image branches are not sharded)")
     H, W = SIZE_CONFIGS[args.size][1], SIZE_CONFIGS[args.size][0]
     grid = ((args.frame_num - 1) // 4 + 1, H // 8, W // 8)
     logging.info(f"Generation job args: {args}")

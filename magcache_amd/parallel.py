@@ -119,6 +119,15 @@ class SequenceParallelForward:
                 if work is not None:
                     work.wait()                    # stream dependency, no host sync
                 e.block_post_attn(layer, branch, mode)
+                nv, stride = getattr(e, "vace_layers", 0), getattr(e, "vace_stride", 0)
+                if nv and layer % stride == 0 and layer // stride < nv:
+                    # VACE control block of this layer: same two phases on the control stream, then the hint
+                    i = layer // stride
+                    e.vace_block_pre(i)
+                    work = self._all_gather_kv()
+                    if work is not None:
+                        work.wait()
+                    e.vace_block_post(i, branch, mode)
             if mode == MC_MODE_CALIB:
                 has = e.calib_has_stats(branch)
                 if has:

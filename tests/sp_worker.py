@@ -47,6 +47,24 @@ def main():
     gathered = [torch.zeros_like(res.cpu()) for _ in range(world)]
     dist.all_gather(gathered, res.cpu())
 
+    # ---- VACE: control blocks on the sharded control stream (their own K/V gather), hints into the main stream
+    from magcache_amd import model as M
+    vcfg = dict(W.tiny_config(num_layers=4, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64),
+                vace_layers=[0, 2], vace_in_dim=96)
+    voracle = W.init_synthetic_(W.VaceWanModel(**vcfg), seed=9, std=0.05)
+    vctx = torch.randn(96, *grid, generator=g).to(dev)
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+
+    def vace_model(sp):
+        cls = type("VaceSP%d" % sp, (M.WanModelHIP,), {"forward": M.vace_plain_forward})
+        m = cls(vcfg, grid, device=dev, calibration=False, sp_rank=rank if sp > 1 else 0, sp_size=sp)
+        m.load_state_dict(voracle.state_dict())
+        return m
+    tt = torch.tensor([700.0], device=dev)
+    v_sp = vace_model(world)([lat], t=tt, vace_context=[vctx], context=[ctx], seq_len=L, vace_context_scale=0.8)[0]
+    v_1 = vace_model(1)([lat], t=tt, vace_context=[vctx], context=[ctx], seq_len=L, vace_context_scale=0.8)[0]
+    rel_vace = float((v_sp - v_1).norm() / v_1.norm())
+
     out = {}
     if rank == 0:
         e1 = Engine(cfg, grid, device=dev, n_branches=2, calibration=True)
@@ -57,7 +75,7 @@ def main():
         e1.forward(lat, 700.0, ctx, 1, MC_MODE_CALIB)
         e1.forward(lat * 0.9, 600.0, ctx, 1, MC_MODE_CALIB)
         st1 = e1.calib_stats(1)
-        out = dict(rel_full=rel(full, f1), rel_skip=rel(skip, s1),
+        out = dict(rel_full=rel(full, f1), rel_skip=rel(skip, s1), rel_vace=rel_vace,
                    rel_calib=max(abs(a - b) for a, b in zip(stats, st1)),
                    rel_residual=rel(torch.cat(gathered), e1.residual(0).cpu()), stats=stats, stats1=st1)
         json.dump(out, open(a.out, "w"))
