@@ -282,16 +282,17 @@ def vace_plain_forward(self, x, t, vace_context, context, seq_len, vace_context_
     return self._run(x, t, context, 0, MC_MODE_FULL, vace=(vace_context, vace_context_scale))
 
 
-def call_branch(model, step, branch, x, t, context, seq_len):
+def call_branch(model, step, branch, x, t, context, seq_len, **kw):
     """One forward of ONE CFG branch at sampler step `step` (CFG-parallel layouts: this rank never sees the
     other branch's call).  The reference's counter runs over both branches (cnt = 2*step + branch selects
     mag_ratios[cnt] and the state slot cnt % 2, :279-292); it is positioned before the call, and the skipped
     sibling call is accounted for afterwards so that the end-of-video reset (:306-311) happens as usual."""
     cls = type(model)
-    has_state = getattr(cls, "forward", None) in (magcache_forward, magcache_calibration)
+    has_state = getattr(cls, "forward", None) in (magcache_forward, magcache_calibration, magcache_vace_forward,
+                                                  magcache_vace_calibration)
     if has_state:
         model.cnt = 2 * step + branch
-    out = model(x, t=t, context=context, seq_len=seq_len)
+    out = model(x, t=t, context=context, seq_len=seq_len, **kw)
     if has_state and branch == 0:
         _advance(model)                    # the uncond call made by the other half of the node
     return out

@@ -170,7 +170,7 @@ def sample(model, noise, context, context_null, sampling_steps=50, shift=5.0, gu
             # this rank evaluates one CFG branch; the pair {cond rank, uncond rank} swaps predictions
             from .model import call_branch
             mine = call_branch(model, i, layout.branch, [latent], timestep,
-                               [context if layout.branch == 0 else context_null], seq_len)[0]
+                               [context if layout.branch == 0 else context_null], seq_len, **mk)[0]
             eps_c, eps_u = layout.exchange(mine.contiguous())
         else:
             eps_c = model([latent], t=timestep, context=[context], seq_len=seq_len, **mk)[0]
