@@ -48,3 +48,25 @@ def test_cfg_parallel_sampler_gloo(tmp_path, world, port):
             assert x[solver]["state_par"][0] == 0 == x[solver]["state_seq"][0]   # cnt reset at the end (:306-311)
         w = x["wan22"]      # Wan2.2 two-expert loop under the same layout (wan22.call_branch)
         assert w["equal"] and w["calls_match"] and w["skipped"] > 0 and w["state_par"] == w["state_seq"], x
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_mmdit_sequence_parallel_orchestration_gloo(tmp_path, world):
+    """mmdit.MMDiTSequenceParallel (FLUX / HunyuanVideo, N > 1) on CPU: phase order per block (pre -> gather -> local ->
+    post), every rank's image K|V shard lands in its slot of every peer, the sharded outputs are assembled in rank
+    order, a skipped step goes begin -> end without touching the blocks."""
+    out = tmp_path / "mmdit.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29590 + world), os.path.join(ROOT, "tests", "gloo_mmdit_worker.py"), str(out)]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert len(res) == world
+    blocks = [[["pre", b], ["local", b], ["post", b]] for b in range(3)]
+    for x in res:
+        for fam in ("flux", "hunyuan"):
+            assert x[fam]["out_ok"] and x[fam]["kv_ok"], x
+            tail = [["end"]] + ([["unpatchify"]] if fam == "hunyuan" else [])
+            assert x[fam]["log"] == [["begin", 0]] + [s for b in blocks for s in b] + tail, x[fam]["log"]
+            assert x[fam]["skip_log"] == [["begin", 1]] + tail, x[fam]["skip_log"]
