@@ -119,7 +119,7 @@ def cpu_baseline(cfg, threads):
     this box's host cores on a bounded sample, extrapolated with the FLOP model."""
     from oracle import wan_dit_ref as W
     torch.set_num_threads(threads)
-    n_layers, grid = 3, (2, 60, 104)
+    n_layers, grid = 2, (2, 60, 104)
     L = grid[0] * 30 * 52
     c = dict(cfg, num_layers=n_layers)
     oracle = W.init_synthetic_(W.WanModel(**c), seed=0)
