@@ -191,17 +191,29 @@ hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stre
 
 // Kernel choice.  g_gemm_kernel: 0 = by shape, 1 = always the 128x128 kernel, 2 = the 256x256
 // kernel wherever it is supported (mc_set_option("gemm_kernel", v); used by the A/B benchmarks).
-// By shape: the 256^2 kernel runs one workgroup per CU and its epilogue is not overlapped with
-// another tile's main loop, so it is used where the main loop dominates: K >= 1024 and at least
-// one full wave of 256 tiles.
+// By shape: estimated throughput = (fraction of the tile slots the grid fills, over its whole number of waves) x the
+// kernel's per-tile rate.  The 256x256 kernel runs one workgroup per CU (256 slots) and is ~1.3x faster per tile; the
+// 128x128 kernel runs two per CU (512 slots) and has 4x the tiles, so it wins when M*N is small (measured on the
+// FLUX / sequence-parallel shapes with tools/gemm_smallm_ab.py: e.g. M=1024 N=9216: 858 vs 660 TF for 256^2,
+// M=512 N=9216: 490 vs 566 TF).  K < 1024: the 256^2 kernel's prologue/epilogue dominate, keep the small one.
 int g_gemm_kernel = 0;
+
+static double fill_efficiency(long tiles, long slots) {
+  const long waves = (tiles + slots - 1) / slots;
+  return (double)tiles / (double)(waves * slots);
+}
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
   bool big = false;
   if (g_gemm_kernel != 1 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
       gemm_bf16_big_supported(p)) {
-    const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
-    big = (g_gemm_kernel == 2) || (p.K >= 1024 && tiles >= 256);
+    if (g_gemm_kernel == 2) {
+      big = true;
+    } else if (p.K >= 1024) {
+      const long tiles_big = (long)((p.M + 255) / 256) * (p.N / 256);
+      const long tiles_small = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+      big = 1.3 * fill_efficiency(tiles_big, 256) >= fill_efficiency(tiles_small, 512);
+    }
   }
   return big ? launch_gemm_bf16_big(p, epi, stream) : launch_gemm_bf16_small(p, epi, stream);
 }
