@@ -25,6 +25,7 @@ from ._lib import (MC_F32, MC_BF16, MC_FAMILY_FLUX, MC_FAMILY_HUNYUAN, MC_MODE_C
                    McMmditConfig, check)
 from .mag_ratios import TABLES
 from .model import nearest_interp
+from .parallel import SP_OVERLAP
 
 FLUX_DEV = dict(in_channels=64, num_layers=19, num_single_layers=38, attention_head_dim=128, num_attention_heads=24,
                 joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
@@ -210,6 +211,9 @@ class MMDiTSequenceParallel:
                 # shard and the text keys; block_post then attends the remote shards and merges
                 work = self._gather(self.kv, self.kv[self.rank].clone() if not self.inplace else self.kv[self.rank],
                                     async_op=True)
+                if work is not None and not SP_OVERLAP:
+                    work.wait()
+                    work = None
                 e.block_attn_local(blk)
                 if work is not None:
                     work.wait()

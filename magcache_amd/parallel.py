@@ -21,10 +21,15 @@ then attends the P-1 remote shards and merges the two partial softmaxes by their
 kernel epilogue.  Nothing else in a layer is independent of the gathered K/V, so this is the overlap
 the data flow allows.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from ._lib import MC_MODE_CALIB, MC_MODE_SKIP
+
+# MAGCACHE_SP_OVERLAP=0: wait for the K/V all-gather before the local-shard attention (no kernel runs beside RCCL)
+SP_OVERLAP = os.environ.get("MAGCACHE_SP_OVERLAP", "1") != "0"
 
 
 class ParallelLayout:
@@ -115,6 +120,9 @@ class SequenceParallelForward:
             for layer in range(self.NL):
                 e.block_pre_attn(layer)
                 work = self._all_gather_kv()
+                if work is not None and not SP_OVERLAP:
+                    work.wait()
+                    work = None
                 e.block_attn_local(layer)          # overlaps the gather: needs only this rank's shard
                 if work is not None:
                     work.wait()                    # stream dependency, no host sync
