@@ -474,3 +474,37 @@ def test_wan22_two_experts_i2v_vs_oracle():
     assert [int(m == MC_MODE_SKIP) for m in modes] == [int(s) for _, _, s in ref.trace]
     assert any(s for _, _, s in ref.trace) and type(hi).cnt == 0
     assert MR.psnr(x_hip.cpu().numpy(), x_ref.numpy(), data_range=float(x_ref.abs().max())) > 30.0
+
+
+def test_forward_is_graph_capturable(golden, hip_model):
+    """The boundary's ownership rule (no allocation or synchronisation inside mc_forward, asynchronous on
+    the given stream) makes one transformer evaluation capturable in a HIP graph: capture FULL and SKIP forwards once,
+    then replay them on new latents / timesteps written in place and compare with eager launches, bit for bit."""
+    g, meta, _ = golden
+    e = hip_model.engine
+    e.reset()
+    x = torch.from_numpy(g["latent0"]).to(DEV).contiguous()
+    ctx = torch.from_numpy(g["ctx"]).to(DEV).float().contiguous()
+    t = torch.tensor([700.0], device=DEV)
+    out_full = torch.empty_like(e.forward(x, t, ctx, 0, MC_MODE_FULL))   # warm-up: first launches set kernel attributes
+    out_skip = torch.empty_like(out_full)
+    torch.cuda.synchronize()
+    graphs = {}
+    for mode, out in ((MC_MODE_FULL, out_full), (MC_MODE_SKIP, out_skip)):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            e.forward(x, t, ctx, 0, mode, out=out)
+        graphs[mode] = gr
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    for tval in (500.0, 120.0):
+        x.copy_(torch.randn(x.shape, generator=gen, device=DEV))
+        t.fill_(tval)
+        graphs[MC_MODE_FULL].replay()
+        graphs[MC_MODE_SKIP].replay()          # uses the residual the replayed FULL forward just captured
+        torch.cuda.synchronize()
+        a, b = out_full.clone(), out_skip.clone()
+        ea = e.forward(x, t, ctx, 0, MC_MODE_FULL)
+        eb = e.forward(x, t, ctx, 0, MC_MODE_SKIP)
+        torch.cuda.synchronize()
+        assert torch.equal(a, ea) and torch.equal(b, eb)
+        assert not torch.equal(a, b) and bool(torch.isfinite(a).all())
