@@ -61,13 +61,20 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 #define MC_WAIT(n, r) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // interval boundary: nothing (MFMAs included -- they are register-only and would otherwise drift
 // across the asm statements) is scheduled across it
-#define MC_BARRIER()                          \
-  do {                                        \
-    asm volatile("s_barrier" ::: "memory");   \
-    __builtin_amdgcn_sched_barrier(0);        \
+#define MC_BARRIER()                                          \
+  do {                                                        \
+    if (!(MC_ABL & 8)) asm volatile("s_barrier" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                        \
   } while (0)
 
 #define MC_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// Timing ablations (tools/build_variants.py gemm_bf16_big.hip <bits>; results are WRONG by construction): what the
+// steady-state LDS traffic costs.  1: no A fragment reads, 2: no W fragment reads, 4: no LDS-DMA refills,
+// 8: no workgroup barriers.  The prologue always runs, so every register holds finite data.
+#ifndef MC_ABL
+#define MC_ABL 0
+#endif
 
 struct Frag4 {  // one 32-row block x 64 k = 4 MFMA operands
   bf16x8 v[4];
@@ -235,24 +242,24 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   { \
     /* q0: (m0,n0); reads Wn1(kt); DMA Wn0(kt+2) */ \
     mma1(0, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (true) read_w1(ST, 1, 0, W1); \
+    if (!(MC_ABL & 2)) read_w1(ST, 1, 0, W1); \
     MC_PIN(); \
     mma1(1, W0, A0, acc[0][0][0], acc[0][1][0]); \
     MC_PIN(); \
     mma1(2, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (true) read_w1(ST, 1, 1, W1); \
-    if (TAIL == 0) dma_w1((kt) + 2, ST, 0, 0); \
+    if (!(MC_ABL & 2)) read_w1(ST, 1, 1, W1); \
+    if (TAIL == 0 && !(MC_ABL & 4)) dma_w1((kt) + 2, ST, 0, 0); \
     MC_PIN(); \
     mma1(3, W0, A0, acc[0][0][0], acc[0][1][0]); \
     MC_PIN(); \
     mma1(4, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (true) read_w1(ST, 1, 2, W1); \
+    if (!(MC_ABL & 2)) read_w1(ST, 1, 2, W1); \
     MC_PIN(); \
     mma1(5, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (TAIL == 0) dma_w1((kt) + 2, ST, 0, 1); \
+    if (TAIL == 0 && !(MC_ABL & 4)) dma_w1((kt) + 2, ST, 0, 1); \
     MC_PIN(); \
     mma1(6, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (true) read_w1(ST, 1, 3, W1); \
+    if (!(MC_ABL & 2)) read_w1(ST, 1, 3, W1); \
     MC_PIN(); \
     mma1(7, W0, A0, acc[0][0][0], acc[0][1][0]); \
     MC_PIN(); \
@@ -260,53 +267,53 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
     MC_BARRIER(); \
     /* q1: (m0,n1); reads Am1(kt); DMA Am0(kt+2) */ \
     mma1(0, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (true) read_a1(ST, 1, 0, A1); \
+    if (!(MC_ABL & 1)) read_a1(ST, 1, 0, A1); \
     MC_PIN(); \
     mma1(1, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (true) read_a1(ST, 1, 1, A1); \
+    if (!(MC_ABL & 1)) read_a1(ST, 1, 1, A1); \
     MC_PIN(); \
     mma1(2, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (true) read_a1(ST, 1, 2, A1); \
-    if (TAIL == 0) dma_a1((kt) + 2, ST, 0, 0); \
+    if (!(MC_ABL & 1)) read_a1(ST, 1, 2, A1); \
+    if (TAIL == 0 && !(MC_ABL & 4)) dma_a1((kt) + 2, ST, 0, 0); \
     MC_PIN(); \
     mma1(3, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (true) read_a1(ST, 1, 3, A1); \
+    if (!(MC_ABL & 1)) read_a1(ST, 1, 3, A1); \
     MC_PIN(); \
     mma1(4, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (true) read_a1(ST, 1, 4, A1); \
+    if (!(MC_ABL & 1)) read_a1(ST, 1, 4, A1); \
     MC_PIN(); \
     mma1(5, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (true) read_a1(ST, 1, 5, A1); \
-    if (TAIL == 0) dma_a1((kt) + 2, ST, 0, 1); \
+    if (!(MC_ABL & 1)) read_a1(ST, 1, 5, A1); \
+    if (TAIL == 0 && !(MC_ABL & 4)) dma_a1((kt) + 2, ST, 0, 1); \
     MC_PIN(); \
     mma1(6, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (true) read_a1(ST, 1, 6, A1); \
+    if (!(MC_ABL & 1)) read_a1(ST, 1, 6, A1); \
     MC_PIN(); \
     mma1(7, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (true) read_a1(ST, 1, 7, A1); \
+    if (!(MC_ABL & 1)) read_a1(ST, 1, 7, A1); \
     MC_PIN(); \
     if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(6, 0); \
     MC_BARRIER(); \
     /* q2: (m1,n1); reads Wn0(kt+1); DMA Wn1(kt+2) */ \
     mma1(0, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL != 2) read_w1(1 - ST, 0, 0, W2); \
+    if (TAIL != 2 && !(MC_ABL & 2)) read_w1(1 - ST, 0, 0, W2); \
     MC_PIN(); \
     mma1(1, W1, A1, acc[1][0][1], acc[1][1][1]); \
     MC_PIN(); \
     mma1(2, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL != 2) read_w1(1 - ST, 0, 1, W2); \
-    if (TAIL == 0) dma_w1((kt) + 2, ST, 1, 0); \
+    if (TAIL != 2 && !(MC_ABL & 2)) read_w1(1 - ST, 0, 1, W2); \
+    if (TAIL == 0 && !(MC_ABL & 4)) dma_w1((kt) + 2, ST, 1, 0); \
     MC_PIN(); \
     mma1(3, W1, A1, acc[1][0][1], acc[1][1][1]); \
     MC_PIN(); \
     mma1(4, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL != 2) read_w1(1 - ST, 0, 2, W2); \
+    if (TAIL != 2 && !(MC_ABL & 2)) read_w1(1 - ST, 0, 2, W2); \
     MC_PIN(); \
     mma1(5, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL == 0) dma_w1((kt) + 2, ST, 1, 1); \
+    if (TAIL == 0 && !(MC_ABL & 4)) dma_w1((kt) + 2, ST, 1, 1); \
     MC_PIN(); \
     mma1(6, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL != 2) read_w1(1 - ST, 0, 3, W2); \
+    if (TAIL != 2 && !(MC_ABL & 2)) read_w1(1 - ST, 0, 3, W2); \
     MC_PIN(); \
     mma1(7, W1, A1, acc[1][0][1], acc[1][1][1]); \
     MC_PIN(); \
@@ -314,30 +321,30 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
     MC_BARRIER(); \
     /* q3: (m1,n0); reads Am0(kt+1); DMA Am1(kt+2) */ \
     mma1(0, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2) read_a1(1 - ST, 0, 0, A0); \
+    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 0, A0); \
     MC_PIN(); \
     mma1(1, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2) read_a1(1 - ST, 0, 1, A0); \
+    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 1, A0); \
     MC_PIN(); \
     mma1(2, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2) read_a1(1 - ST, 0, 2, A0); \
-    if (TAIL == 0) dma_a1((kt) + 2, ST, 1, 0); \
+    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 2, A0); \
+    if (TAIL == 0 && !(MC_ABL & 4)) dma_a1((kt) + 2, ST, 1, 0); \
     MC_PIN(); \
     mma1(3, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2) read_a1(1 - ST, 0, 3, A0); \
+    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 3, A0); \
     MC_PIN(); \
     mma1(4, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2) read_a1(1 - ST, 0, 4, A0); \
+    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 4, A0); \
     MC_PIN(); \
     mma1(5, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2) read_a1(1 - ST, 0, 5, A0); \
-    if (TAIL == 0) dma_a1((kt) + 2, ST, 1, 1); \
+    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 5, A0); \
+    if (TAIL == 0 && !(MC_ABL & 4)) dma_a1((kt) + 2, ST, 1, 1); \
     MC_PIN(); \
     mma1(6, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2) read_a1(1 - ST, 0, 6, A0); \
+    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 6, A0); \
     MC_PIN(); \
     mma1(7, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2) read_a1(1 - ST, 0, 7, A0); \
+    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 7, A0); \
     MC_PIN(); \
     if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(2, 0); \
     MC_BARRIER(); \
