@@ -213,13 +213,9 @@ hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream) {
   if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;
   const int nqb = p.Lq_pad / QB;
   const int tiles_per_shard = (p.shard_valid + KT - 1) / KT;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e =
-        hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ready{0};
+  if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_kernel, 2 * STAGE, lds_ready); e != hipSuccess)
+    return e;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(nqb * p.n_heads), dim3(512), 2 * STAGE, stream, p, nqb,
                      tiles_per_shard);
   return hipGetLastError();

@@ -505,13 +505,9 @@ hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream) {
   if (p.ldk * 64 * 2 >= (1l << 31) || p.ldv * 64 * 2 >= (1l << 31)) return hipErrorInvalidValue;
   const int nqb = p.Lq_pad / QB;
   const int tiles_per_shard = (p.shard_valid + KT - 1) / KT;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e =
-        hipFuncSetAttribute((const void*)attn_fwd_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ready{0};
+  if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_v3_kernel, LDS_BYTES, lds_ready); e != hipSuccess)
+    return e;
   hipLaunchKernelGGL(attn_fwd_v3_kernel, dim3(nqb * p.n_heads), dim3(512), LDS_BYTES, stream, p, nqb,
                      tiles_per_shard);
   return hipGetLastError();

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <atomic>
+
 namespace mc {
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits in HBM
@@ -76,6 +78,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   int q = nwg / nx, r = nwg % nx;
   int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute belongs to the device that is current when it is
+// set; a process may hold engines on several GPUs).  `done` is the kernel's own bit mask of devices already prepared.
+inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
 }
 
 }  // namespace mc

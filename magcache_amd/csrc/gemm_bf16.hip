@@ -159,13 +159,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmParams p, int 
 template <int EPI>
 hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<EPI>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ready{0};
+  if (hipError_t e = ensure_dynamic_lds((const void*)gemm_bf16_tn_kernel<EPI>, 2 * STAGE_BYTES, lds_ready); e != hipSuccess)
+    return e;
   hipLaunchKernelGGL((gemm_bf16_tn_kernel<EPI>), dim3(tilesM * tilesN), dim3(256), 2 * STAGE_BYTES, stream, p,
                      tilesM, tilesN);
   return hipGetLastError();

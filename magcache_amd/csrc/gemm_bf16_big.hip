@@ -396,13 +396,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
 template <int EPI, bool F8 = false>
 hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
   const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_big_kernel<EPI, F8>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ready{0};
+  if (hipError_t e = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI, F8>, 2 * STAGE_BYTES, lds_ready); e != hipSuccess)
+    return e;
   hipLaunchKernelGGL((gemm_big_kernel<EPI, F8>), dim3(tilesM * tilesN), dim3(512), 2 * STAGE_BYTES, stream, p,
                      tilesM, tilesN);
   return hipGetLastError();
