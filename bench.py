@@ -269,6 +269,19 @@ def main():
                                                  "no-cache region (mc_profile_read)")
             line["roofline"]["kernel"] = "attn_fwd_v3_kernel (self-attention, 71% of forward FLOPs, 64% of forward time)"
             line["kernels"] = k
+        if world > 1 and attn_live and attn_live[1] > 0:
+            # N > 1: rank 0's self-attention launches of the timed no-cache region (cfg2: one full-sequence launch per
+            # layer; sequence parallel: local-shard + remote-shards launch per layer), algorithmic FLOPs of its share
+            sp = layout.sp_size
+            pairs = attn_live[1] // (2 if sp > 1 else 1)
+            fl_attn = 4.0 * (SEQ / sp) * SEQ * cfg["dim"] * pairs
+            rate = fl_attn / (attn_live[0] * 1e-3)
+            line["roofline"] = {"bound": "mfma", "achieved": rate / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                "frac": rate / 2.5e15, "traffic": None, "launches": attn_live[1],
+                                "avg_launch_ms": attn_live[0] / attn_live[1],
+                                "measured": "rank 0, hipEvent pairs around every self-attention launch of the timed "
+                                            "no-cache region; per-GPU rate",
+                                "kernel": "attn_fwd_v3_kernel (self-attention)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
         print(json.dumps(line), flush=True)

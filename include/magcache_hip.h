@@ -114,7 +114,8 @@ mc_status mc_set_clip_fea(mc_engine* e, const void* clip_dev, mc_dtype dtype, in
 mc_status mc_set_vace_context(mc_engine* e, const float* vace_dev, float context_scale, mc_stream stream);
 
 /* Measurement hook: with profiling on, every SELF-attention launch of a forward is bracketed by a hipEvent pair on the
- * launch stream (up to 8192 launches between reads); mc_profile_read waits for them, returns the summed kernel time
+ * launch stream (sequence parallel: the local-shard and the remote-shards launch of a layer each; up to 8192 launches
+ * between reads); mc_profile_read waits for them, returns the summed kernel time
  * and the launch count, and clears the log.  bench.py uses it for roofline.achieved over its timed region. */
 mc_status mc_profile_enable(mc_engine* e, int on);
 mc_status mc_profile_read(mc_engine* e, double* attn_ms_total, int* attn_launches);

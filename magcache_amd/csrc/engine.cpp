@@ -723,7 +723,13 @@ mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream_) {
   a.K = kvl; a.ldk = 2 * d; a.V = kvl + d; a.ldv = 2 * d;
   a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
   a.lse_out = e->buf<float>("attn_lse");
+  const bool prof = e->profile && e->prof_n + 2 <= e->prof_ev.size();   // measurement hook, see mc_profile_enable
+  if (prof) HIP_TRY(hipEventRecord(e->prof_ev[e->prof_n], s));
   HIP_TRY(mc::launch_attention(a, s));
+  if (prof) {
+    HIP_TRY(hipEventRecord(e->prof_ev[e->prof_n + 1], s));
+    e->prof_n += 2;
+  }
   e->local_attn_layer = layer;
   return MC_OK;
 }

@@ -14,6 +14,8 @@ from magcache_amd import _lib  # noqa: E402
 import hip_ops as H  # noqa: E402
 
 lib = _lib.load()
+# ATTN_VARIANTS: comma list of kernel generations (1, 2, 3); +10 = the engine's interleaved [L, 3d] operand layout
+VARIANTS = [int(v) for v in __import__("os").environ.get("ATTN_VARIANTS", "3,13").split(",")]
 L, heads = 32768, 12
 d = heads * 128
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
@@ -26,7 +28,7 @@ fl = 4.0 * L * 32760 * d
 qkv = torch.cat([q, k, v], dim=1).contiguous()        # the engine's interleaved [L, 3d] layout
 qi, ki, vi = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
 for rnd in range(2):
-    for var in (3, 13):
+    for var in VARIANTS:
         lib.mc_set_option(b"attn_kernel", var % 10)
         if var < 10:
             run = lambda: H.attention(q, k, v, o, heads, L, 32760, 1, 1 / math.sqrt(128))
