@@ -422,7 +422,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_buf(e, cur, "ao2", Lp * d * 2);
   }
   if (e->P > 1) add_buf(e, cur, "attn_lse", (size_t)e->H * Lp * 4);
-  add_buf(e, cur, "calib_partial", 1024 * 4 * 8);
+  add_buf(e, cur, "calib_partial", 2048 * 4 * 8);
   add_buf(e, cur, "calib_sums", 4 * 8);
   add_buf(e, cur, "calib_stats", 2 * 3 * 4);
   e->ws_need = cur;
@@ -850,7 +850,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
         if (!e->cfg.calibration) return fail(MC_ESTATE, "engine was created without calibration=1");
         if (e->have_res[branch]) {
           HIP_TRY(mc::launch_calib_stats(e->residual(dst), d, e->residual(e->res_slot[branch]), d, e->Lr, d,
-                                         e->buf<double>("calib_partial"), 1024, e->buf<double>("calib_sums"),
+                                         e->buf<double>("calib_partial"), 2048, e->buf<double>("calib_sums"),
                                          e->buf<float>("calib_stats") + 3 * branch, s));
           e->have_stats[branch] = true;
         } else {
@@ -941,7 +941,7 @@ static mc_status capture_unfused(mc_engine* e, int branch, mc_mode mode, hipStre
     if (!e->cfg.calibration) return fail(MC_ESTATE, "engine was created without calibration=1");
     if (e->have_res[branch]) {
       HIP_TRY(mc::launch_calib_stats(e->residual(dst), d, e->residual(e->res_slot[branch]), d, e->Lr, d,
-                                     e->buf<double>("calib_partial"), 1024, e->buf<double>("calib_sums"),
+                                     e->buf<double>("calib_partial"), 2048, e->buf<double>("calib_sums"),
                                      e->buf<float>("calib_stats") + 3 * branch, s));
       e->have_stats[branch] = true;
     } else {

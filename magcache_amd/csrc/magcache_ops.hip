@@ -16,50 +16,47 @@ namespace mc {
 
 namespace {
 
-// 8 elements / thread / iteration: 16 B of bf16 + 2 x 16 B of fp32 in, 2 x 16 B out.
-__global__ __launch_bounds__(256) void skip_add_kernel(const bf16_t* __restrict__ x0, long ldx0,
-                                                       const float* __restrict__ r, long ldr,
-                                                       float* __restrict__ out, long ldo, int M, int D8) {
-  const long total = (long)M * D8;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(i / D8), e = (int)(i % D8) * 8;
-    const u32x4 b = *(const u32x4*)(x0 + (size_t)row * ldx0 + e);
-    const f32x4 r0 = *(const f32x4*)(r + (size_t)row * ldr + e);
-    const f32x4 r1 = *(const f32x4*)(r + (size_t)row * ldr + e + 4);
-    f32x4 o0, o1;
-    o0[0] = __uint_as_float(b[0] << 16) + r0[0];
-    o0[1] = __uint_as_float(b[0] & 0xffff0000u) + r0[1];
-    o0[2] = __uint_as_float(b[1] << 16) + r0[2];
-    o0[3] = __uint_as_float(b[1] & 0xffff0000u) + r0[3];
-    o1[0] = __uint_as_float(b[2] << 16) + r1[0];
-    o1[1] = __uint_as_float(b[2] & 0xffff0000u) + r1[1];
-    o1[2] = __uint_as_float(b[3] << 16) + r1[2];
-    o1[3] = __uint_as_float(b[3] & 0xffff0000u) + r1[3];
-    *(f32x4*)(out + (size_t)row * ldo + e) = o0;
-    *(f32x4*)(out + (size_t)row * ldo + e + 4) = o1;
-  }
+// 4 elements / thread / access: 8 B of bf16 + 16 B of fp32 in, 16 B out -- every wave instruction touches one contiguous
+// 512 B / 1 KiB span; two independent groups per loop trip keep 4 loads in flight per lane.
+__device__ __forceinline__ f32x4 bf16x4_to_f32(u32x2 b) {
+  f32x4 v;
+  v[0] = __uint_as_float(b[0] << 16);
+  v[1] = __uint_as_float(b[0] & 0xffff0000u);
+  v[2] = __uint_as_float(b[1] << 16);
+  v[3] = __uint_as_float(b[1] & 0xffff0000u);
+  return v;
 }
 
-__global__ __launch_bounds__(256) void residual_sub_kernel(const float* __restrict__ x, long ldx,
-                                                           const bf16_t* __restrict__ x0, long ldx0,
-                                                           float* __restrict__ r, long ldr, int M, int D8) {
-  const long total = (long)M * D8;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(i / D8), e = (int)(i % D8) * 8;
-    const u32x4 b = *(const u32x4*)(x0 + (size_t)row * ldx0 + e);
-    const f32x4 x0v = *(const f32x4*)(x + (size_t)row * ldx + e);
-    const f32x4 x1v = *(const f32x4*)(x + (size_t)row * ldx + e + 4);
-    f32x4 o0, o1;
-    o0[0] = x0v[0] - __uint_as_float(b[0] << 16);
-    o0[1] = x0v[1] - __uint_as_float(b[0] & 0xffff0000u);
-    o0[2] = x0v[2] - __uint_as_float(b[1] << 16);
-    o0[3] = x0v[3] - __uint_as_float(b[1] & 0xffff0000u);
-    o1[0] = x1v[0] - __uint_as_float(b[2] << 16);
-    o1[1] = x1v[1] - __uint_as_float(b[2] & 0xffff0000u);
-    o1[2] = x1v[2] - __uint_as_float(b[3] << 16);
-    o1[3] = x1v[3] - __uint_as_float(b[3] & 0xffff0000u);
-    *(f32x4*)(r + (size_t)row * ldr + e) = o0;
-    *(f32x4*)(r + (size_t)row * ldr + e + 4) = o1;
+// out = x0 (bf16) + r (fp32)                                   MagCache4Wan2.1/magcache_generate.py:294-295
+// SUB: r_out = x (fp32) - x0 (bf16)                             MagCache4Wan2.1/magcache_generate.py:299-301
+// (32-bit group index: M * D/4 < 2^31, checked by the launchers)
+template <bool SUB>
+__global__ __launch_bounds__(256) void skip_add_kernel(const bf16_t* __restrict__ x0, long ldx0,
+                                                       const float* __restrict__ f, long ldf,
+                                                       float* __restrict__ out, long ldo, uint32_t total, uint32_t D4) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  auto one = [&](uint32_t g, u32x2& b, f32x4& v, size_t& o) {
+    const uint32_t row = g / D4, e = (g - row * D4) * 4;
+    b = *(const u32x2*)(x0 + (size_t)row * ldx0 + e);
+    v = *(const f32x4*)(f + (size_t)row * ldf + e);
+    o = (size_t)row * ldo + e;
+  };
+  for (; i + stride < total && i + stride > i; i += 2 * stride) {   // both groups in range: 4 loads, then 2 stores
+    u32x2 b0, b1;
+    f32x4 v0, v1;
+    size_t o0, o1;
+    one(i, b0, v0, o0);
+    one(i + stride, b1, v1, o1);
+    *(f32x4*)(out + o0) = SUB ? v0 - bf16x4_to_f32(b0) : bf16x4_to_f32(b0) + v0;
+    *(f32x4*)(out + o1) = SUB ? v1 - bf16x4_to_f32(b1) : bf16x4_to_f32(b1) + v1;
+  }
+  if (i < total) {
+    u32x2 b0;
+    f32x4 v0;
+    size_t o0;
+    one(i, b0, v0, o0);
+    *(f32x4*)(out + o0) = SUB ? v0 - bf16x4_to_f32(b0) : bf16x4_to_f32(b0) + v0;
   }
 }
 
@@ -75,14 +72,35 @@ __global__ __launch_bounds__(256) void calib_partial_kernel(const float* __restr
     const float* a = r + (size_t)row * ldr;
     const float* b = rp + (size_t)row * ldrp;
     float aa = 0.f, bb = 0.f, ab = 0.f;
-    for (int e = lane * 4; e < D; e += 256) {
-      const f32x4 av = *(const f32x4*)(a + e);
-      const f32x4 bv = *(const f32x4*)(b + e);
+    // four 16-byte chunks of each slab per lane in flight before the first FMA (8 KiB per wave); the per-lane
+    // accumulation order is still ascending e, so the sums do not depend on the unrolling
+    for (int e0 = lane * 4; e0 < D; e0 += 1024) {
+      f32x4 av[4], bv[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        aa = __builtin_fmaf(av[j], av[j], aa);
-        bb = __builtin_fmaf(bv[j], bv[j], bb);
-        ab = __builtin_fmaf(av[j], bv[j], ab);
+      for (int u = 0; u < 4; ++u) {
+        // out-of-range chunks re-read chunk 0 (always valid) and are zeroed by a select: no branch around a load
+        const int e = e0 + u * 256;
+        const int ec = e < D ? e : 0;
+        av[u] = *(const f32x4*)(a + ec);
+        bv[u] = *(const f32x4*)(b + ec);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool keep = (e0 + u * 256) < D;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          av[u][j] = keep ? av[u][j] : 0.f;
+          bv[u][j] = keep ? bv[u][j] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          aa = __builtin_fmaf(av[u][j], av[u][j], aa);
+          bb = __builtin_fmaf(bv[u][j], bv[u][j], bb);
+          ab = __builtin_fmaf(av[u][j], bv[u][j], ab);
+        }
       }
     }
     aa = wave_sum(aa);
@@ -148,17 +166,17 @@ inline int grid_for(long total, int block, int cap = 2048) {
 
 hipError_t launch_skip_add(const bf16_t* x0, long ldx0, const float* r, long ldr, float* out, long ldo, int M,
                            int D, hipStream_t stream) {
-  if ((D % 8) || (ldx0 % 8) || (ldr % 4) || (ldo % 4)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(skip_add_kernel, dim3(grid_for((long)M * (D / 8), 256, 4096)), dim3(256), 0, stream, x0, ldx0,
-                     r, ldr, out, ldo, M, D / 8);
+  if ((D % 8) || (ldx0 % 8) || (ldr % 4) || (ldo % 4) || (long)M * (D / 4) >= (1l << 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(skip_add_kernel<false>, dim3(grid_for((long)M * (D / 4), 512, 8192)), dim3(256), 0, stream, x0,
+                     ldx0, r, ldr, out, ldo, (uint32_t)M * (uint32_t)(D / 4), (uint32_t)(D / 4));
   return hipGetLastError();
 }
 
 hipError_t launch_residual_sub(const float* x, long ldx, const bf16_t* x0, long ldx0, float* r, long ldr, int M,
                                int D, hipStream_t stream) {
-  if ((D % 8) || (ldx0 % 8) || (ldr % 4) || (ldx % 4)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(residual_sub_kernel, dim3(grid_for((long)M * (D / 8), 256, 4096)), dim3(256), 0, stream, x, ldx,
-                     x0, ldx0, r, ldr, M, D / 8);
+  if ((D % 8) || (ldx0 % 8) || (ldr % 4) || (ldx % 4) || (long)M * (D / 4) >= (1l << 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(skip_add_kernel<true>, dim3(grid_for((long)M * (D / 4), 512, 8192)), dim3(256), 0, stream, x0,
+                     ldx0, x, ldx, r, ldr, (uint32_t)M * (uint32_t)(D / 4), (uint32_t)(D / 4));
   return hipGetLastError();
 }
 

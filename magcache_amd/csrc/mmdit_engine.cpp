@@ -369,7 +369,7 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
   add_buf(e, cur, "head_tokens", Li * 64 * 4);
   add_buf(e, cur, "residual0", Sp * d * 4);
   if (c.calibration) add_buf(e, cur, "residual1", Sp * d * 4);
-  add_buf(e, cur, "calib_partial", 1024 * 4 * 8);
+  add_buf(e, cur, "calib_partial", 2048 * 4 * 8);
   add_buf(e, cur, "calib_sums", 64);
   add_buf(e, cur, "calib_stats", 64);
   e->ws_need = cur;
@@ -813,7 +813,7 @@ mc_status mc_mmdit_block_post(mc_mmdit* e, int blk, mc_stream stream_) {
   if (last) {
     if (e->mode == MC_MODE_CALIB && e->have_res) {
       HIP_TRY(mc::launch_calib_stats(e->residual(e->dst), d, e->residual(e->res_cur), d, Li, d,
-                                     e->buf<double>("calib_partial"), 1024, e->buf<double>("calib_sums"),
+                                     e->buf<double>("calib_partial"), 2048, e->buf<double>("calib_sums"),
                                      e->buf<float>("calib_stats"), s));
       e->have_stats = true;
     }

@@ -98,7 +98,7 @@ def residual_sub(x, x0, r):
                                  S()))
 
 
-def calib_stats(r, rp, n_blocks=256):
+def calib_stats(r, rp, n_blocks=2048):     # 2048 = what both engines launch (32 waves per CU)
     lib = _lib.load()
     partial = torch.empty(4 * n_blocks, dtype=torch.float64, device=r.device)
     sums = torch.empty(4, dtype=torch.float64, device=r.device)
