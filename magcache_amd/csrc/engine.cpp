@@ -1208,7 +1208,8 @@ mc_status mc_set_option(const char* key, int value) {
   if (!key) return fail(MC_EINVAL, "null key");
   const std::string k(key);
   if (k == "gemm_kernel") {
-    if (value < 0 || value > 2) return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128) or 2 (256x256)");
+    if (value < 0 || value > 3)
+      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 3 (256x256, 4 waves)");
     mc::g_gemm_kernel = value;
   } else if (k == "attn_kernel") {
     if (value < 0 || value > 3)

@@ -40,9 +40,10 @@ struct GemmParams {
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
 hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stream);  // 128x128 tiles
-hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);    // 256x256 tiles
+hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);    // 256x256 tiles, 8 waves
+hipError_t launch_gemm_bf16_w128(const GemmParams& p, int epi, hipStream_t stream);   // 256x256 tiles, 4 waves x 128x128
 bool gemm_bf16_big_supported(const GemmParams& p);
-extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported
+extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported, 3 the 4-wave big variant where supported
 // fp8 (e4m3) operands, 256x256 tiles, v_mfma_f32_32x32x64_f8f6f4; K (fp8 elements) a multiple of 256
 hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);
 bool gemm_fp8_supported(const GemmParams& p);
