@@ -178,6 +178,40 @@ def test_gemm_linearity_full_shape(kernel_variant):
     torch.testing.assert_close(outs[0][idx], a[idx].float() @ Wt.float().t(), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 1024), (1000, 768, 1024), (2048, 1536, 1536), (512, 256, 8960)])
+def test_gemm_four_wave_variant_equals_eight_wave_kernel_bitwise(M, N, K):
+    """gemm_bf16_w128.hip (option 3: 4 waves x 128x128 wave tiles) accumulates every output element in the same k order
+    with the same MFMA as gemm_bf16_big.hip (option 2), so all epilogues must agree bit for bit; and both are the fp32
+    product up to accumulation order."""
+    lib = _lib.load()
+    A = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    Wt = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    bias, gate, x_in = rnd(N, seed=3), rnd(N, seed=5), rnd(M, N, seed=4)
+    X0 = rnd(M, N, seed=6, dtype=torch.bfloat16)
+    res = {}
+    try:
+        for var in (2, 3):
+            _lib.check(lib.mc_set_option(b"gemm_kernel", var))
+            Cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            H.gemm(A, Wt, bias, 0, Cb=Cb)
+            Cg = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            H.gemm(A, Wt, bias, 1, Cb=Cg)
+            X = x_in.clone()
+            H.gemm(A, Wt, bias, 2, X=X, gate=gate)
+            Xc, R = x_in.clone(), torch.zeros(M, N, device=DEV)
+            H.gemm(A, Wt, bias, 3, X=Xc, gate=gate, X0=X0, R=R)
+            F32 = torch.zeros(M, N, device=DEV)
+            H.gemm(A, Wt, bias, 5, X=F32)
+            torch.cuda.synchronize()
+            res[var] = (Cb, Cg, X, Xc, R, F32)
+    finally:
+        _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
+    for a, b in zip(res[2], res[3]):
+        assert torch.equal(a, b)
+    ref = A.float() @ Wt.float().t() + bias
+    torch.testing.assert_close(res[3][5], ref, rtol=1e-4, atol=1e-3 * math.sqrt(K / 64))
+
+
 # ----------------------------------------------------------------------------- attention
 def attn_ref(q, k, v, n_heads, valid_idx):
     Lq = q.shape[0]
