@@ -164,11 +164,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
 
   // LDS-DMA issue in inline asm: hipcc's waitcnt pass makes every ds_read that follows a
   // __builtin_amdgcn_global_load_lds wait for it (vmcnt(0) in the loop); an asm DMA is invisible to
-  // that pass and ordered only by the counted waits below.  saddr form: 64-bit uniform base in
-  // SGPRs + one 32-bit byte offset per lane.  M0 = LDS byte address of the piece (wave-uniform);
-  // s_nop covers the SALU-write-M0 -> LDS-DMA hazard; M0 is restored for the compiler.
-  // one 1 KiB piece: M0 = LDS byte address (wave-uniform), saddr form: 64-bit uniform base + 32-bit
-  // lane offset; s_nop covers the SALU-write-M0 -> LDS-DMA hazard; M0 is restored for the compiler.
+  // that pass and ordered only by the counted waits below.  One 1 KiB piece per call.  saddr form: 64-bit
+  // uniform base in SGPRs + one 32-bit byte offset per lane; M0 = LDS byte address of the piece
+  // (wave-uniform); s_nop covers the SALU-write-M0 -> LDS-DMA hazard.
   auto dma1 = [&](const bf16_t* base, uint32_t off, uint32_t lds) {
     // M0 is clobbered, not saved: nothing the compiler emits in this kernel reads it
     asm volatile(
