@@ -48,6 +48,16 @@ constexpr int GROUP_M = 8;
   } while (0)
 #define MC_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// Build-time experiment (tools/build_variants.py gemm_bf16_w128.hip 16; NOT in the shipped library, unmeasured):
+// MC_ABL & 16 = two barriers per K tile instead of four.  Waits and barriers only after q1 and q3; a half is still
+// refilled at least one barrier after its last read and needed 4 (not 5) halves after it was issued:
+//   end of q1: Wn0, Am0 of tile kt+1 landed -> vmcnt(16);  end of q3: Wn1, Am1 of tile kt+1 landed -> vmcnt(16);
+//   tile nk-2: 8, 0;  tile nk-1: nothing;  the prologue waits for all four halves of tile 0 -> vmcnt(16).
+#ifndef MC_ABL
+#define MC_ABL 0
+#endif
+constexpr bool TWO_BARRIERS = (MC_ABL & 16) != 0;
+
 struct Frag4 {  // one 32-row block x 64 k = 4 MFMA operands
   bf16x8 v[4];
 };
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_w128_kernel(GemmParams p, int tilesM
   // ---- prologue: K tiles 0 and 1 in the steady-state issue order (32 DMAs); Wn0(0), Am0(0), Wn1(0) landed
   dma_w(0, 0, 0); dma_a(0, 0, 0); dma_w(0, 0, 1); dma_a(0, 0, 1);
   dma_w(1, 1, 0); dma_a(1, 1, 0); dma_w(1, 1, 1); dma_a(1, 1, 1);
-  MC_WAIT(20);
+  if (TWO_BARRIERS) MC_WAIT(16); else MC_WAIT(20);
   MC_BARRIER();
   Frag4 A0[2], A1[2], W0[2], W1[2], W2[2];
 #pragma unroll
@@ -203,29 +213,43 @@ __global__ __launch_bounds__(256) void gemm_w128_kernel(GemmParams p, int tilesM
       auto rd = [&](int i) { read_w1(ST, 1, i, W1); }; \
       auto dm = [&](int j) { if (TAIL == 0) dma_w1((kt) + 2, ST, 0, j); }; \
       MC_IVAL(W0, A0, q00, rd, dm) \
-      if (TAIL == 0) MC_WAIT(20); else if (TAIL == 1) MC_WAIT(16); else MC_WAIT(0); \
-      MC_BARRIER(); \
+      if (!TWO_BARRIERS) { \
+        if (TAIL == 0) MC_WAIT(20); else if (TAIL == 1) MC_WAIT(16); else MC_WAIT(0); \
+        MC_BARRIER(); \
+      } \
     } \
     { /* q1: (m0,n1); reads Am1(kt); DMA Am0(kt+2) */ \
       auto rd = [&](int i) { read_a1(ST, 1, i, A1); }; \
       auto dm = [&](int j) { if (TAIL == 0) dma_a1((kt) + 2, ST, 0, j); }; \
       MC_IVAL(W1, A0, q01, rd, dm) \
-      if (TAIL == 0) MC_WAIT(20); else if (TAIL == 1) MC_WAIT(12); \
-      MC_BARRIER(); \
+      if (TWO_BARRIERS) { \
+        if (TAIL == 0) MC_WAIT(16); else if (TAIL == 1) MC_WAIT(8); \
+        if (TAIL != 2) MC_BARRIER(); \
+      } else { \
+        if (TAIL == 0) MC_WAIT(20); else if (TAIL == 1) MC_WAIT(12); \
+        MC_BARRIER(); \
+      } \
     } \
     { /* q2: (m1,n1); reads Wn0(kt+1); DMA Wn1(kt+2) */ \
       auto rd = [&](int i) { if (TAIL != 2) read_w1(1 - ST, 0, i, W2); }; \
       auto dm = [&](int j) { if (TAIL == 0) dma_w1((kt) + 2, ST, 1, j); }; \
       MC_IVAL(W1, A1, q11, rd, dm) \
-      if (TAIL == 0) MC_WAIT(20); else if (TAIL == 1) MC_WAIT(8); \
-      MC_BARRIER(); \
+      if (!TWO_BARRIERS) { \
+        if (TAIL == 0) MC_WAIT(20); else if (TAIL == 1) MC_WAIT(8); \
+        MC_BARRIER(); \
+      } \
     } \
     { /* q3: (m1,n0); reads Am0(kt+1); DMA Am1(kt+2) */ \
       auto rd = [&](int i) { if (TAIL != 2) read_a1(1 - ST, 0, i, A0); }; \
       auto dm = [&](int j) { if (TAIL == 0) dma_a1((kt) + 2, ST, 1, j); }; \
       MC_IVAL(W0, A1, q10, rd, dm) \
-      if (TAIL == 0) MC_WAIT(20); else if (TAIL == 1) MC_WAIT(4); \
-      MC_BARRIER(); \
+      if (TWO_BARRIERS) { \
+        if (TAIL == 0) MC_WAIT(16); else if (TAIL == 1) MC_WAIT(0); \
+        if (TAIL != 2) MC_BARRIER(); \
+      } else { \
+        if (TAIL == 0) MC_WAIT(20); else if (TAIL == 1) MC_WAIT(4); \
+        MC_BARRIER(); \
+      } \
     } \
   }
 
