@@ -39,7 +39,10 @@ SIZE_CONFIGS = {"720*1280": (720, 1280), "1280*720": (1280, 720), "480*832": (48
 SUPPORTED_SIZES = {"t2v-14B": ("720*1280", "1280*720", "480*832", "832*480"), "t2v-1.3B": ("480*832", "832*480"),
                    "t2i-14B": tuple(SIZE_CONFIGS.keys()),
                    "i2v-14B": ("720*1280", "1280*720", "480*832", "832*480"),
-                   "vace-1.3B": ("480*832", "832*480"), "vace-14B": ("720*1280", "1280*720", "480*832", "832*480")}
+                   "vace-1.3B": ("480*832", "832*480"), "vace-14B": ("720*1280", "1280*720", "480*832", "832*480"),
+                   # Wan2.2 two-expert models (MagCache4Wan2.2/magcache_generate.py); ti2v-5B is not implemented
+                   "t2v-A14B": ("720*1280", "1280*720", "480*832", "832*480"),
+                   "i2v-A14B": ("720*1280", "1280*720", "480*832", "832*480")}
 EXAMPLE_PROMPT = "Two anthropomorphic cats in comfy boxing gear and bright gloves fight intensely on a spotlighted stage."
 
 
@@ -56,6 +59,16 @@ def str2bool(v):
 def _validate_args(args):
     """magcache_generate.py:563-595"""
     assert args.task in SUPPORTED_SIZES, f"Unsupport task: {args.task} (this engine: {', '.join(SUPPORTED_SIZES)})"
+    if args.task.endswith("A14B"):
+        # MagCache4Wan2.2/magcache_generate.py:409-419: the defaults come from the task's upstream config
+        from magcache_amd.wan22 import WAN22_DEFAULTS
+        d = WAN22_DEFAULTS[args.task]
+        args.sample_steps = d["sample_steps"] if args.sample_steps is None else args.sample_steps
+        args.sample_shift = d["sample_shift"] if args.sample_shift is None else args.sample_shift
+        g = args.sample_guide_scale
+        args.sample_guide_scale = d["guide_scale"] if g is None else (g, g)     # (low-noise, high-noise expert)
+    if args.sample_guide_scale is None:
+        args.sample_guide_scale = 5.0
     if args.sample_steps is None:
         args.sample_steps = 50
     if args.sample_shift is None:
@@ -82,7 +95,7 @@ def _parse_args(argv=None):
     p.add_argument("--sample_solver", type=str, default="unipc", choices=["unipc", "dpm++", "euler"])
     p.add_argument("--sample_steps", type=int, default=None)
     p.add_argument("--sample_shift", type=float, default=None)
-    p.add_argument("--sample_guide_scale", type=float, default=5.0)
+    p.add_argument("--sample_guide_scale", type=float, default=None)
     p.add_argument("--magcache_thresh", type=float, default=0.12)
     p.add_argument("--retention_ratio", type=float, default=0.2)
     p.add_argument("--magcache_K", type=int, default=2)
@@ -152,6 +165,8 @@ def generate(args):
     if args.ulysses_size > 1 or args.ring_size > 1:
         logging.info("--ulysses_size/--ring_size are ignored: the token sequence is sharded over WORLD_SIZE ranks")
 
+    if args.task.endswith("A14B"):
+        return _generate_wan22(args, device, rank, world, layout)
     is_i2v, is_vace = "i2v" in args.task, "vace" in args.task
     if is_i2v:
         cfg = WAN_I2V_14B
@@ -221,6 +236,69 @@ def generate(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     logging.info(f"denoising: {dt:.2f} s, {args.sample_steps / dt:.3f} steps/s")
+    if rank == 0:
+        out = args.save_file or f"{args.task}_{args.size.replace('*', 'x')}_{args.base_seed}_latent.pt"
+        torch.save(latent.cpu(), out)
+        logging.info(f"Saving the final latent to {out} (no VAE decoder in this repository)")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return latent
+
+
+def _generate_wan22(args, device, rank, world, layout):
+    """--task t2v-A14B / i2v-A14B: the two-expert loop of MagCache4Wan2.2/magcache_generate.py (:683-800) on two
+    engines.  --ckpt_dir follows the upstream layout (high_noise_model/ and low_noise_model/ with *.safetensors);
+    i2v-A14B takes --y_file ([20, F, H/8, W/8]: mask + first-frame latent), there is no CLIP branch in Wan2.2."""
+    import torch
+    import torch.distributed as dist
+    from magcache_amd import wan22
+    from magcache_amd.engine import synthetic_weights
+    d = wan22.WAN22_DEFAULTS[args.task]
+    mode = "i2v" if args.task.startswith("i2v") else "t2v"
+    cfg = wan22.WAN22_I2V_A14B if mode == "i2v" else wan22.WAN22_T2V_A14B
+    H, W = SIZE_CONFIGS[args.size][1], SIZE_CONFIGS[args.size][0]
+    grid = ((args.frame_num - 1) // 4 + 1, H // 8, W // 8)
+    logging.info(f"Generation job args: {args}")
+    sp = dict(sp_rank=layout.sp_rank, sp_size=layout.sp_size, sp_group=layout.sp_group) if layout else {}
+    high, low = wan22.make_experts(cfg, grid, device=device, calibration=args.magcache_calibration, **sp)
+    for seed, (m, sub) in enumerate(((high, "high_noise_model"), (low, "low_noise_model"))):
+        files = sorted(glob.glob(os.path.join(args.ckpt_dir or "", sub, "*.safetensors")))
+        if files:
+            from safetensors.torch import load_file
+            sd = {}
+            for f in files:
+                sd.update(load_file(f, device="cpu"))
+            m.load_state_dict(sd)
+            logging.info(f"{sub}: loaded {len(sd)} tensors")
+        else:
+            logging.warning(f"no {sub}/*.safetensors under --ckpt_dir: seeded RANDOM-INIT weights of the architecture")
+            m.engine.load_weights(synthetic_weights(cfg, seed=seed, device=device))
+    split = wan22.high_noise_steps(args.sample_shift, args.sample_steps, d["boundary"])          # :696-697
+    if args.use_magcache:
+        wan22.init_magcache(high, wan22.table_without_pad("wan2.2_i2v_A14B" if mode == "i2v" else "wan2.2_t2v_A14B"),
+                            args.sample_steps, args.magcache_thresh, args.magcache_K, args.retention_ratio,
+                            split_steps=split, mode=mode)                                          # :698, :774
+    if args.magcache_calibration:
+        wan22.init_magcache_calibration(high, args.sample_steps)                                   # :704, :780
+    prompt = args.prompt or EXAMPLE_PROMPT
+    ctx = _context(args.context_file, prompt, args.base_seed, cfg["text_dim"], device)
+    ctx_null = _context(args.context_null_file, "", args.base_seed + 1, cfg["text_dim"], device)
+    g = torch.Generator(device=device).manual_seed(args.base_seed)
+    noise = torch.randn(16, *grid, dtype=torch.float32, device=device, generator=g)
+    y = None
+    if mode == "i2v":
+        gi = torch.Generator(device="cpu").manual_seed(args.base_seed + 2)
+        y = (torch.load(args.y_file, map_location="cpu") if args.y_file
+             else torch.randn(20, *grid, generator=gi)).float().to(device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    latent = wan22.sample(high, low, noise, ctx, ctx_null, d["boundary"], sampling_steps=args.sample_steps,
+                          shift=args.sample_shift, guide_scale=args.sample_guide_scale, y=y, solver=args.sample_solver,
+                          layout=layout)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    logging.info(f"denoising: {dt:.2f} s, {args.sample_steps / dt:.3f} steps/s ({split} high-noise steps)")
     if rank == 0:
         out = args.save_file or f"{args.task}_{args.size.replace('*', 'x')}_{args.base_seed}_latent.pt"
         torch.save(latent.cpu(), out)

@@ -16,10 +16,12 @@ What differs from Wan2.1 on the hot path:
     tokens carry the same t, which makes it the Wan2.1 computation -- what the engine runs.  (TI2V-5B gives
     the first-frame tokens their own t: not implemented.)
 """
+import json
+
 import numpy as np
 import torch
 
-from .engine import MC_MODE_FULL, MC_MODE_SKIP, WAN_T2V_14B
+from .engine import MC_MODE_CALIB, MC_MODE_FULL, MC_MODE_SKIP, WAN_T2V_14B
 from .mag_ratios import TABLES
 from .model import WanModelHIP, nearest_interp
 
@@ -95,6 +97,54 @@ def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
     return out
 
 
+def magcache_calibration(self, x, t, context, seq_len, clip_fea=None, y=None):
+    """Drop-in for MagCache4Wan2.2/magcache_generate.py magcache_calibration (:98-208): never skips; from the third
+    call on records norm_ratio / norm_std / cos_dis of the new residual against residual_cache[cnt % 2] -- which, on
+    the first two calls after the expert switch, is the residual the OTHER expert produced (the cache is a class
+    attribute): it is handed to this expert's engine before the forward.  The three JSON files keep the reference's
+    names (it writes wan2_1_* here too, :205-207)."""
+    if self.model_type == "i2v":
+        assert y is not None
+    if y is not None:
+        x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
+    type(self)._check_inputs(_T2VChecks(self), x, context, seq_len, None, None)
+    cls = type(self)
+    cnt = int(cls.cnt)
+    p = cnt % 2
+    cached = cls.residual_cache[p]
+    if cnt >= 2 and cached is not None and cached.data_ptr() != self.engine.residual(p).data_ptr():
+        self.engine.import_residual(p, cached)
+    out = self._run(x, t, context, p, MC_MODE_CALIB)
+    if cnt >= 2:
+        norm_ratio, norm_std, cos_dis = self.engine.calib_stats(p)
+        cls.norm_ratio.append(round(norm_ratio, 5))
+        cls.norm_std.append(round(norm_std, 5))
+        cls.cos_dis.append(round(cos_dis, 5))
+        print(f"time: {cnt}, norm_ratio: {norm_ratio}, norm_std: {norm_std}, cos_dis: {cos_dis}")
+    cls.residual_cache[p] = self.engine.residual(p)
+    cls.cnt = cnt + 1
+    if cls.cnt >= cls.num_steps:
+        cls.cnt = 0
+        for title, name, v in (("norm ratio", "wan2_1_mag_ratio", cls.norm_ratio), ("norm std", "wan2_1_mag_std", cls.norm_std),
+                               ("cos_dis", "wan2_1_cos_dis", cls.cos_dis)):
+            print(title)
+            print(v)
+            with open(name + ".json", "w") as f:
+                json.dump(v, f)
+    return out
+
+
+def init_magcache_calibration(model, sample_steps):
+    """:365-373.  `model` is either expert (created with make_experts(..., calibration=True))."""
+    cls = model.__class__
+    cls.forward = magcache_calibration
+    cls.cnt = 0
+    cls.num_steps = sample_steps * 2
+    cls.norm_ratio, cls.norm_std, cls.cos_dis = [], [], []
+    cls.residual_cache = [None, None]
+    return model
+
+
 class _T2VChecks:
     """view of a model whose input checks are the t2v ones (Wan2.1's i2v check asks for clip_fea)"""
     model_type = "t2v"
@@ -139,11 +189,12 @@ def table_without_pad(name):
     return t[2:] if (len(t) >= 2 and t[0] == 1.0 and t[1] == 1.0) else t
 
 
-def make_experts(cfg, latent_grid, device="cuda:0", name="WanModelHIP22", **kw):
-    """two engines (high-noise, low-noise) whose shims are instances of ONE fresh class"""
+def make_experts(cfg, latent_grid, device="cuda:0", name="WanModelHIP22", calibration=False, **kw):
+    """two engines (high-noise, low-noise) whose shims are instances of ONE fresh class; calibration=True reserves the
+    extra residual slot init_magcache_calibration needs"""
     cls = type(name, (WanModelHIP,), {"model_type": "i2v" if cfg["in_dim"] == 36 else "t2v"})
-    hi = cls(cfg, latent_grid, device=device, calibration=False, **kw)
-    lo = cls(cfg, latent_grid, device=device, calibration=False, **kw)
+    hi = cls(cfg, latent_grid, device=device, calibration=calibration, **kw)
+    lo = cls(cfg, latent_grid, device=device, calibration=calibration, **kw)
     return hi, lo
 
 

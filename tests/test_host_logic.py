@@ -213,6 +213,57 @@ def test_generate_cli_accepts_i2v_and_vace_tasks():
         G._parse_args(["--task", "vace-1.3B", "--size", "1280*720"])          # not a supported size of the 1.3B model
 
 
+def test_generate_cli_wan22_tasks_take_their_defaults_from_the_task_config():
+    """MagCache4Wan2.2/magcache_generate.py:409-419: steps / shift / guide scale default to the task's upstream config"""
+    from magcache_amd import generate as G
+    a = G._parse_args(["--task", "t2v-A14B", "--use_magcache"])
+    assert (a.sample_steps, a.sample_shift, a.sample_guide_scale, a.frame_num) == (40, 12.0, (3.0, 4.0), 81)
+    a = G._parse_args(["--task", "i2v-A14B", "--size", "832*480", "--sample_steps", "20", "--sample_guide_scale", "4.5"])
+    assert (a.sample_steps, a.sample_shift, a.sample_guide_scale) == (20, 5.0, (4.5, 4.5))
+    assert G._parse_args(["--task", "t2v-14B"]).sample_guide_scale == 5.0
+
+
+def test_generate_wan22_glue_on_fakes(tmp_path, monkeypatch):
+    """generate() for --task i2v-A14B with the engines, the sampler and the CUDA calls replaced by fakes: two experts of
+    the 36-channel architecture, class-shared MagCache state with the split step of the schedule, y handed to the loop,
+    latent saved.  (The engines themselves: tests/test_engine_gpu.py::test_wan22_two_experts_i2v_vs_oracle.)"""
+    import torch
+    from magcache_amd import generate as G
+    from magcache_amd import engine as E
+    wan22, cls, hi, lo = make_experts22()
+    seen = {}
+    for m in (hi, lo):
+        m.engine.load_weights = lambda w, tag=m.engine.tag: seen.setdefault("weights", []).append((tag, w))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setattr(E, "synthetic_weights", lambda cfg, seed, device: ("synthetic", cfg["in_dim"], seed))
+    monkeypatch.setattr(wan22, "make_experts", lambda cfg, grid, device, calibration=False, **kw:
+                        (seen.update(cfg=cfg, grid=grid, calibration=calibration), (hi, lo))[1])
+
+    def fake_sample(high, low, noise, ctx, ctx_null, boundary, **kw):
+        seen.update(boundary=boundary, kw=kw, noise=tuple(noise.shape), ctx=tuple(ctx.shape))
+        return noise
+
+    monkeypatch.setattr(wan22, "sample", fake_sample)
+    real_gen, real_randn = torch.Generator, torch.randn
+    monkeypatch.setattr(torch, "Generator", lambda device="cpu": real_gen(device="cpu"))
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: real_randn(*a, **{kk: v for kk, v in k.items() if kk != "device"}))
+    monkeypatch.setattr(G, "_context", lambda path, prompt, seed, dim, device: real_randn(8, dim))
+    out = tmp_path / "lat.pt"
+    args = G._parse_args(["--task", "i2v-A14B", "--size", "832*480", "--frame_num", "5", "--base_seed", "3",
+                          "--use_magcache", "--magcache_K", "2", "--save_file", str(out)])
+    monkeypatch.setattr(torch.Tensor, "to", lambda self, *a, **k: self)
+    lat = G.generate(args)
+    assert seen["cfg"]["in_dim"] == 36 and seen["grid"] == (2, 60, 104) and seen["calibration"] is False
+    assert seen["weights"] == [("hi", ("synthetic", 36, 0)), ("lo", ("synthetic", 36, 1))]
+    split = wan22.high_noise_steps(5.0, 40, 0.9)
+    assert cls.forward is wan22.magcache_forward and cls.split_step == 2 * split and cls.mode == "i2v"
+    assert len(cls.mag_ratios) == 80 and cls.K == 2
+    assert seen["boundary"] == 0.9 and seen["kw"]["guide_scale"] == (3.5, 3.5) and seen["kw"]["sampling_steps"] == 40
+    assert tuple(seen["kw"]["y"].shape) == (20, 2, 60, 104) and seen["noise"] == (16, 2, 60, 104)
+    assert tuple(torch.load(out).shape) == (16, 2, 60, 104) and lat is not None
+
+
 def test_generate_cli_defaults_and_validation():
     """the flags, defaults and checks of the reference's _parse_args / _validate_args
     (MagCache4Wan2.1/magcache_generate.py:563-595, :598-775) for the hot-path arguments"""
@@ -302,6 +353,30 @@ def test_wan22_skip_uses_the_other_experts_residual():
     lo(["x"], t=0, context=["c"], seq_len=4)
     lo(["x"], t=0, context=["c"], seq_len=4)      # branch 0 again: now its own slot, nothing to import
     assert lo.engine.imported == [(0, "hi"), (1, "hi")]
+
+
+def test_wan22_calibration_shim_across_the_expert_switch(tmp_path, monkeypatch, capsys):
+    """MagCache4Wan2.2 magcache_calibration (:98-208): class-shared counter / cache over both experts, statistics from
+    the third call on, the other expert's residual handed over at the switch, JSON dump + reset at the end"""
+    monkeypatch.chdir(tmp_path)
+    wan22, cls, hi, lo = make_experts22()
+    for m in (hi, lo):
+        m.engine.calib_stats = lambda p, tag=m.engine.tag: (1.23456789, 0.5, 0.25)
+    wan22.init_magcache_calibration(hi, 3)
+    assert cls.num_steps == 6 and cls.residual_cache == [None, None] and cls.forward is wan22.magcache_calibration
+    for step in range(3):
+        m = hi if step < 1 else lo                      # expert switch after the first step
+        for _ in range(2):
+            assert m(["x"], t=0, context=["c"], seq_len=4) == ["out"]
+    assert [(e, b) for e, b, _ in cls.trace] == [("hi", 0), ("hi", 1), ("lo", 0), ("lo", 1), ("lo", 0), ("lo", 1)]
+    assert all(mode == _lib.MC_MODE_CALIB for _, _, mode in cls.trace)
+    # calls 2 and 3 (first of the low-noise expert) compare against the high-noise expert's residuals
+    assert lo.engine.imported == [(0, "hi"), (1, "hi")] and hi.engine.imported == []
+    assert cls.norm_ratio == [1.23457] * 4 and cls.norm_std == [0.5] * 4 and cls.cos_dis == [0.25] * 4
+    assert cls.cnt == 0 and cls.residual_cache[0].tag == "lo"
+    assert json.load(open(tmp_path / "wan2_1_mag_ratio.json")) == [1.23457] * 4
+    assert json.load(open(tmp_path / "wan2_1_cos_dis.json")) == [0.25] * 4
+    assert "norm ratio" in capsys.readouterr().out
 
 
 def test_wan22_timesteps_and_split():
