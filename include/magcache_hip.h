@@ -73,9 +73,9 @@ const char* mc_last_error(void);
 const char* mc_version(void);
 /* Process-wide tuning knobs (no reference counterpart; results are identical for every setting up
  * to fp32 summation order): "gemm_kernel" 0 = chosen by shape, 1 = 128x128-tile kernel, 2 = 256x256
- * counted-vmcnt kernel wherever it applies, 3 = its 4-wave / 128x128-wave-tile variant wherever it applies (never
- * chosen by shape); "attn_kernel" 0 = default, 1 = 8-wave kernel, 2 = 4-wave
- * software-pipelined kernel, 3 = 8-wave software-pipelined kernel.  Used by the A/B micro-benchmarks and the parity tests. */
+ * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 (= 3) = the one attention kernel shipped.  Used by the
+ * parity tests and the A/B micro-benchmarks (tools/build_ab_lib.py builds a library that also answers to the
+ * retired kernel generations under tools/kernels_ab/). */
 mc_status mc_set_option(const char* key, int value);
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -1,14 +1,15 @@
 // Flash-style non-causal attention for gfx950, head_dim 128 -- 8 waves, software pipelined.
 //
-// Same contract as attention.hip / attention_v2.hip (upstream wan/modules/attention.py
-// flash_attention(q,k,v,k_lens); reference call site MagCache4Wan2.1/magcache_generate.py:297-298).
+// Contract: upstream wan/modules/attention.py flash_attention(q,k,v,k_lens) (reference call site
+// MagCache4Wan2.1/magcache_generate.py:297-298).  The two earlier generations of this kernel (8 waves unpipelined,
+// 4 waves x 64 rows) live in tools/kernels_ab/ and are linked only into the A/B library of tools/build_ab_lib.py.
 //
 // Why this shape (measured with tools/ubench_issue.cpp on MI355X): ONE wave issues at most one
 // v_mfma_f32_32x32x16_bf16 per ~35 cycles and hides only ~4 other instructions behind it, each
 // further VALU instruction costs ~4.5 cycles (v_exp_f32 ~10).  TWO waves on a SIMD sustain one MFMA
 // per ~17.5 cycles and twice the VALU issue rate.  Attention needs ~7 non-MFMA instructions per MFMA
-// (exp2, fma, row sums, bf16 packing, row maxima, K / V^T fragment reads), so the 4-wave kernel of
-// attention_v2.hip is issue-bound at one wave per SIMD; here every SIMD runs two waves of 32 query
+// (exp2, fma, row sums, bf16 packing, row maxima, K / V^T fragment reads), so a 4-wave kernel
+// (tools/kernels_ab/attention_v2.hip) is issue-bound at one wave per SIMD; here every SIMD runs two waves of 32 query
 // rows each (256 VGPRs per wave, all MFMAs in VGPR form -- no AGPR copies, no asm MFMAs), and each
 // wave runs the same software pipeline:
 //
@@ -20,7 +21,7 @@
 //    (wave-uniform, rare); the decision for tile t is taken after PV(t-1) is complete and before
 //    P(t) is exponentiated.
 //  * S^T = K Q^T is issued swapped and its accumulator layout is the B operand of the PV MFMA, as
-//    in attention.hip; fragment layouts and LDS swizzles are identical to that kernel.
+//    (an MFMA's contraction index may be permuted if both operands agree).
 //  * K/V tiles: LDS-DMA (global_load_lds_dwordx4, inline asm so hipcc's waitcnt pass does not
 //    serialise ds_reads behind it) into 3-deep rings; the 4 pieces a wave moves per tile are issued
 //    between MFMAs; one counted s_waitcnt vmcnt(4) + s_barrier per tile.
@@ -511,6 +512,21 @@ hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(attn_fwd_v3_kernel, dim3(nqb * p.n_heads), dim3(512), LDS_BYTES, stream, p, nqb,
                      tiles_per_shard);
   return hipGetLastError();
+}
+
+// mc_set_option("attn_kernel", v): 0 / 3 = this kernel.  The A/B library (tools/build_ab_lib.py, -DMC_AB_KERNELS)
+// also links tools/kernels_ab/attention{,_v2}.hip as 1 / 2; the shipped library has this kernel only.
+int g_attn_kernel = 0;
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+  const bool two_phase = p.skip_shard_p1 != 0 || p.lse_out || p.lse_in;
+  if (two_phase && (p.skip_shard_p1 < 0 || p.skip_shard_p1 > p.n_shards || (p.skip_shard_p1 && p.n_shards < 2)))
+    return hipErrorInvalidValue;
+#ifdef MC_AB_KERNELS
+  if (!two_phase && g_attn_kernel == 1) return launch_attention_v1(p, stream);
+  if (!two_phase && g_attn_kernel == 2) return launch_attention_v2(p, stream);
+#endif
+  return launch_attention_v3(p, stream);
 }
 
 }  // namespace mc

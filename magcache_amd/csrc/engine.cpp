@@ -234,8 +234,9 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   e->L = c.latent_f * (c.latent_h / 2) * (c.latent_w / 2);
   e->P = c.sp_size; e->rank = c.sp_rank;
   if (e->L % e->P) {
+    const int seq_len = e->L;
     delete e;
-    return fail(MC_EINVAL, "seq_len %d not divisible by sp_size %d", e->L, c.sp_size);
+    return fail(MC_EINVAL, "seq_len %d not divisible by sp_size %d", seq_len, c.sp_size);
   }
   e->Lr = e->L / e->P;
   e->Lp = (int)align_up(e->Lr, 256);
@@ -1208,12 +1209,19 @@ mc_status mc_set_option(const char* key, int value) {
   if (!key) return fail(MC_EINVAL, "null key");
   const std::string k(key);
   if (k == "gemm_kernel") {
-    if (value < 0 || value > 3)
-      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 3 (256x256, 4 waves)");
+#ifdef MC_AB_KERNELS
+    const int gemm_max = 3;
+#else
+    const int gemm_max = 2;
+#endif
+    if (value < 0 || value > gemm_max)
+      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128) or 2 (256x256)");
     mc::g_gemm_kernel = value;
   } else if (k == "attn_kernel") {
-    if (value < 0 || value > 3)
-      return fail(MC_EINVAL, "attn_kernel must be 0 (default), 1 (8-wave), 2 (4-wave pipelined) or 3 (8-wave pipelined)");
+#ifndef MC_AB_KERNELS
+    if (value != 0 && value != 3) return fail(MC_EINVAL, "attn_kernel must be 0 or 3 (one attention kernel is shipped)");
+#endif
+    if (value < 0 || value > 3) return fail(MC_EINVAL, "attn_kernel must be 0..3");
     mc::g_attn_kernel = value;
   } else {
     return fail(MC_EINVAL, "unknown option '%s'", key);

@@ -186,8 +186,8 @@ hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stre
 }
 
 // Kernel choice.  g_gemm_kernel: 0 = by shape, 1 = always the 128x128 kernel, 2 = the 256x256
-// kernel wherever it is supported, 3 = its 4-wave variant gemm_bf16_w128.hip wherever supported
-// (mc_set_option("gemm_kernel", v); used by the A/B benchmarks).
+// kernel wherever it is supported (mc_set_option("gemm_kernel", v); used by the parity tests and A/B benchmarks);
+// 3 = the 4-wave variant tools/kernels_ab/gemm_bf16_w128.hip, linked only into the A/B library (-DMC_AB_KERNELS).
 // By shape: estimated throughput = (fraction of the tile slots the grid fills, over its whole number of waves) x the
 // kernel's per-tile rate.  The 256x256 kernel runs one workgroup per CU (256 slots) and is ~1.3x faster per tile; the
 // 128x128 kernel runs two per CU (512 slots) and has 4x the tiles, so it wins when M*N is small (measured on the
@@ -212,9 +212,11 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
       big = 1.3 * fill_efficiency(tiles_big, 256) >= fill_efficiency(tiles_small, 512);
     }
   }
+#ifdef MC_AB_KERNELS
   if (g_gemm_kernel == 3 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
       gemm_bf16_big_supported(p))
     return launch_gemm_bf16_w128(p, epi, stream);   // the 4-wave 128x128-wave-tile variant: explicit request only
+#endif
   return big ? launch_gemm_bf16_big(p, epi, stream) : launch_gemm_bf16_small(p, epi, stream);
 }
 

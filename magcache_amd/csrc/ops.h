@@ -41,9 +41,9 @@ struct GemmParams {
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
 hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stream);  // 128x128 tiles
 hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);    // 256x256 tiles, 8 waves
-hipError_t launch_gemm_bf16_w128(const GemmParams& p, int epi, hipStream_t stream);   // 256x256 tiles, 4 waves x 128x128
+hipError_t launch_gemm_bf16_w128(const GemmParams& p, int epi, hipStream_t stream);   // tools/kernels_ab (A/B library only)
 bool gemm_bf16_big_supported(const GemmParams& p);
-extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported, 3 the 4-wave big variant where supported
+extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported (3: A/B library only)
 // fp8 (e4m3) operands, 256x256 tiles, v_mfma_f32_32x32x64_f8f6f4; K (fp8 elements) a multiple of 256
 hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);
 bool gemm_fp8_supported(const GemmParams& p);
@@ -73,10 +73,10 @@ struct AttnParams {
 };
 // K/V rows in [shard_valid, shard_rows) are read (and masked) but must hold finite values.
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);     // picks a kernel
-hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows
-hipError_t launch_attention_v2(const AttnParams& p, hipStream_t stream);  // 4 waves x 64 rows, pipelined
-hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows, pipelined
-extern int g_attn_kernel;  // 0 default, 1 v1, 2 v2, 3 v3
+hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows, pipelined (the kernel)
+hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)
+hipError_t launch_attention_v2(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)
+extern int g_attn_kernel;  // 0 / 3: attention_v3.hip (1, 2: A/B library only)
 
 // ---------------------------------------------------------------- token-wise ops (elementwise.hip)
 // out[m,:] = bf16( LN(x[m,:]) * a + b ),  a = 1+scale (modulate) or weight (affine)

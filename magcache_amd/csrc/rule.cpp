@@ -39,11 +39,21 @@ bool strict_less(int variant) {
          variant == MC_RULE_WAN22_TI2V || variant == MC_RULE_QWEN;
 }
 
-// index of the table entry the call at counter cnt reads
+// index of the table entry the call at counter cnt reads.  May be negative for the two eval variants when num_steps
+// is short (eval Wan opens its gate at int(n*0.2) but reads ratio[t-10]): the reference indexes a Python list / ndarray,
+// which wraps a negative index once (ratios[-3] = third from the end) and raises beyond that -- table_entry() below
+// does the same wrap, and mc_rule_create rejects every configuration that would raise.
 int ratio_index(const mc_rule* r) {
   if (r->variant == MC_RULE_EVAL_WAN) return r->cnt - 10;       // "ratios are cached after 10 steps"
   if (r->variant == MC_RULE_EVAL_OPENSORA) return r->cnt - 1;
   return r->cnt;
+}
+
+bool index_valid(long idx, long n) { return idx >= -n && idx < n; }
+
+double table_entry(const mc_rule* r, int idx) {
+  const long n = (long)r->ratios.size();
+  return r->ratios[(size_t)(idx < 0 ? idx + n : idx)];
 }
 
 bool gate_open(const mc_rule* r) {
@@ -72,8 +82,7 @@ extern "C" {
 
 mc_rule* mc_rule_create(int variant, int num_steps, double thresh, int K, double retention_ratio,
                         const double* mag_ratios, int n_ratios, int split_step) {
-  const int need = variant == MC_RULE_EVAL_WAN ? num_steps - 10 : variant == MC_RULE_EVAL_OPENSORA ? num_steps - 1 : num_steps;
-  if (variant < MC_RULE_WAN21 || variant > MC_RULE_EVAL_OPENSORA || num_steps <= 0 || !mag_ratios || n_ratios < need)
+  if (variant < MC_RULE_WAN21 || variant > MC_RULE_EVAL_OPENSORA || num_steps <= 0 || !mag_ratios || n_ratios <= 0)
     return nullptr;
   mc_rule* r = new mc_rule();
   r->variant = variant;
@@ -84,6 +93,14 @@ mc_rule* mc_rule_create(int variant, int num_steps, double thresh, int K, double
   r->split_step = split_step;
   r->ratios.assign(mag_ratios, mag_ratios + n_ratios);
   if (variant == MC_RULE_OMNIGEN2) r->acc_steps[0] = 3;   // MagCacheParams.accumulated_steps: int = 3 (:44)
+  // every call whose gate is open reads one table entry: all of them must exist (Python would raise IndexError)
+  for (r->cnt = 0; r->cnt < num_steps; ++r->cnt) {
+    if (gate_open(r) && !index_valid(ratio_index(r), n_ratios)) {
+      delete r;
+      return nullptr;
+    }
+  }
+  r->cnt = 0;
   return r;
 }
 
@@ -99,7 +116,7 @@ int mc_rule_step(mc_rule* r, int* branch) {
     r->acc_err[0] = 0.0;
   }
   if (gate_open(r)) {
-    const double cur = r->ratios[ratio_index(r)];
+    const double cur = table_entry(r, ratio_index(r));
     r->acc_ratio[p] = r->acc_ratio[p] * cur;
     r->acc_steps[p] += 1;
     // Open-Sora's eval script accumulates the SIGNED distance (no abs, opensora.py:301)

@@ -144,7 +144,13 @@ class Engine:
         t = t.to(self.device).contiguous()
         shape = (C.c_int64 * t.dim())(*t.shape)
         dt = MC_F32 if t.dtype == torch.float32 else MC_BF16
-        check(self.lib.mc_set_weight(self.h, name.encode(), _ptr(t), dt, shape, t.dim(), _stream()))
+        st = self.lib.mc_set_weight(self.h, name.encode(), _ptr(t), dt, shape, t.dim(), _stream())
+        if st != 0 and dt == MC_BF16 and b"must be given as fp32" in self.lib.mc_last_error():
+            # fp32 slots (biases, norm weights, modulation, time MLP, head): a state_dict converted with
+            # .to(bfloat16) (upstream convert_model_dtype) still loads, widened exactly
+            t = t.float()
+            st = self.lib.mc_set_weight(self.h, name.encode(), _ptr(t), MC_F32, shape, t.dim(), _stream())
+        check(st)
         torch.cuda.current_stream().synchronize()  # t may be freed by the caller right after
 
     def load_weights(self, named_tensors):

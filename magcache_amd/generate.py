@@ -198,8 +198,9 @@ def generate(args):
         name = args.ckpt_dir or ("Wan2.1-T2V-1.3B" if "1.3B" in args.task else "Wan2.1-T2V-14B")
         if "T2V-1.3B" not in name and "T2V-14B" not in name:
             name = "Wan2.1-T2V-1.3B" if "1.3B" in args.task else "Wan2.1-T2V-14B"
-        table = M.select_table(args.ckpt_dir or ("720P" if "720" in args.size else "480P"), task=args.task) \
-            if (is_i2v or is_vace) else None                                      # :1001-1004, :1141-1144
+        hint = args.ckpt_dir or (("14B" if "14B" in args.task else "1.3B") if is_vace else
+                                 ("720P" if "720" in args.size else "480P"))
+        table = M.select_table(hint, task=args.task) if (is_i2v or is_vace) else None    # :1001-1004, :1141-1144
         mca.init_magcache(model, args.sample_steps, args.magcache_thresh, args.magcache_K, args.retention_ratio,
                           ckpt_dir=name, mag_ratios=table)                        # :896-919
         if is_vace:
@@ -232,7 +233,7 @@ def generate(args):
     t0 = time.perf_counter()
     latent = mca.sample(model, noise, ctx, ctx_null, sampling_steps=args.sample_steps, shift=args.sample_shift,
                         guide_scale=args.sample_guide_scale, solver=args.sample_solver, layout=layout,
-                        model_kwargs=extra)
+                        model_kwargs=extra, sigma_grid="upstream")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     logging.info(f"denoising: {dt:.2f} s, {args.sample_steps / dt:.3f} steps/s")
@@ -295,7 +296,7 @@ def _generate_wan22(args, device, rank, world, layout):
     t0 = time.perf_counter()
     latent = wan22.sample(high, low, noise, ctx, ctx_null, d["boundary"], sampling_steps=args.sample_steps,
                           shift=args.sample_shift, guide_scale=args.sample_guide_scale, y=y, solver=args.sample_solver,
-                          layout=layout)
+                          layout=layout, sigma_grid="upstream")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     logging.info(f"denoising: {dt:.2f} s, {args.sample_steps / dt:.3f} steps/s ({split} high-noise steps)")

@@ -121,15 +121,18 @@ class MMDiTEngine:
         return self.buffer("residual", torch.float32).view(-1, self.dim)[:self.tokens_per_rank]
 
     def set_rope(self, cos, sin):
-        """upstream use_real tables [n, 128]; uploaded only when their CONTENT changes (constant over a sample)"""
+        """upstream use_real tables [n, 128]; uploaded only when the tensors change (constant over a sample).  The
+        check is by tensor identity + version counter (model._tensor_key), not by content: no device sync per call."""
+        from .model import _same_tensor, _tensor_key
+        k = self._rope_key
+        if k is not None and _same_tensor(k[0], cos) and _same_tensor(k[1], sin):
+            return
+        key = (_tensor_key(cos), _tensor_key(sin))
         cos, sin = _f32(cos, self.device), _f32(sin, self.device)
         assert cos.shape == sin.shape and cos.shape[1] == 128, f"RoPE tables {tuple(cos.shape)}"
-        k = self._rope_key
-        if k is not None and k[0].shape == cos.shape and torch.equal(k[0], cos) and torch.equal(k[1], sin):
-            return
         check(self.lib.mc_mmdit_set_rope(self.h, _ptr(cos), _ptr(sin), cos.shape[0], _stream()))
         torch.cuda.current_stream().synchronize()
-        self._rope_key = (cos.clone(), sin.clone())
+        self._rope_key = key
 
     def forward(self, img, timestep, guidance, txt, txt_valid, vec, mode=MC_MODE_FULL, out=None):
         img, txt, vec = _f32(img, self.device), _f32(txt, self.device), _f32(vec, self.device)
@@ -292,10 +295,13 @@ class FluxTransformer2DModelHIP:
             txt_ids = txt_ids[0]
         if img_ids.ndim == 3:
             img_ids = img_ids[0]
-        ids = torch.cat((txt_ids, img_ids), dim=0).to(self.device, torch.float32)
-        if self._ids_key is None or self._ids_key.shape != ids.shape or not torch.equal(self._ids_key, ids):
-            self.engine.set_rope(*flux_rope(ids, tuple(self.cfg["axes_dims_rope"])))
-            self._ids_key = ids
+        from .model import _same_tensor, _tensor_key
+        k = self._ids_key
+        if k is None or not (_same_tensor(k[0], txt_ids) and _same_tensor(k[1], img_ids)):   # identity, no device sync
+            ids = torch.cat((txt_ids, img_ids), dim=0).to(self.device, torch.float32)
+            self._rope_tables = flux_rope(ids, tuple(self.cfg["axes_dims_rope"]))
+            self.engine.set_rope(*self._rope_tables)
+            self._ids_key = (_tensor_key(txt_ids), _tensor_key(img_ids))
         out = _engine_forward(self, hidden_states[0], t, g, encoder_hidden_states[0], self.txt_len, pooled_projections[0], mode)
         return out.unsqueeze(0).to(hidden_states.dtype)
 

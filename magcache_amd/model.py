@@ -55,6 +55,20 @@ def select_table(ckpt_dir, task="t2v"):
     raise ValueError(f"no mag_ratios table for ckpt_dir={ckpt_dir!r}; run --magcache_calibration first")
 
 
+def _tensor_key(t):
+    """Identity of a conditioning tensor WITHOUT reading it (a content compare is a device-to-host sync on every
+    forward): the tensor object is kept alive, so its storage cannot be recycled for different data, and an in-place
+    write bumps `_version`.  A caller that rebuilds the tensor every step only pays the re-upload."""
+    return (t, t._version)
+
+
+def _same_tensor(key, t):
+    k, ver = key
+    return k is t and ver == t._version or (k.data_ptr() == t.data_ptr() and k.shape == t.shape and
+                                            k.dtype == t.dtype and k.device == t.device and
+                                            ver == k._version == t._version)
+
+
 class WanModelHIP:
     """Wan2.1 DiT (T2V, or I2V when cfg has model_type='i2v' / clip_dim) whose forward runs on the HIP engine.
     One latent grid per instance."""
@@ -101,21 +115,20 @@ class WanModelHIP:
         if y is not None:
             lat = torch.cat([lat, y[0].to(self.device)], dim=0)
         if vace is not None:
-            # vace_patch_embedding(vace_context) is constant over a video: upload when the content / scale changes
+            # vace_patch_embedding(vace_context) is constant over a video: upload when the tensor / scale changes
             vc, scale = vace[0][0], float(vace[1])
             k = self._vace_key
-            if k is None or k[0].shape != vc.shape or not torch.equal(k[0], vc.to(k[0].device)):
+            if k is None or not _same_tensor(k[0], vc):
                 self.engine.set_vace_context(vc, scale)
-                self._vace_key = (vc.detach().to(self.device).clone(), scale)
+                self._vace_key = (_tensor_key(vc), scale)
             elif k[1] != scale:
                 self.engine.set_vace_context(None, scale)
                 self._vace_key = (k[0], scale)
         if clip_fea is not None:
             # img_emb(clip_fea) is constant over a video: run it when the tensor changes, not every call
-            k = self._clip_key
-            if k is None or k.shape != clip_fea.shape or k.dtype != clip_fea.dtype or not torch.equal(k, clip_fea.to(k.device)):
+            if self._clip_key is None or not _same_tensor(self._clip_key, clip_fea):
                 self.engine.set_clip_fea(clip_fea)
-                self._clip_key = clip_fea.detach().to(self.device).clone()
+                self._clip_key = _tensor_key(clip_fea)
         t = t if not torch.is_tensor(t) else t.to(self.device)
         ctx = context[0].to(self.device)
         if self.engine.sp_size > 1:
@@ -156,13 +169,12 @@ def _advance(self):
         self.accumulated_steps = [0, 0]
 
 
-def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
-    """Drop-in for the reference's magcache_forward (:198-312)."""
-    self._check_inputs(x, context, seq_len, clip_fea, y)
+def _decide(self):
+    """The MagCache decision (:277-292; the VACE twin :521-536 is the same code): host scalars only.  Returns
+    (state slot p, skip_forward)."""
     p = self.cnt % 2  # cond calls are even, uncond odd
     skip_forward = False
     if self.cnt >= int(self.num_steps * self.retention_ratio):
-        # magnitude-ratio bookkeeping, host scalars only (:279-292)
         self.accumulated_ratio[p] = self.accumulated_ratio[p] * self.mag_ratios[self.cnt]
         self.accumulated_steps[p] += 1
         self.accumulated_err[p] += np.abs(1 - self.accumulated_ratio[p])
@@ -174,19 +186,22 @@ def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
             self.accumulated_ratio[p] = 1.0
     if skip_forward and self.residual_cache[p] is None:
         raise RuntimeError("MagCache asked to skip before any residual was cached (retention_ratio too small?)")
-    out = self._run(x, t, context, p, MC_MODE_SKIP if skip_forward else MC_MODE_FULL, **_i2v_inputs(clip_fea, y))
-    self.residual_cache[p] = self.engine.residual(p)  # a view of the engine's HBM slot
+    return p, skip_forward
+
+
+def _cached_forward(self, x, t, context, **run_kw):
+    p, skip_forward = _decide(self)
+    out = self._run(x, t, context, p, MC_MODE_SKIP if skip_forward else MC_MODE_FULL, **run_kw)
+    self.residual_cache[p] = self.engine.residual(p)  # a view of the engine's HBM slot (:301)
     _advance(self)
     return out
 
 
-def magcache_calibration(self, x, t, context, seq_len, clip_fea=None, y=None):
-    """Drop-in for the reference's magcache_calibration (:80-194): never skips, records
-    norm_ratio / norm_std / cos_dis against the previous residual of the same branch and dumps the
-    three JSON files when the video is finished."""
-    self._check_inputs(x, context, seq_len, clip_fea, y)
+def _calibration_forward(self, x, t, context, **run_kw):
+    """:165-193 (VACE twin :405-437): never skips, records norm_ratio / norm_std / cos_dis against the previous
+    residual of the same branch and dumps the three JSON files when the video is finished."""
     p = self.cnt % 2
-    out = self._run(x, t, context, p, MC_MODE_CALIB, **_i2v_inputs(clip_fea, y))
+    out = self._run(x, t, context, p, MC_MODE_CALIB, **run_kw)
     if self.cnt >= 2:
         norm_ratio, norm_std, cos_dis = self.engine.calib_stats(p)
         self.norm_ratio.append(round(norm_ratio, 5))
@@ -211,6 +226,18 @@ def magcache_calibration(self, x, t, context, seq_len, clip_fea=None, y=None):
             with open(fn + ".json", "w") as f:
                 json.dump(v, f)
     return out
+
+
+def magcache_forward(self, x, t, context, seq_len, clip_fea=None, y=None):
+    """Drop-in for the reference's magcache_forward (:198-312)."""
+    self._check_inputs(x, context, seq_len, clip_fea, y)
+    return _cached_forward(self, x, t, context, **_i2v_inputs(clip_fea, y))
+
+
+def magcache_calibration(self, x, t, context, seq_len, clip_fea=None, y=None):
+    """Drop-in for the reference's magcache_calibration (:80-194)."""
+    self._check_inputs(x, context, seq_len, clip_fea, y)
+    return _calibration_forward(self, x, t, context, **_i2v_inputs(clip_fea, y))
 
 
 def _vace_checks(self, x, vace_context, context, seq_len):
@@ -224,56 +251,13 @@ def magcache_vace_forward(self, x, t, vace_context, context, seq_len, vace_conte
     """Drop-in for the reference's magcache_vace_forward (:439-560): the MagCache rule of magcache_forward around the
     VACE model (control blocks + hints run inside the engine)."""
     _vace_checks(self, x, vace_context, context, seq_len)
-    p = self.cnt % 2
-    skip_forward = False
-    if self.cnt >= int(self.num_steps * self.retention_ratio):                              # :521-536
-        self.accumulated_ratio[p] = self.accumulated_ratio[p] * self.mag_ratios[self.cnt]
-        self.accumulated_steps[p] += 1
-        self.accumulated_err[p] += np.abs(1 - self.accumulated_ratio[p])
-        if self.accumulated_err[p] < self.magcache_thresh and self.accumulated_steps[p] <= self.K:
-            skip_forward = True
-        else:
-            self.accumulated_err[p] = 0
-            self.accumulated_steps[p] = 0
-            self.accumulated_ratio[p] = 1.0
-    if skip_forward and self.residual_cache[p] is None:
-        raise RuntimeError("MagCache asked to skip before any residual was cached (retention_ratio too small?)")
-    out = self._run(x, t, context, p, MC_MODE_SKIP if skip_forward else MC_MODE_FULL,
-                    vace=(vace_context, vace_context_scale))
-    self.residual_cache[p] = self.engine.residual(p)
-    _advance(self)
-    return out
+    return _cached_forward(self, x, t, context, vace=(vace_context, vace_context_scale))
 
 
 def magcache_vace_calibration(self, x, t, vace_context, context, seq_len, vace_context_scale=1.0, clip_fea=None, y=None):
     """Drop-in for the reference's magcache_vace_calibration (:314-437)."""
     _vace_checks(self, x, vace_context, context, seq_len)
-    p = self.cnt % 2
-    out = self._run(x, t, context, p, MC_MODE_CALIB, vace=(vace_context, vace_context_scale))
-    if self.cnt >= 2:
-        norm_ratio, norm_std, cos_dis = self.engine.calib_stats(p)
-        self.norm_ratio.append(round(norm_ratio, 5))
-        self.norm_std.append(round(norm_std, 5))
-        self.cos_dis.append(round(cos_dis, 5))
-        print(f"time: {self.cnt}, norm_ratio: {norm_ratio}, norm_std: {norm_std}, cos_dis: {cos_dis}")
-    self.residual_cache[p] = self.engine.residual(p)
-    self.cnt += 1
-    if self.cnt >= self.num_steps:
-        self.cnt = 0
-        self.accumulated_ratio = [1.0, 1.0]
-        self.accumulated_err = [0.0, 0.0]
-        self.accumulated_steps = [0, 0]
-        print("norm ratio")
-        print(self.norm_ratio)
-        print("norm std")
-        print(self.norm_std)
-        print("cos_dis")
-        print(self.cos_dis)
-        for fn, v in (("wan2_1_mag_ratio", self.norm_ratio), ("wan2_1_mag_std", self.norm_std),
-                      ("wan2_1_cos_dis", self.cos_dis)):
-            with open(fn + ".json", "w") as f:
-                json.dump(v, f)
-    return out
+    return _calibration_forward(self, x, t, context, vace=(vace_context, vace_context_scale))
 
 
 def vace_plain_forward(self, x, t, vace_context, context, seq_len, vace_context_scale=1.0, clip_fea=None, y=None):

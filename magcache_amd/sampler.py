@@ -23,9 +23,18 @@ from . import _lib
 from ._lib import check
 
 
-def flow_timesteps(num_steps, shift=5.0, num_train_timesteps=1000):
-    """sigmas [n+1] (last = 0) and integer timesteps [n]."""
-    sig = np.linspace(1.0, 0.01, num_steps + 1)[:-1]
+def flow_timesteps(num_steps, shift=5.0, num_train_timesteps=1000, sigma_grid="reference"):
+    """sigmas [n+1] (last = 0) and integer timesteps [n].
+    sigma_grid "reference": linspace(1.0, 0.01, n+1)[:-1], the reference's own restatement of the scheduler
+      (MagCache4Wan2.2/magcache_generate.py:43-95 `get_timesteps` defaults; SURVEY 8d's benchmark schedule);
+    sigma_grid "upstream": linspace(1 - 1/N, 0, n+1)[:-1], what upstream's FlowUniPC / FlowDPMSolver schedulers
+      (wan/utils/fm_solvers*.py, not in the reference tree) run: sigma_max / sigma_min are the ends of their training
+      grid 1 - linspace(1, 1/N, N)[::-1].  The generate CLI samples on this grid."""
+    if sigma_grid == "upstream":
+        sig = np.linspace(1.0 - 1.0 / num_train_timesteps, 0.0, num_steps + 1)[:-1]
+    else:
+        assert sigma_grid == "reference", sigma_grid
+        sig = np.linspace(1.0, 0.01, num_steps + 1)[:-1]
     sig = shift * sig / (1 + (shift - 1) * sig)
     sig = np.concatenate([sig, [0.0]]).astype(np.float32)
     return sig, (sig[:-1] * num_train_timesteps).astype(np.int64)
@@ -148,7 +157,7 @@ class FlowSolver:
 
 
 def sample(model, noise, context, context_null, sampling_steps=50, shift=5.0, guide_scale=5.0, seq_len=None,
-           callback=None, solver="euler", layout=None, lincomb=None, model_kwargs=None):
+           callback=None, solver="euler", layout=None, lincomb=None, model_kwargs=None, sigma_grid="reference"):
     """Run the denoising loop; returns the final latent (fp32 [C,F,H,W]).  `model` is called like the
     upstream model: model([latent], t=timestep, context=[ctx], seq_len=seq_len)[0].  `layout`
     (parallel.ParallelLayout) with cfg_size == 2: this rank runs one CFG branch per step and swaps the
@@ -156,7 +165,7 @@ def sample(model, noise, context, context_null, sampling_steps=50, shift=5.0, gu
     `model_kwargs`: extra conditioning passed to every call (i2v: clip_fea, y; vace: vace_context, vace_context_scale),
     like upstream's arg_c / arg_null dictionaries."""
     mk = model_kwargs or {}
-    sig, ts = flow_timesteps(sampling_steps, shift)
+    sig, ts = flow_timesteps(sampling_steps, shift, sigma_grid=sigma_grid)
     device = noise.device
     t_dev = torch.tensor(ts, dtype=torch.float32, device=device)
     latent = noise.clone().float().contiguous()

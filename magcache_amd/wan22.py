@@ -219,7 +219,7 @@ def call_branch(model, step, branch, x, t, context, seq_len, **kw):
 
 
 def sample(high, low, noise, context, context_null, boundary, sampling_steps=40, shift=12.0, guide_scale=(3.0, 4.0),
-           y=None, seq_len=None, solver="euler", layout=None, lincomb=None):
+           y=None, seq_len=None, solver="euler", layout=None, lincomb=None, sigma_grid="reference"):
     """The two-expert denoising loop (upstream wan/text2video.py generate(): expert by timestep, guidance
     scale per expert (low, high), cond call first, uncond second).  `layout` (parallel.ParallelLayout): with
     cfg_size == 2 this rank evaluates one CFG branch per step and swaps predictions with its pair rank; the experts'
@@ -227,7 +227,9 @@ def sample(high, low, noise, context, context_null, boundary, sampling_steps=40,
     sp_group=))."""
     from .sampler import FlowSolver, lincomb_hip
     lincomb_hip = lincomb or lincomb_hip
-    ts, sig = get_timesteps(shift, sampling_steps)
+    # the sampling schedule; get_timesteps() above stays what the reference uses it for, the split-step COUNT (:697-698)
+    from .sampler import flow_timesteps
+    sig, ts = flow_timesteps(sampling_steps, shift, sigma_grid=sigma_grid)
     device = noise.device
     t_dev = torch.tensor(ts, dtype=torch.float32, device=device)
     latent = noise.clone().float().contiguous()

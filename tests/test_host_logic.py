@@ -73,6 +73,44 @@ def test_c_rule_rejects_bad_arguments():
     arr = (C.c_double * 4)(1, 1, 1, 1)
     assert not lib.mc_rule_create(0, 10, 0.1, 2, 0.2, arr, 4, 0)   # table shorter than num_steps
     assert not lib.mc_rule_create(99, 4, 0.1, 2, 0.2, arr, 4, 0)   # unknown variant
+    assert not lib.mc_rule_create(0, 4, 0.1, 2, 0.2, arr, 0, 0)    # empty table
+
+
+def test_c_rule_short_eval_schedules_wrap_like_python():
+    """eval Wan reads ratio[t - 10] from t >= int(n * 0.2) on; with few steps the index is negative.  The reference
+    indexes a Python list, which wraps once (ratios[-3]) and raises IndexError beyond -len: the C rule wraps the same
+    way and refuses to build a rule that would raise (this used to be an out-of-bounds vector read)."""
+    lib = _lib.load()
+    EVAL_WAN, EVAL_OPENSORA = 9, 10
+    n = 20                                           # gate opens at cnt 4 -> first index -6
+    table = [1.0 - 0.01 * i for i in range(10)]      # len 10 >= 6: every wrapped index exists
+    arr = (C.c_double * len(table))(*table)
+    r = lib.mc_rule_create(EVAL_WAN, n, 0.5, 3, 0.2, arr, len(table), 0)
+    assert r
+    acc = [1.0, 1.0]
+    err = [0.0, 0.0]
+    steps = [0, 0]
+    for cnt in range(n):
+        want = False
+        p = cnt % 2
+        if cnt >= int(n * 0.2):
+            acc[p] *= table[cnt - 10]               # Python negative-index semantics
+            steps[p] += 1
+            err[p] += abs(1 - acc[p])
+            if err[p] <= 0.5 and steps[p] <= 3:
+                want = True
+            else:
+                acc[p], steps[p], err[p] = 1.0, 0, 0.0
+        b = C.c_int()
+        assert bool(lib.mc_rule_step(r, C.byref(b))) == want, cnt
+    lib.mc_rule_destroy(r)
+    short = (C.c_double * 3)(1, 1, 1)
+    assert not lib.mc_rule_create(EVAL_WAN, n, 0.5, 3, 0.2, short, 3, 0)       # ratios[-6] of a 3-list raises
+    assert not lib.mc_rule_create(EVAL_OPENSORA, 30, 0.1, 2, 0.2, short, 3, 0)  # ratio[28] does not exist
+    # Open-Sora with R*n < 1: the gate is open at t = 0 and reads ratio[-1] = the last entry
+    r = lib.mc_rule_create(EVAL_OPENSORA, 3, 10.0, 5, 0.2, short, 3, 0)
+    assert r
+    lib.mc_rule_destroy(r)
 
 
 def test_c_nearest_interp(golden_dir):

@@ -24,8 +24,8 @@
 //    that XCD's L2 once.
 //  * KV may be given as n_shards shards of shard_rows rows with only the first shard_valid rows
 //    valid (sequence-parallel all-gather layout; also covers the zero-padded tail when 1 shard).
-#include "common.h"
-#include "ops.h"
+#include "../../magcache_amd/csrc/common.h"
+#include "../../magcache_amd/csrc/ops.h"
 
 namespace mc {
 
@@ -219,23 +219,6 @@ hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(nqb * p.n_heads), dim3(512), 2 * STAGE, stream, p, nqb,
                      tiles_per_shard);
   return hipGetLastError();
-}
-
-// mc_set_option("attn_kernel", v): 0 default, 1 = this kernel, 2 = attention_v2.hip, 3 = attention_v3.hip
-int g_attn_kernel = 0;
-
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
-  const bool two_phase = p.skip_shard_p1 != 0 || p.lse_out || p.lse_in;  // only attention_v3.hip implements it
-  if (two_phase) {
-    if (p.skip_shard_p1 < 0 || p.skip_shard_p1 > p.n_shards || (p.skip_shard_p1 && p.n_shards < 2))
-      return hipErrorInvalidValue;
-    return launch_attention_v3(p, stream);
-  }
-  switch (g_attn_kernel) {
-    case 1: return launch_attention_v1(p, stream);
-    case 2: return launch_attention_v2(p, stream);
-    default: return launch_attention_v3(p, stream);
-  }
 }
 
 }  // namespace mc

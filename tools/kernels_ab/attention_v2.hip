@@ -26,8 +26,8 @@
 //    and V one tile ahead of their use... (K(t+3), V(t+2) are issued in iteration t), issued from
 //    inline asm so that hipcc's waitcnt pass does not serialise ds_reads behind them; ordered by
 //    one counted s_waitcnt vmcnt(8) + s_barrier per tile.
-#include "common.h"
-#include "ops.h"
+#include "../../magcache_amd/csrc/common.h"
+#include "../../magcache_amd/csrc/ops.h"
 
 // Timing ablations (tools/build_variants.py; results are wrong by construction): bit 0 no softmax
 // VALU, 1 no V^T reads, 2 no K reads, 3 no DMA, 4 no barrier/vmcnt, 5 no row max, 6 no QK MFMAs,

@@ -25,9 +25,9 @@
 // Selected only by mc_set_option("gemm_kernel", 3) (A/B harnesses, tests); the shape dispatcher does not pick it.
 // Reference call site of the Linears it serves: MagCache4Wan2.1/magcache_generate.py:297-298 (the DiT blocks).
 #pragma clang diagnostic ignored "-Winline-asm"
-#include "common.h"
-#include "gemm_epilogue.h"
-#include "ops.h"
+#include "../../magcache_amd/csrc/common.h"
+#include "../../magcache_amd/csrc/gemm_epilogue.h"
+#include "../../magcache_amd/csrc/ops.h"
 
 namespace mc {
 
