@@ -114,28 +114,92 @@ def kernel_rooflines(cfg, device):
     return res
 
 
-def cpu_baseline(cfg, threads):
-    """The oracle (PyTorch CPU restatement, bf16 autocast = the reference's execution mode) timed on
-    this box's host cores on a bounded sample, extrapolated with the FLOP model."""
+def cpu_baseline(cfg, max_threads):
+    """The oracle (PyTorch CPU restatement, bf16 autocast = the reference's execution mode) timed on this box's host
+    cores, following SURVEY 8(d): after a warm-up, (a) ONE block at the full L = 32 760 -- everything but the attention
+    core measured at full length, the attention core on a 2 048-query slice against all 32 760 keys and scaled by
+    L / 2 048 (it is linear in the query count) -- and (b) the whole 30-layer forward at L = 3 120 (5 latent frames).
+    The thread count is the best of {8, 32, 64, all} on a bf16 F.linear probe of the FFN-1 shape.  The full-size
+    forward is extrapolated from (a): 30 x (t_rest + t_attention); (b) is reported next to it as a cross-check of the
+    per-layer model at small L."""
+    import torch.nn.functional as F
     from oracle import wan_dit_ref as W
+    d, ffn, heads = cfg["dim"], cfg["ffn_dim"], cfg["num_heads"]
+    t_begin = time.perf_counter()
+
+    # ---- thread sweep on a GEMM probe (bf16 F.linear, M = 3120, the FFN-1 shape): 2*M*N*K = 86 GFLOP
+    xa = torch.randn(3120, d).bfloat16()
+    wa = torch.randn(ffn, d).bfloat16()
+    probe = {}
+    for th in sorted({min(t, max_threads) for t in (8, 32, 64, max_threads)}):
+        torch.set_num_threads(th)
+        F.linear(xa, wa)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            F.linear(xa, wa)
+        probe[th] = 3 * 2.0 * 3120 * ffn * d / (time.perf_counter() - t0) / 1e12
+    threads = max(probe, key=probe.get)
     torch.set_num_threads(threads)
-    n_layers, grid = 2, (2, 60, 104)
-    L = grid[0] * 30 * 52
-    c = dict(cfg, num_layers=n_layers)
-    oracle = W.init_synthetic_(W.WanModel(**c), seed=0)
+
     g = torch.Generator().manual_seed(42)
-    lat = torch.randn(16, *grid, generator=g)
     ctx = torch.randn(512, cfg["text_dim"], generator=g)
+    tt = torch.tensor([500.0])
+
+    # ---- (b) 30 layers at L = 3120, warm-up = the same model on a 1-frame latent
+    grid_s = (2, 60, 104)
+    Ls = grid_s[0] * 30 * 52
+    # one block is initialised and COPIED into the other 29 (distinct memory, same values: CPU time does not depend on
+    # the values, and drawing 1.4 G parameters on the host would cost more than the measurement)
+    import copy
+    oracle = W.init_synthetic_(W.WanModel(**dict(cfg, num_layers=1)), seed=0)
+    oracle.blocks = torch.nn.ModuleList([oracle.blocks[0]] + [copy.deepcopy(oracle.blocks[0])
+                                                              for _ in range(cfg["num_layers"] - 1)])
+    oracle.forward([torch.randn(16, 1, 16, 16, generator=g)], tt, [ctx], 64, autocast=True)     # warm-up
     t0 = time.perf_counter()
-    oracle.forward([lat], torch.tensor([500.0]), [ctx], L, autocast=True)
-    dt = time.perf_counter() - t0
-    f_sample, f_full = flops_forward(c, L), flops_forward(cfg, SEQ)
-    t_full = dt * f_full / f_sample
+    oracle.forward([torch.randn(16, *grid_s, generator=g)], tt, [ctx], Ls, autocast=True)
+    t_b = time.perf_counter() - t0
+    f_b = flops_forward(cfg, Ls)
+
+    # ---- (a) one block at full L
+    blk = oracle.blocks[0]
+    lat = torch.randn(16, *GRID, generator=g)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        x, e, kw = oracle.embed([lat], tt, [ctx], SEQ)
+        real_attention = W.attention_ref
+        try:
+            # everything but the self-attention core (cross-attention keeps its 512-key attention)
+            W.attention_ref = lambda q, k, v, k_lens=None: v if k.size(1) == q.size(1) else real_attention(q, k, v, k_lens)
+            t0 = time.perf_counter()
+            blk(x, **kw)
+            t_rest = time.perf_counter() - t0
+        finally:
+            W.attention_ref = real_attention
+        nq = 2048
+        q = torch.randn(1, nq, heads, 128, generator=g).bfloat16()
+        k = torch.randn(1, SEQ, heads, 128, generator=g).bfloat16()
+        v = torch.randn(1, SEQ, heads, 128, generator=g).bfloat16()
+        W.attention_ref(q[:, :256], k, v)                                                       # warm-up
+        t0 = time.perf_counter()
+        W.attention_ref(q, k, v)
+        t_attn_s = time.perf_counter() - t0
+    t_attn = t_attn_s * SEQ / nq
+    f_attn = 4.0 * SEQ * SEQ * d
+    f_layer = flops_forward(dict(cfg, num_layers=1), SEQ) - 2 * SEQ * 64 * d * 2
+    f_rest = f_layer - f_attn
+    t_full = cfg["num_layers"] * (t_rest + t_attn)
+    f_full = flops_forward(cfg, SEQ)
     return dict(value=1.0 / (2 * t_full), unit="denoising steps/s (no cache)", cores=threads, kind="port",
-                sample=f"one oracle forward, {n_layers} of {cfg['num_layers']} blocks, L={L} of {SEQ} tokens: "
-                       f"{dt:.1f} s = {f_sample / dt / 1e12:.2f} TFLOP/s; extrapolated by the FLOP model "
-                       f"({f_full / 1e12:.0f} TFLOP/forward) to {t_full:.0f} s/forward",
-                seconds_measured=dt)
+                sample=(f"(a) one oracle block at L={SEQ}: all but the self-attention core {t_rest:.1f} s "
+                        f"({f_rest / t_rest / 1e12:.2f} TFLOP/s), attention core on {nq} of {SEQ} query rows "
+                        f"{t_attn_s:.1f} s -> {t_attn:.1f} s per layer ({f_attn / t_attn / 1e12:.2f} TFLOP/s); "
+                        f"(b) the {cfg['num_layers']}-layer forward at L={Ls}: {t_b:.1f} s ({f_b / t_b / 1e12:.2f} TFLOP/s); "
+                        f"full-size forward = {cfg['num_layers']} x (a) = {t_full:.0f} s ({f_full / t_full / 1e12:.2f} TFLOP/s); "
+                        f"bf16 F.linear probe {probe[threads]:.2f} TFLOP/s on {threads} threads"),
+                threads_probe_tflops={str(k): round(v, 3) for k, v in probe.items()},
+                seconds_measured=time.perf_counter() - t_begin,
+                block_full_L=dict(rest_s=t_rest, attention_s=t_attn, attention_sampled_s=t_attn_s, query_rows=nq),
+                forward_small_L=dict(tokens=Ls, seconds=t_b, tflops=f_b / t_b / 1e12),
+                seconds_per_forward_extrapolated=t_full)
 
 
 def main():
