@@ -219,7 +219,9 @@ mc_status mc_op_skip_add(const void* x0_bf16_dev, long ldx0, const float* r_dev,
                          int M, int D, mc_stream stream);
 mc_status mc_op_residual_sub(const float* x_dev, long ldx, const void* x0_bf16_dev, long ldx0, float* r_dev,
                              long ldr, int M, int D, mc_stream stream);
-/* partial_dev: 4*n_blocks doubles scratch; sums_dev: 4 doubles; stats_dev: 3 floats */
+/* One launch: per-token ratios + the cross-block reduction by the last block to arrive.  partial_dev: 4*n_blocks + 1
+ * doubles of scratch whose LAST 8 bytes (the arrival ticket) must be zero before the first call -- the kernel rearms it;
+ * sums_dev: 4 doubles (sum rho, sum rho^2, sum 1-cos, count); stats_dev: 3 floats or NULL */
 mc_status mc_op_calib_stats(const float* r_dev, long ldr, const float* rp_dev, long ldrp, int M, int D,
                             double* partial_dev, int n_blocks, double* sums_dev, float* stats_dev,
                             mc_stream stream);

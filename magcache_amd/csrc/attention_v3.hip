@@ -63,6 +63,11 @@ __device__ __forceinline__ float rowmax32(const f32x16& a, const f32x16& b) {
 #define MC_ABL 0  // timing ablations (tools/build_variants.py; results are wrong by construction): 1 no exp2,
 #endif            // 2 no row-sum adds, 4 no row maximum, 8 no V^T fragment reads, 16 no K fragment reads
 #define MC_PIN() __builtin_amdgcn_sched_barrier(0)
+// Diagnostic / tuning build variants (tools/build_variants.py --define MC_VAR=<bits>; results stay correct):
+//   1: static s_setprio 1 for the second-dispatched half of the workgroup (waves 4-7), CDNA4 guide T5 static form
+#ifndef MC_VAR
+#define MC_VAR 0
+#endif
 
 __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int nqb, int tiles_per_shard) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v3_kernel(AttnParams p, int n
     mx = rowmax32(s[0], s[1]);
   }
 
+  if ((MC_VAR & 1) && wv >= 4) __builtin_amdgcn_s_setprio(1);   // wv is a readfirstlane value: a scalar branch
   int slot_k = 1, slot_v = 0;  // ring slots of K(t+1) and V(t)
   // Fragments that cross a phase boundary (no LDS latency at the start of a phase): the K fragments of
   // d-steps 0 and 1 of the NEXT iteration's phase 1 are read at the end of phase 2 (its K tile was

@@ -423,7 +423,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_buf(e, cur, "ao2", Lp * d * 2);
   }
   if (e->P > 1) add_buf(e, cur, "attn_lse", (size_t)e->H * Lp * 4);
-  add_buf(e, cur, "calib_partial", 2048 * 4 * 8);
+  add_buf(e, cur, "calib_partial", (2048 * 4 + 2) * 8);   // + the arrival ticket of calib_stats_kernel
   add_buf(e, cur, "calib_sums", 4 * 8);
   add_buf(e, cur, "calib_stats", 2 * 3 * 4);
   e->ws_need = cur;
@@ -454,6 +454,8 @@ mc_status mc_set_workspace(mc_engine* e, void* ws_dev, size_t bytes) {
   e->ws = (char*)ws_dev;
   e->ws_bytes = bytes;
   e->have_res[0] = e->have_res[1] = false;
+  // the arrival ticket of the one-launch calibration reduction starts at zero (the kernel rearms it itself)
+  HIP_TRY(hipMemset(e->buf<double>("calib_partial") + 2048 * 4, 0, 16));
   return MC_OK;
 }
 

@@ -49,7 +49,10 @@ constexpr int BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // Am0 | Am1 | Wn0 | Wn1
 constexpr int OFF_AM0 = 0, OFF_AM1 = HALF_BYTES, OFF_WN0 = 2 * HALF_BYTES, OFF_WN1 = 3 * HALF_BYTES;
-constexpr int GROUP_M = 8;
+#ifndef MC_GROUP_M
+#define MC_GROUP_M 8
+#endif
+constexpr int GROUP_M = MC_GROUP_M;
 // E8M0 block scale 127 = 2^0 in all four bytes: the MX-scaled MFMA with unit scales
 #define MC_F8_UNIT_SCALE 0x7f7f7f7f
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -58,7 +61,13 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // end-of-interval wait: at most n LDS-DMA instructions of this wave still in flight.  (ds_reads need
 // no wait here: a region is re-filled two barriers after its last read, and every read has been
 // consumed by an MFMA -- i.e. waited for -- one barrier earlier.)
-#define MC_WAIT(n, r) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define MC_WAIT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define MC_WAIT(n, r)                                    \
+  do {                                                   \
+    if (MC_VAR & 16) MC_WAIT_(0);                        \
+    else if ((MC_VAR & 2) && (n) == 10) MC_WAIT_(8);     \
+    else MC_WAIT_(n);                                    \
+  } while (0)
 // interval boundary: nothing (MFMAs included -- they are register-only and would otherwise drift
 // across the asm statements) is scheduled across it
 #define MC_BARRIER()                                          \
@@ -74,6 +83,15 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // 8: no workgroup barriers.  The prologue always runs, so every register holds finite data.
 #ifndef MC_ABL
 #define MC_ABL 0
+#endif
+// Diagnostic build variants (tools/build_variants.py --define MC_VAR=<bits>; results stay CORRECT, only the
+// synchronisation changes -- used by tools/race_repro.cpp to bisect the two-stream nondeterminism of DESIGN 3.2):
+//   1: WITHOUT the barrier between the prologue's fragment reads and the first refill (the round-1 kernel)
+//   2: every steady-state wait retires one more half (vmcnt(8) instead of (10)): masks an under-counted wait
+//   4: the LDS-DMA loads carry sc0 sc1 (served by L2, the CU's vector L1 is bypassed): masks a stale L1 line
+//  16: vmcnt(0) at the end of every interval: no LDS-DMA is ever in flight across a barrier
+#ifndef MC_VAR
+#define MC_VAR 0
 #endif
 
 struct Frag4 {  // one 32-row block x 64 k = 4 MFMA operands
@@ -169,13 +187,23 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   // (wave-uniform); s_nop covers the SALU-write-M0 -> LDS-DMA hazard.
   auto dma1 = [&](const bf16_t* base, uint32_t off, uint32_t lds) {
     // M0 is clobbered, not saved: nothing the compiler emits in this kernel reads it
-    asm volatile(
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %2"
-        :
-        : "v"(off), "s"(lds), "s"(base)
-        : "memory", "m0");
+    if (MC_VAR & 4) {
+      asm volatile(
+          "s_mov_b32 m0, %1\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %0, %2 sc0 sc1"
+          :
+          : "v"(off), "s"(lds), "s"(base)
+          : "memory", "m0");
+    } else {
+      asm volatile(
+          "s_mov_b32 m0, %1\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %0, %2"
+          :
+          : "v"(off), "s"(lds), "s"(base)
+          : "memory", "m0");
+    }
   };
   // piece j (0/1) of half h of K tile kt into stage st (= kt & 1)
   auto dma_a1 = [&](int kt, int st, int h, int j) {
@@ -231,6 +259,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   Frag4 A0[2], A1[2], W0, W1, W2;
   read_w(0, 0, W0);
   read_a(0, 0, A0);
+  // Wn0 of stage 0 is re-filled (K tile 2) by the FIRST interval below: every wave must have issued its reads of
+  // Wn0(0) before any wave issues that DMA.  (Steady state has two barriers between the last read of a half and its
+  // refill; this is the one place where the prologue had none -- a WAR window of a few hundred cycles that only a
+  // wave delayed by that much behind its workgroup could hit.)
+  if (!(MC_VAR & 1)) MC_BARRIER();
 
   // TAIL 0: steady state (tile kt+2 exists); 1: kt == nk-2; 2: kt == nk-1.  ST = kt & 1, a literal.
   // Wait counts: at the end of an interval the half that is read in the NEXT interval must have

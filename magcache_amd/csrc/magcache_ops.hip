@@ -60,12 +60,32 @@ __global__ __launch_bounds__(256) void skip_add_kernel(const bf16_t* __restrict_
   }
 }
 
-// One wave per token: |r|^2, |rp|^2, r.rp in one pass over both slabs (each byte read once),
-// then rho = |r|/|rp| and 1-cos accumulated per wave in double; block partials to HBM.
-__global__ __launch_bounds__(256) void calib_partial_kernel(const float* __restrict__ r, long ldr,
-                                                            const float* __restrict__ rp, long ldrp, int M, int D,
-                                                            double* __restrict__ partial) {
+// stats[0] = mean(rho), stats[1] = std(rho) (unbiased, torch default), stats[2] = mean(1-cos)
+__device__ __forceinline__ void calib_finalize(const double* sums, float* stats) {
+  const double n = sums[3];
+  const double mean = sums[0] / n;
+  double var = (sums[1] - sums[0] * sums[0] / n) / (n - 1.0);
+  if (var < 0.0) var = 0.0;
+  stats[0] = (float)mean;
+  stats[1] = (float)sqrt(var);
+  stats[2] = (float)(sums[2] / n);
+}
+
+// ONE launch (round 1 used three: partial sums, a one-block reduce, a one-thread finalize -- the two tails cost as much
+// as 20 % of the streaming pass).  One wave per token: |r|^2, |rp|^2, r.rp in one pass over both slabs (each byte read
+// once, non-temporal: nothing is re-read), rho = |r|/|rp| and 1-cos accumulated per wave in double; every block
+// publishes its 4 partial sums and draws an arrival ticket; the block that draws the last one reduces the partials IN
+// INDEX ORDER (so the result does not depend on which block that is), writes sums[4] (+ stats[3]) and rearms the
+// ticket.  Hand-off = the agent-scope release / acquire pair of the CDNA4 guide (per-XCD L2s are not coherent):
+// plain stores -> __syncthreads -> lane 0: release fence, asm vmcnt(0), relaxed ticket add; last arriver: acquire
+// fence -> __syncthreads -> plain loads.
+// ticket: one zero-initialised uint32 (the engine zeroes its workspace once; standalone callers zero the scratch).
+__global__ __launch_bounds__(256) void calib_stats_kernel(const float* __restrict__ r, long ldr,
+                                                          const float* __restrict__ rp, long ldrp, int M, int D,
+                                                          double* __restrict__ partial, unsigned int* __restrict__ ticket,
+                                                          double* __restrict__ sums, float* __restrict__ stats) {
   __shared__ double red[4][4];
+  __shared__ int is_last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double s_rho = 0.0, s_rho2 = 0.0, s_cos = 0.0, s_cnt = 0.0;
   for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
@@ -81,8 +101,8 @@ __global__ __launch_bounds__(256) void calib_partial_kernel(const float* __restr
         // out-of-range chunks re-read chunk 0 (always valid) and are zeroed by a select: no branch around a load
         const int e = e0 + u * 256;
         const int ec = e < D ? e : 0;
-        av[u] = *(const f32x4*)(a + ec);
-        bv[u] = *(const f32x4*)(b + ec);
+        av[u] = __builtin_nontemporal_load((const f32x4*)(a + ec));
+        bv[u] = __builtin_nontemporal_load((const f32x4*)(b + ec));
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -118,18 +138,22 @@ __global__ __launch_bounds__(256) void calib_partial_kernel(const float* __restr
     red[wv][0] = s_rho; red[wv][1] = s_rho2; red[wv][2] = s_cos; red[wv][3] = s_cnt;
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < 4)
     partial[blockIdx.x * 4 + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back must be complete before the ticket moves
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-}
-
-__global__ __launch_bounds__(256) void calib_reduce_kernel(const double* __restrict__ partial, int n_blocks,
-                                                           double* __restrict__ sums) {
-  __shared__ double red[4][4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (!is_last) return;
+  // ---- the last arriver: deterministic reduction of all partials (thread t owns blocks t, t+256, ... in order)
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < n_blocks; i += 256) {
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] += partial[i * 4 + k];
   }
@@ -140,20 +164,20 @@ __global__ __launch_bounds__(256) void calib_reduce_kernel(const double* __restr
     for (int k = 0; k < 4; ++k) red[wv][k] = acc[k];
   }
   __syncthreads();
-  if (threadIdx.x < 4) sums[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x == 0) {
+    double tot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tot[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+      sums[k] = tot[k];
+    }
+    if (stats) calib_finalize(tot, stats);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rearm for the next launch
+  }
 }
 
-// stats[0] = mean(rho), stats[1] = std(rho) (unbiased, torch default), stats[2] = mean(1-cos)
 __global__ void calib_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stats) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const double n = sums[3];
-    const double mean = sums[0] / n;
-    double var = (sums[1] - sums[0] * sums[0] / n) / (n - 1.0);
-    if (var < 0.0) var = 0.0;
-    stats[0] = (float)mean;
-    stats[1] = (float)sqrt(var);
-    stats[2] = (float)(sums[2] / n);
-  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) calib_finalize(sums, stats);
 }
 
 inline int grid_for(long total, int block, int cap = 2048) {
@@ -183,9 +207,10 @@ hipError_t launch_residual_sub(const float* x, long ldx, const bf16_t* x0, long 
 hipError_t launch_calib_stats(const float* r, long ldr, const float* rp, long ldrp, int M, int D, double* partial,
                               int n_blocks, double* sums, float* stats, hipStream_t stream) {
   if ((D % 4) || n_blocks <= 0 || M < 2) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(calib_partial_kernel, dim3(n_blocks), dim3(256), 0, stream, r, ldr, rp, ldrp, M, D, partial);
-  hipLaunchKernelGGL(calib_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, n_blocks, sums);
-  if (stats) hipLaunchKernelGGL(calib_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, stats);
+  // the arrival ticket sits behind the 4*n_blocks partial sums (scratch of 4*n_blocks + 1 doubles, zeroed once)
+  unsigned int* ticket = (unsigned int*)(partial + 4 * (size_t)n_blocks);
+  hipLaunchKernelGGL(calib_stats_kernel, dim3(n_blocks), dim3(256), 0, stream, r, ldr, rp, ldrp, M, D, partial, ticket,
+                     sums, stats);
   return hipGetLastError();
 }
 

@@ -369,7 +369,7 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
   add_buf(e, cur, "head_tokens", Li * 64 * 4);
   add_buf(e, cur, "residual0", Sp * d * 4);
   if (c.calibration) add_buf(e, cur, "residual1", Sp * d * 4);
-  add_buf(e, cur, "calib_partial", 2048 * 4 * 8);
+  add_buf(e, cur, "calib_partial", (2048 * 4 + 2) * 8);   // + the arrival ticket of calib_stats_kernel
   add_buf(e, cur, "calib_sums", 64);
   add_buf(e, cur, "calib_stats", 64);
   e->ws_need = cur;
@@ -392,6 +392,7 @@ mc_status mc_mmdit_set_workspace(mc_mmdit* e, void* ws_dev, size_t bytes) {
   if (((uintptr_t)ws_dev) & 255) return fail(MC_EINVAL, "workspace must be 256-byte aligned");
   e->ws = (char*)ws_dev;
   e->have_res = e->have_stats = e->pads_clean = false;
+  HIP_TRY(hipMemset(e->buf<double>("calib_partial") + 2048 * 4, 0, 16));   // arrival ticket of calib_stats_kernel
   return MC_OK;
 }
 

@@ -100,7 +100,8 @@ def residual_sub(x, x0, r):
 
 def calib_stats(r, rp, n_blocks=2048):     # 2048 = what both engines launch (32 waves per CU)
     lib = _lib.load()
-    partial = torch.empty(4 * n_blocks, dtype=torch.float64, device=r.device)
+    # 4 partial sums per block + the arrival ticket, which must be zero before the first launch (the kernel rearms it)
+    partial = torch.zeros(4 * n_blocks + 1, dtype=torch.float64, device=r.device)
     sums = torch.empty(4, dtype=torch.float64, device=r.device)
     stats = torch.empty(3, dtype=torch.float32, device=r.device)
     check(lib.mc_op_calib_stats(P(r), r.stride(0), P(rp), rp.stride(0), r.shape[0], r.shape[1], P(partial), n_blocks,

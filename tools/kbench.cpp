@@ -1,19 +1,20 @@
-// Stand-alone A/B micro-benchmark of the hot kernels through the C ABI (no Python, no torch: a fresh
-// GPU box spends minutes importing torch, this starts in seconds).
+// Torch-free kernel A/B harness for the two MFMA-bound kernels at the Wan2.1-1.3B 480p shapes, through the C ABI.
 //
-//   hipcc --offload-arch=gfx950 -O2 tools/kbench.cpp -Iinclude -Lmagcache_amd -lmagcache_hip \
-//         -Wl,-rpath,'$ORIGIN/../magcache_amd' -o tools/kbench.bin
-//   tools/kbench.bin [gemm|attn|all] [iters]
+//   kbench.bin <what> <rounds> <launches> libA.so [libB.so ...]
+//      what: gemm | attn | calib | all
 //
-// For every shape it runs each kernel variant (mc_set_option), checks the variants against each
-// other and -- attention -- a sample of rows against an fp64 host reference, and prints the average
-// launch time from HIP events with the achieved TFLOP/s.  Random data, never zero-filled (zeros
-// inflate MFMA throughput by ~20 % through DVFS).
+// Every library given on the command line is dlopen'ed privately (RTLD_LOCAL), so build variants of
+// libmagcache_hip.so (tools/build_variants.py, tools/build_ab_lib.py) are measured INTERLEAVED IN ONE PROCESS on the same
+// buffers: per shape a 1 s warm-up (sustained-power regime), then <rounds> rounds of <launches> back-to-back launches
+// per library, hipEvent-timed; median and minimum per library are printed (CDNA4 guide, methodology rules 24/25: a
+// within-probe interleaved A/B on random data).  Results of libB.. are compared bit for bit with libA, and libA is
+// spot-checked against an fp64 reference.  KBENCH_AMP=0 gives zero-filled operands (shows how much of a rate is DVFS;
+// never a number to quote).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
-#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,41 +23,61 @@
 
 #include "magcache_hip.h"
 
-#define CK(x)                                                                         \
-  do {                                                                                \
-    hipError_t e_ = (x);                                                              \
-    if (e_ != hipSuccess) {                                                           \
-      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);   \
-      exit(2);                                                                        \
-    }                                                                                 \
-  } while (0)
-#define MC(x)                                                                   \
-  do {                                                                          \
-    mc_status s_ = (x);                                                         \
-    if (s_ != MC_OK) {                                                          \
-      printf("mc error %d: %s at %s:%d\n", (int)s_, mc_last_error(), __FILE__, __LINE__); \
-      exit(3);                                                                  \
-    }                                                                           \
+#define CK(x)                                                                     \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                    \
+    }                                                                             \
   } while (0)
 
-__device__ __forceinline__ uint32_t hash32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
+struct Lib {
+  std::string path;
+  void* h;
+  decltype(&mc_op_gemm_bf16) gemm;
+  decltype(&mc_op_attention) attn;
+  decltype(&mc_op_calib_stats) calib;
+  decltype(&mc_set_option) set_option;
+  decltype(&mc_last_error) last_error;
+};
+static std::vector<Lib> g_libs;
+static float g_amp = 1.0f;
+
+#define MCL(lib, x)                                                                           \
+  do {                                                                                        \
+    if ((x) != MC_OK) {                                                                       \
+      fprintf(stderr, "%s: mc error: %s at %s:%d\n", (lib).path.c_str(), (lib).last_error(), __FILE__, __LINE__); \
+      exit(2);                                                                                \
+    }                                                                                         \
+  } while (0)
+
+__device__ __forceinline__ uint32_t hash32(uint32_t i, uint32_t seed) {
+  uint32_t h = i * 2654435761u + seed * 0x9e3779b9u;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
 }
-__device__ __forceinline__ float urand(uint64_t i, uint32_t seed) {  // uniform in [-1, 1)
-  uint32_t h = hash32((uint32_t)i * 2654435761u + seed) ^ hash32((uint32_t)(i >> 32) + 0x9e3779b9u * seed);
-  return (float)(int32_t)h * (1.0f / 2147483648.0f);
+// standard normal (Box-Muller on two hashes): the bench's operands are randn, and the sustained clock depends on the
+// operand distribution
+__device__ __forceinline__ float randn(size_t i, uint32_t seed) {
+  const float u1 = ((hash32((uint32_t)i, seed) >> 8) + 1) * (1.0f / 16777216.0f);
+  const float u2 = (hash32((uint32_t)i, seed ^ 0x5bd1e995u) >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
 }
 __global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float amp) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float v = urand(i, seed) * amp;
-    __bf16 b = (__bf16)v;
+    __bf16 b = (__bf16)(randn(i, seed) * amp);
     p[i] = __builtin_bit_cast(uint16_t, b);
   }
 }
-__global__ void fill_f32(float* p, size_t n, uint32_t seed, float amp) {
+__global__ void fill_f32(float* p, size_t n, uint32_t seed, float amp, float bias) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    p[i] = urand(i, seed) * amp;
+    p[i] = randn(i, seed) * amp + bias;
+}
+__global__ void count_diff(const uint32_t* a, const uint32_t* b, size_t n, unsigned long long* out) {
+  unsigned long long c = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+  if (c) atomicAdd(out, c);
 }
 
 static float bf16_to_f(uint16_t v) {
@@ -66,223 +87,280 @@ static float bf16_to_f(uint16_t v) {
   return f;
 }
 
-extern float g_amp_v;
 template <class F>
-static double time_ms(F&& f, int iters) {
+static void measure(const char* what, double flops_or_bytes, const char* unit, double unit_scale, int rounds, int launches,
+                    F&& launch) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  for (int i = 0; i < 2; ++i) f();
-  CK(hipDeviceSynchronize());
-  CK(hipEventRecord(a, 0));
-  for (int i = 0; i < iters; ++i) f();
-  CK(hipEventRecord(b, 0));
-  CK(hipEventSynchronize(b));
-  float ms = 0;
-  CK(hipEventElapsedTime(&ms, a, b));
+  // warm-up: ~1 s of the first library
+  {
+    CK(hipEventRecord(a, nullptr));
+    float ms = 0;
+    int n = 0;
+    do {
+      for (int i = 0; i < 20; ++i) launch(0);
+      CK(hipEventRecord(b, nullptr));
+      CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&ms, a, b));
+      n += 20;
+    } while (ms < 1000.f && n < 20000);
+  }
+  std::vector<std::vector<double>> t(g_libs.size());
+  for (int r = 0; r < rounds; ++r) {
+    for (size_t l = 0; l < g_libs.size(); ++l) {
+      launch((int)l);
+      CK(hipEventRecord(a, nullptr));
+      for (int i = 0; i < launches; ++i) launch((int)l);
+      CK(hipEventRecord(b, nullptr));
+      CK(hipEventSynchronize(b));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, a, b));
+      t[l].push_back(ms / launches);
+    }
+  }
+  for (size_t l = 0; l < g_libs.size(); ++l) {
+    std::sort(t[l].begin(), t[l].end());
+    const double med = t[l][t[l].size() / 2], mn = t[l][0];
+    printf("%-12s lib%zu  median %8.4f ms %8.1f %s | min %8.4f ms %8.1f %s | x%.3f vs lib0 (median)\n", what, l, med,
+           flops_or_bytes / (med * 1e-3) * unit_scale, unit, mn, flops_or_bytes / (mn * 1e-3) * unit_scale, unit,
+           t[0][t[0].size() / 2] / med);
+  }
+  fflush(stdout);
   CK(hipEventDestroy(a));
   CK(hipEventDestroy(b));
-  return ms / iters;
 }
 
-struct Diff {
-  double max_abs = 0, max_ref = 0, sum_sq = 0, ref_sq = 0;
-  size_t nan = 0;
-  void add(double x, double ref) {
-    if (std::isnan(x) || std::isinf(x)) { ++nan; return; }
-    max_abs = std::max(max_abs, std::fabs(x - ref));
-    max_ref = std::max(max_ref, std::fabs(ref));
-    sum_sq += (x - ref) * (x - ref);
-    ref_sq += ref * ref;
-  }
-  double rel_l2() const { return ref_sq > 0 ? std::sqrt(sum_sq / ref_sq) : 0; }
-};
-
 // ------------------------------------------------------------------------------------------ GEMM
-static void bench_gemm(int M, int N, int K, int epi, const char* name, int iters) {
-  uint16_t *A, *W, *Cb[2];
-  float *bias, *gate, *X[2], *X0f;
+static void bench_gemm(const char* name, int M, int N, int K, int epi, int rounds, int launches) {
+  uint16_t *A, *W, *Cb, *Cref;
+  float *bias, *gate, *X, *X0, *Xref;
   CK(hipMalloc(&A, (size_t)M * K * 2));
   CK(hipMalloc(&W, (size_t)N * K * 2));
   CK(hipMalloc(&bias, (size_t)N * 4));
   CK(hipMalloc(&gate, (size_t)N * 4));
-  for (int v = 0; v < 2; ++v) {
-    CK(hipMalloc(&Cb[v], (size_t)M * N * 2));
-    CK(hipMalloc(&X[v], (size_t)M * N * 4));
-  }
-  CK(hipMalloc(&X0f, (size_t)M * N * 4));
-  fill_bf16<<<2048, 256>>>(A, (size_t)M * K, 1, 1.0f * g_amp_v);
-  fill_bf16<<<2048, 256>>>(W, (size_t)N * K, 2, 0.05f * g_amp_v);
-  fill_f32<<<64, 256>>>(bias, N, 3, 0.5f);
-  fill_f32<<<64, 256>>>(gate, N, 4, 1.0f);
-  fill_f32<<<2048, 256>>>(X0f, (size_t)M * N, 5, 1.0f);
+  CK(hipMalloc(&Cb, (size_t)M * N * 2));
+  CK(hipMalloc(&Cref, (size_t)M * N * 2));
+  CK(hipMalloc(&X, (size_t)M * N * 4));
+  CK(hipMalloc(&X0, (size_t)M * N * 4));
+  CK(hipMalloc(&Xref, (size_t)M * N * 4));
+  unsigned long long* dcount;
+  CK(hipMalloc(&dcount, 8));
+  fill_bf16<<<2048, 256>>>(A, (size_t)M * K, 1, 1.0f * g_amp);
+  fill_bf16<<<2048, 256>>>(W, (size_t)N * K, 2, 0.02f * g_amp);
+  fill_f32<<<64, 256>>>(bias, N, 3, 0.02f, 0.f);
+  fill_f32<<<64, 256>>>(gate, N, 4, 0.3f, 0.f);
+  fill_f32<<<2048, 256>>>(X0, (size_t)M * N, 5, 1.0f, 0.f);
+  CK(hipMemcpy(X, X0, (size_t)M * N * 4, hipMemcpyDeviceToDevice));
   CK(hipDeviceSynchronize());
-  const double flops = 2.0 * M * N * K;
-  double ms[2] = {0, 0};
-  for (int v = 0; v < 2; ++v) {
-    MC(mc_set_option("gemm_kernel", v + 1));
-    CK(hipMemcpy(X[v], X0f, (size_t)M * N * 4, hipMemcpyDeviceToDevice));
-    auto run = [&]() {
-      MC(mc_op_gemm_bf16(A, K, W, K, bias, M, N, K, epi, Cb[v], N, X[v], N, gate, nullptr, 0, nullptr, 0, nullptr, 0, 0,
-                         nullptr));
-    };
-    run();  // the compared result: exactly one application on the pristine X
+  auto launch = [&](int l) {
+    MCL(g_libs[l], g_libs[l].gemm(A, K, W, K, bias, M, N, K, epi, Cb, N, X, N, gate, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr));
+  };
+  char what[64];
+  snprintf(what, sizeof(what), "gemm_%s", name);
+  printf("# %s: M=%d N=%d K=%d epi=%d\n", what, M, N, K, epi);
+  measure(what, 2.0 * M * N * K, "TF", 1e-12, rounds, launches, launch);
+  // bitwise comparison with lib0 on pristine outputs
+  for (size_t l = 0; l < g_libs.size(); ++l) {
+    CK(hipMemcpy(X, X0, (size_t)M * N * 4, hipMemcpyDeviceToDevice));
+    CK(hipMemset(Cb, 0, (size_t)M * N * 2));
+    launch((int)l);
     CK(hipDeviceSynchronize());
-    std::vector<uint16_t> hc;
-    std::vector<float> hx;
-    if (epi <= 1) {
-      hc.resize((size_t)M * N);
-      CK(hipMemcpy(hc.data(), Cb[v], hc.size() * 2, hipMemcpyDeviceToHost));
-    } else {
-      hx.resize((size_t)M * N);
-      CK(hipMemcpy(hx.data(), X[v], hx.size() * 4, hipMemcpyDeviceToHost));
-    }
-    static std::vector<uint16_t> ref_c;
-    static std::vector<float> ref_x;
-    if (v == 0) {
-      ref_c = hc;
-      ref_x = hx;
-    } else {
-      Diff d;
-      size_t nbit = 0;
-      if (epi <= 1) {
-        for (size_t i = 0; i < hc.size(); ++i) {
-          d.add(bf16_to_f(hc[i]), bf16_to_f(ref_c[i]));
-          nbit += hc[i] != ref_c[i];
+    if (l == 0) {
+      CK(hipMemcpy(Cref, Cb, (size_t)M * N * 2, hipMemcpyDeviceToDevice));
+      CK(hipMemcpy(Xref, X, (size_t)M * N * 4, hipMemcpyDeviceToDevice));
+      // fp64 spot check of 64 outputs
+      std::vector<uint16_t> ha((size_t)M * K), hw((size_t)N * K);
+      std::vector<float> hb(N), hg(N);
+      CK(hipMemcpy(ha.data(), A, ha.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hw.data(), W, hw.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hb.data(), bias, N * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hg.data(), gate, N * 4, hipMemcpyDeviceToHost));
+      double worst = 0;
+      for (int s = 0; s < 64; ++s) {
+        const int m = (int)(((uint64_t)s * 2654435761ull + 17) % (uint64_t)M), n = (int)(((uint64_t)s * 40503ull + 5) % (uint64_t)N);
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += (double)bf16_to_f(ha[(size_t)m * K + k]) * bf16_to_f(hw[(size_t)n * K + k]);
+        acc += hb[n];
+        double got, want;
+        if (epi <= 1) {
+          uint16_t c;
+          CK(hipMemcpy(&c, Cref + (size_t)m * N + n, 2, hipMemcpyDeviceToHost));
+          got = bf16_to_f(c);
+          want = epi == 0 ? acc : 0.5 * acc * (1.0 + std::tanh(0.7978845608028654 * (acc + 0.044715 * acc * acc * acc)));
+        } else {
+          float xv, x0v;
+          CK(hipMemcpy(&xv, Xref + (size_t)m * N + n, 4, hipMemcpyDeviceToHost));
+          CK(hipMemcpy(&x0v, X0 + (size_t)m * N + n, 4, hipMemcpyDeviceToHost));
+          got = xv;
+          want = x0v + hg[n] * acc;
         }
-      } else {
-        for (size_t i = 0; i < hx.size(); ++i) {
-          d.add(hx[i], ref_x[i]);
-          nbit += hx[i] != ref_x[i];
-        }
+        worst = std::max(worst, std::fabs(got - want) / (std::fabs(want) + 1e-2));
       }
-      printf("  gemm %-10s big vs small: max_abs %.3e (max |ref| %.3e) rel_l2 %.3e differing %zu / %zu nan %zu\n", name,
-             d.max_abs, d.max_ref, d.rel_l2(), nbit, (size_t)M * N, d.nan);
+      printf("  %s lib0 vs fp64 (64 samples): worst rel err %.3e\n", what, worst);
+    } else {
+      CK(hipMemset(dcount, 0, 8));
+      if (epi <= 1) count_diff<<<1024, 256>>>((const uint32_t*)Cb, (const uint32_t*)Cref, (size_t)M * N / 2, dcount);
+      else count_diff<<<1024, 256>>>((const uint32_t*)X, (const uint32_t*)Xref, (size_t)M * N, dcount);
+      unsigned long long c;
+      CK(hipMemcpy(&c, dcount, 8, hipMemcpyDeviceToHost));
+      printf("  %s lib%zu vs lib0: %llu differing dwords\n", what, l, c);
     }
-    ms[v] = time_ms(run, iters);
   }
-  printf("gemm %-10s M=%d N=%d K=%d epi=%d | small %.3f ms %.0f TF | big %.3f ms %.0f TF | x%.2f\n", name, M, N, K, epi,
-         ms[0], flops / ms[0] * 1e-9, ms[1], flops / ms[1] * 1e-9, ms[0] / ms[1]);
   fflush(stdout);
-  MC(mc_set_option("gemm_kernel", 0));
-  CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(gate)); CK(hipFree(X0f));
-  for (int v = 0; v < 2; ++v) { CK(hipFree(Cb[v])); CK(hipFree(X[v])); }
+  CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(gate)); CK(hipFree(Cb)); CK(hipFree(Cref));
+  CK(hipFree(X)); CK(hipFree(X0)); CK(hipFree(Xref)); CK(hipFree(dcount));
 }
 
 // ------------------------------------------------------------------------------------- attention
-// Q [Lq_pad, H*128], K/V [n_shards*shard_rows, H*128] bf16; fp64 reference for `nsample` query rows
-static void bench_attn(int Lq_pad, int H, int shard_rows, int shard_valid, int n_shards, const char* name, int iters) {
+static void bench_attn(const char* name, int Lq_pad, int H, int valid, float q_amp, int rounds, int launches) {
   const int D = H * 128;
-  const int NV = 3;
-  const size_t kv_rows = (size_t)n_shards * shard_rows;
-  uint16_t *Q, *K, *V, *O;
+  uint16_t *Q, *K, *V, *O, *Oref;
   CK(hipMalloc(&Q, (size_t)Lq_pad * D * 2));
-  CK(hipMalloc(&K, kv_rows * D * 2));
-  CK(hipMalloc(&V, kv_rows * D * 2));
+  CK(hipMalloc(&K, (size_t)Lq_pad * D * 2));
+  CK(hipMalloc(&V, (size_t)Lq_pad * D * 2));
   CK(hipMalloc(&O, (size_t)Lq_pad * D * 2));
-  fill_bf16<<<2048, 256>>>(Q, (size_t)Lq_pad * D, 11, 1.7f * g_amp_v);  // uniform(-1.7,1.7): unit variance -> scores ~ N(0,1)
-  fill_bf16<<<2048, 256>>>(K, kv_rows * D, 12, 1.7f * g_amp_v);
-  fill_bf16<<<2048, 256>>>(V, kv_rows * D, 13, 1.0f * g_amp_v);
+  CK(hipMalloc(&Oref, (size_t)Lq_pad * D * 2));
+  unsigned long long* dcount;
+  CK(hipMalloc(&dcount, 8));
+  fill_bf16<<<2048, 256>>>(Q, (size_t)Lq_pad * D, 11, q_amp * g_amp);   // post-RMSNorm q, k: unit variance
+  fill_bf16<<<2048, 256>>>(K, (size_t)Lq_pad * D, 12, 1.0f * g_amp);
+  fill_bf16<<<2048, 256>>>(V, (size_t)Lq_pad * D, 13, 1.0f * g_amp);
   CK(hipDeviceSynchronize());
   const float scale = 1.0f / std::sqrt(128.0f);
-  const double flops = 4.0 * (double)Lq_pad * ((double)n_shards * shard_valid) * D;
-  double ms[NV];
-  std::vector<uint16_t> ho[NV];
-  for (int v = 0; v < NV; ++v) {
-    MC(mc_set_option("attn_kernel", v + 1));
-    CK(hipMemset(O, 0xff, (size_t)Lq_pad * D * 2));  // NaN poison
-    auto run = [&]() {
-      MC(mc_op_attention(Q, D, K, D, (long)shard_rows * D, V, D, (long)shard_rows * D, O, D, Lq_pad, H, shard_rows,
-                         shard_valid, n_shards, scale, nullptr));
-    };
-    ms[v] = time_ms(run, iters);
-    ho[v].resize((size_t)Lq_pad * D);
-    CK(hipMemcpy(ho[v].data(), O, ho[v].size() * 2, hipMemcpyDeviceToHost));
-  }
-  // fp64 reference on sampled (row, head) pairs
-  std::vector<uint16_t> hq((size_t)Lq_pad * D), hk(kv_rows * D), hv(kv_rows * D);
+  auto launch = [&](int l) {
+    MCL(g_libs[l], g_libs[l].attn(Q, D, K, D, 0, V, D, 0, O, D, Lq_pad, H, Lq_pad, valid, 1, scale, nullptr));
+  };
+  char what[64];
+  snprintf(what, sizeof(what), "attn_%s", name);
+  printf("# %s: Lq_pad=%d heads=%d valid keys=%d q_amp=%.1f\n", what, Lq_pad, H, valid, q_amp);
+  measure(what, 4.0 * (double)valid * valid * D, "TF", 1e-12, rounds, launches, launch);
+  std::vector<uint16_t> hq((size_t)Lq_pad * D), hk((size_t)Lq_pad * D), hv((size_t)Lq_pad * D), ho((size_t)Lq_pad * D);
   CK(hipMemcpy(hq.data(), Q, hq.size() * 2, hipMemcpyDeviceToHost));
   CK(hipMemcpy(hk.data(), K, hk.size() * 2, hipMemcpyDeviceToHost));
   CK(hipMemcpy(hv.data(), V, hv.size() * 2, hipMemcpyDeviceToHost));
-  Diff dr[NV], dv[NV];
-  for (int v = 1; v < NV; ++v)
-    for (size_t i = 0; i < ho[0].size(); ++i) dv[v].add(bf16_to_f(ho[v][i]), bf16_to_f(ho[0][i]));
-  const int nsample = 24;
-  for (int sidx = 0; sidx < nsample; ++sidx) {
-    const int row = (int)(((uint64_t)sidx * 2654435761ull + 12345) % (uint64_t)Lq_pad);
-    const int head = sidx % H;
-    std::vector<double> sc;
-    sc.reserve((size_t)n_shards * shard_valid);
-    double mx = -1e300;
-    for (int sh = 0; sh < n_shards; ++sh)
-      for (int k = 0; k < shard_valid; ++k) {
-        const size_t kr = (size_t)sh * shard_rows + k;
+  for (size_t l = 0; l < g_libs.size(); ++l) {
+    CK(hipMemset(O, 0xff, (size_t)Lq_pad * D * 2));
+    launch((int)l);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(ho.data(), O, ho.size() * 2, hipMemcpyDeviceToHost));
+    // fp64 reference on 8 sampled (row, head) pairs
+    double num = 0, den = 0;
+    size_t nan = 0;
+    for (int s = 0; s < 8; ++s) {
+      const int row = (int)(((uint64_t)s * 2654435761ull + 12345) % (uint64_t)valid), head = s % H;
+      std::vector<double> sc(valid);
+      double mx = -1e300;
+      for (int k = 0; k < valid; ++k) {
         double dot = 0;
         for (int d = 0; d < 128; ++d)
-          dot += (double)bf16_to_f(hq[(size_t)row * D + head * 128 + d]) * bf16_to_f(hk[kr * D + head * 128 + d]);
-        dot *= scale;
-        sc.push_back(dot);
-        mx = std::max(mx, dot);
+          dot += (double)bf16_to_f(hq[(size_t)row * D + head * 128 + d]) * bf16_to_f(hk[(size_t)k * D + head * 128 + d]);
+        sc[k] = dot * scale;
+        mx = std::max(mx, sc[k]);
       }
-    double den = 0;
-    std::vector<double> acc(128, 0.0);
-    size_t idx = 0;
-    for (int sh = 0; sh < n_shards; ++sh)
-      for (int k = 0; k < shard_valid; ++k, ++idx) {
-        const double pw = std::exp(sc[idx] - mx);
-        den += pw;
-        const size_t kr = (size_t)sh * shard_rows + k;
-        for (int d = 0; d < 128; ++d) acc[d] += pw * bf16_to_f(hv[kr * D + head * 128 + d]);
+      double z = 0;
+      std::vector<double> acc(128, 0.0);
+      for (int k = 0; k < valid; ++k) {
+        const double pw = std::exp(sc[k] - mx);
+        z += pw;
+        for (int d = 0; d < 128; ++d) acc[d] += pw * bf16_to_f(hv[(size_t)k * D + head * 128 + d]);
       }
-    for (int v = 0; v < NV; ++v)
-      for (int d = 0; d < 128; ++d) dr[v].add(bf16_to_f(ho[v][(size_t)row * D + head * 128 + d]), acc[d] / den);
+      for (int d = 0; d < 128; ++d) {
+        const double got = bf16_to_f(ho[(size_t)row * D + head * 128 + d]), want = acc[d] / z;
+        if (got != got) ++nan;
+        num += (got - want) * (got - want);
+        den += want * want;
+      }
+    }
+    printf("  %s lib%zu vs fp64 (8 rows): rel_l2 %.3e nan %zu", what, l, std::sqrt(num / den), nan);
+    if (l == 0) {
+      CK(hipMemcpy(Oref, O, (size_t)Lq_pad * D * 2, hipMemcpyDeviceToDevice));
+      printf("\n");
+    } else {
+      CK(hipMemset(dcount, 0, 8));
+      count_diff<<<1024, 256>>>((const uint32_t*)O, (const uint32_t*)Oref, (size_t)valid * D / 2, dcount);
+      unsigned long long c;
+      CK(hipMemcpy(&c, dcount, 8, hipMemcpyDeviceToHost));
+      printf(" | vs lib0: %llu differing dwords\n", c);
+    }
   }
-  printf("  attn %-8s vs fp64 (%d rows) rel_l2/max_abs/nan:", name, nsample);
-  for (int v = 0; v < NV; ++v) printf("  v%d %.3e %.3e %zu", v + 1, dr[v].rel_l2(), dr[v].max_abs, dr[v].nan);
-  printf(" | vs v1 rel_l2/nan:");
-  for (int v = 1; v < NV; ++v) printf("  v%d %.3e %zu", v + 1, dv[v].rel_l2(), dv[v].nan);
-  printf("\nattn %-8s Lq=%d H=%d keys=%dx%d(valid %d) |", name, Lq_pad, H, n_shards, shard_rows, shard_valid);
-  for (int v = 0; v < NV; ++v) printf(" v%d %.3f ms %.0f TF |", v + 1, ms[v], flops / ms[v] * 1e-9);
-  printf("\n");
   fflush(stdout);
-  MC(mc_set_option("attn_kernel", 0));
-  CK(hipFree(Q)); CK(hipFree(K)); CK(hipFree(V)); CK(hipFree(O));
+  CK(hipFree(Q)); CK(hipFree(K)); CK(hipFree(V)); CK(hipFree(O)); CK(hipFree(Oref)); CK(hipFree(dcount));
 }
 
-__attribute__((unused)) static float g_amp_dummy;
-float g_amp_v = 1.0f;
-#define g_amp g_amp_v
-static float g_amp_unused = 1.0f;  // KBENCH_AMP=0: zero-filled operands (shows how much of a rate is DVFS, never a result to quote)
+// ------------------------------------------------------------------------------------- calibration statistics
+static void bench_calib(int M, int D, int rounds, int launches) {
+  float *r, *rp, *stats;
+  double *partial, *sums;
+  CK(hipMalloc(&r, (size_t)M * D * 4));
+  CK(hipMalloc(&rp, (size_t)M * D * 4));
+  CK(hipMalloc(&partial, (2048 * 4 + 2) * 8));
+  CK(hipMalloc(&sums, 32));
+  CK(hipMalloc(&stats, 12));
+  CK(hipMemset(partial, 0, (2048 * 4 + 2) * 8));
+  fill_f32<<<2048, 256>>>(r, (size_t)M * D, 21, 1.0f, 0.f);
+  fill_f32<<<2048, 256>>>(rp, (size_t)M * D, 22, 1.1f, 0.f);
+  CK(hipDeviceSynchronize());
+  auto launch = [&](int l) { MCL(g_libs[l], g_libs[l].calib(r, D, rp, D, M, D, partial, 2048, sums, stats, nullptr)); };
+  printf("# calib_stats: 2 x [%d, %d] fp32\n", M, D);
+  measure("calib_stats", 2.0 * M * D * 4, "GB/s", 1e-9, rounds, launches, launch);
+  for (size_t l = 0; l < g_libs.size(); ++l) {
+    launch((int)l);
+    float hs[3];
+    CK(hipMemcpy(hs, stats, 12, hipMemcpyDeviceToHost));
+    printf("  calib_stats lib%zu: norm_ratio %.6f norm_std %.6f cos_dis %.6f\n", l, hs[0], hs[1], hs[2]);
+  }
+  CK(hipFree(r)); CK(hipFree(rp)); CK(hipFree(partial)); CK(hipFree(sums)); CK(hipFree(stats));
+}
 
 int main(int argc, char** argv) {
+  if (argc < 5) {
+    fprintf(stderr, "usage: kbench.bin <gemm|attn|calib|all> <rounds> <launches> libA.so [libB.so ...]\n");
+    return 2;
+  }
   if (getenv("KBENCH_AMP")) g_amp = (float)atof(getenv("KBENCH_AMP"));
-  const std::string what = argc > 1 ? argv[1] : "all";
-  const int iters = argc > 2 ? atoi(argv[2]) : 10;
-  printf("%s\n", mc_version());
-  if (what == "attn1") bench_attn(32768, 12, 32768, 32760, 1, "self480p", iters);
-  if (what == "gemm1") {
-    bench_gemm(32768, 4608, 1536, 0, "qkv", iters);
-    bench_gemm(32768, 1536, 8960, 2, "ffn2_resid", iters);
+  const std::string what = argv[1];
+  const int rounds = atoi(argv[2]), launches = atoi(argv[3]);
+  for (int i = 4; i < argc; ++i) {
+    Lib l;
+    l.path = argv[i];
+    l.h = dlopen(argv[i], RTLD_NOW | RTLD_LOCAL);
+    if (!l.h) {
+      fprintf(stderr, "dlopen %s: %s\n", argv[i], dlerror());
+      return 2;
+    }
+    l.gemm = (decltype(l.gemm))dlsym(l.h, "mc_op_gemm_bf16");
+    l.attn = (decltype(l.attn))dlsym(l.h, "mc_op_attention");
+    l.calib = (decltype(l.calib))dlsym(l.h, "mc_op_calib_stats");
+    l.set_option = (decltype(l.set_option))dlsym(l.h, "mc_set_option");
+    l.last_error = (decltype(l.last_error))dlsym(l.h, "mc_last_error");
+    if (!l.gemm || !l.attn || !l.calib || !l.set_option || !l.last_error) {
+      fprintf(stderr, "%s: missing symbols\n", argv[i]);
+      return 2;
+    }
+    // KBENCH_OPT_<i>="key=value": a process-wide option of library i (e.g. gemm_kernel=1)
+    char envn[32];
+    snprintf(envn, sizeof(envn), "KBENCH_OPT_%d", i - 4);
+    if (const char* o = getenv(envn)) {
+      std::string s(o);
+      const size_t eq = s.find('=');
+      if (eq != std::string::npos) MCL(l, l.set_option(s.substr(0, eq).c_str(), atoi(s.c_str() + eq + 1)));
+    }
+    printf("lib%d = %s\n", i - 4, argv[i]);
+    g_libs.push_back(l);
+  }
+  const int M = 32768;
+  if (what == "gemm" || what == "all") {
+    bench_gemm("qkv", M, 4608, 1536, 0, rounds, launches);
+    bench_gemm("ffn1_gelu", M, 8960, 1536, 1, rounds, launches);
+    bench_gemm("ffn2_resid", M, 1536, 8960, 2, rounds, launches);
+    bench_gemm("o_resid", M, 1536, 1536, 2, rounds, launches);
+    bench_gemm("o_bf16", M, 1536, 1536, 0, rounds, launches);
   }
   if (what == "attn" || what == "all") {
-    // correctness-first small cases (odd tile counts, partial tails, shards), then the 480p shape
-    bench_attn(256, 2, 64, 37, 1, "1tile", 3);
-    bench_attn(512, 2, 192, 130, 1, "3tiles", 3);
-    bench_attn(512, 3, 256, 256, 1, "4full", 3);
-    bench_attn(512, 2, 320, 300, 2, "2shards", 3);
-    bench_attn(1024, 2, 512, 512, 1, "cross512", 3);
-    bench_attn(32768, 12, 512, 512, 1, "xattn", iters);
-    bench_attn(32768, 12, 4096, 4095, 8, "sp8", iters);
-    bench_attn(32768, 12, 32768, 32760, 1, "self480p", iters);
+    bench_attn("self480p", 32768, 12, 32760, 1.0f, rounds, std::max(1, launches / 4));
+    bench_attn("self480p_q6", 32768, 12, 32760, 6.0f, rounds, std::max(1, launches / 4));
   }
-  if (what == "gemm" || what == "all") {
-    bench_gemm(32768, 4608, 1536, 0, "qkv", iters);
-    bench_gemm(32768, 1536, 1536, 0, "crossq", iters);
-    bench_gemm(32768, 1536, 1536, 2, "o_resid", iters);
-    bench_gemm(32768, 8960, 1536, 1, "ffn1_gelu", iters);
-    bench_gemm(32768, 1536, 8960, 2, "ffn2_resid", iters);
-    bench_gemm(4096, 3072, 1536, 0, "sp8_kv", iters);
-    bench_gemm(512, 1536, 4096, 1, "text0", iters);
-  }
+  if (what == "calib" || what == "all") bench_calib(32760, 1536, rounds, launches * 2);
   return 0;
 }
