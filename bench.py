@@ -217,9 +217,15 @@ def main():
     ap.add_argument("--no_nocache", action="store_true", help="skip the second (cache off) timed region")
     ap.add_argument("--fp8_linear", action="store_true",
                     help="OPTIONAL precision mode, never the headline: QKV / FFN Linears on the fp8 e4m3 MFMA path")
-    ap.add_argument("--no_cfg_parallel", action="store_true",
-                    help="N > 1: shard the sequence over all N ranks instead of CFG branches x N/2")
+    ap.add_argument("--layout", choices=("auto", "sp", "cfg2sp"), default="auto",
+                    help="N > 1: 'sp' = the token sequence sharded over all N ranks, one K/V all-gather per layer "
+                         "(north_star's split); 'cfg2sp' = CFG branches on two halves of the node x sequence parallel "
+                         "inside a half (SURVEY 8e's alternative); 'auto' = both are timed on 2 no-cache steps before "
+                         "the timed region (reported as layout_ablation) and the faster one runs the benchmark")
+    ap.add_argument("--no_cfg_parallel", action="store_true", help="same as --layout sp")
     args = ap.parse_args()
+    if args.no_cfg_parallel:
+        args.layout = "sp"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -229,52 +235,118 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    layout = None
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(device))
-        else:
-            dist.init_process_group(backend)
-        from magcache_amd.parallel import ParallelLayout
-        layout = ParallelLayout(cfg_parallel=not args.no_cfg_parallel)
 
     from magcache_amd import model as M
+    from magcache_amd import parallel as PAR
     from magcache_amd.engine import WAN_T2V_1_3B, synthetic_weights
     from magcache_amd.mag_ratios import TABLES
     from magcache_amd.sampler import sample
 
     cfg = dict(WAN_T2V_1_3B, fp8_linear=True) if args.fp8_linear else WAN_T2V_1_3B
-    model = M.WanModelHIP(cfg, GRID, device=device, calibration=False,
-                          sp_rank=layout.sp_rank if layout else 0, sp_size=layout.sp_size if layout else 1,
-                          sp_group=layout.sp_group if layout else None)
-    model.engine.load_weights(synthetic_weights(cfg, seed=0, device=device))
     g = torch.Generator(device=device).manual_seed(42)
     noise = torch.randn(16, *GRID, generator=g, device=device)
     ctx = torch.randn(512, cfg["text_dim"], generator=g, device=device)
     ctx_null = torch.randn(512, cfg["text_dim"], generator=g, device=device)
-
     sync = torch.cuda.synchronize
     barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
 
-    def run(steps):
+    def make_model(layout, tag):
+        cls = type("WanModelHIP_" + tag, (M.WanModelHIP,), {})     # MagCache state lives on the class: one per layout
+        m = cls(cfg, GRID, device=device, calibration=False, sp_rank=layout.sp_rank if layout else 0,
+                sp_size=layout.sp_size if layout else 1, sp_group=layout.sp_group if layout else None)
+        m.engine.load_weights(synthetic_weights(cfg, seed=0, device=device))
+        return m
+
+    def run(model, layout, steps):
         return sample(model, noise, ctx, ctx_null, sampling_steps=steps, shift=args.shift,
                       guide_scale=args.guide_scale, layout=layout)
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt[0])
+
+    layout, extra = None, {}
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
+        # how many ranks really joined the communicator (an all-reduce of ones on the data-path backend)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        extra["rccl_world"] = int(ones[0])
+        extra["comm_backend"] = dist.get_backend()
+        names = ["sp"] + (["cfg2sp"] if world % 2 == 0 else [])
+        if args.layout != "auto":
+            assert args.layout in names, f"--layout {args.layout} needs an even number of ranks"
+            names = [args.layout]
+        layouts = {n: PAR.ParallelLayout(cfg_parallel=(n == "cfg2sp")) for n in names}   # every rank builds every group
+        models = {}
+        # ---- sequence-parallel self-check: the overlapped forward (local-shard attention beside the K/V all-gather)
+        # must agree with the serialised one; otherwise run without the overlap
+        check_name = next((n for n in names if layouts[n].sp_size > 1), None)
+        if check_name is not None:
+            models[check_name] = make_model(layouts[check_name], check_name)
+            m = M.disable_magcache(models[check_name])
+            tt = torch.tensor([500.0], device=device)
+            saved = PAR.SP_OVERLAP
+            outs = []
+            for ov in (True, False):
+                PAR.SP_OVERLAP = ov
+                outs.append(m([noise], t=tt, context=[ctx], seq_len=SEQ)[0].clone())
+            PAR.SP_OVERLAP = saved
+            rel = float((outs[0] - outs[1]).norm() / outs[1].norm().clamp_min(1e-30))
+            rel = max_over_ranks(rel if rel == rel else float("inf"))
+            extra["sp_selfcheck_rel"] = rel
+            if not (rel <= 3e-3):
+                PAR.SP_OVERLAP = False
+            extra["sp_overlap"] = bool(PAR.SP_OVERLAP)
+        # ---- layout ablation: 2 no-cache steps of every candidate after 1 untimed step; the faster one is benchmarked
+        if len(names) > 1:
+            abl = {}
+            for n in names:
+                if n not in models:
+                    models[n] = make_model(layouts[n], n)
+                m = M.disable_magcache(models[n])
+                run(m, layouts[n], 1)
+                dt, _ = timed(lambda: run(m, layouts[n], 2), sync, barrier)
+                abl[n] = 2.0 / max_over_ranks(dt)
+            extra["layout_ablation_nocache_steps_per_s"] = abl
+            chosen = max(abl, key=abl.get)
+            ch = torch.tensor([names.index(chosen)], device=device)
+            dist.broadcast(ch, 0)                       # identical choice on every rank
+            chosen = names[int(ch[0])]
+        else:
+            chosen = names[0]
+        layout = layouts[chosen]
+        model = models.get(chosen) or make_model(layout, chosen)
+        for n in list(models):
+            if n != chosen:
+                del models[n]
+        torch.cuda.empty_cache()
+        extra["layout"] = chosen
+    else:
+        model = make_model(None, "single")
+
     M.disable_magcache(model)
     if args.warmup > 0:
-        run(args.warmup)
+        run(model, layout, args.warmup)
     # ---- timed region 1: K steps with MagCache
     M.init_magcache(model, args.steps, args.magcache_thresh, args.magcache_K, args.retention_ratio,
                     mag_ratios=TABLES["wan2.1_t2v_1.3B"])
     modes = []
     fwd = model._run
     model._run = lambda x, t, c, branch, mode: (modes.append(mode), fwd(x, t, c, branch, mode))[1]
-    t_mc, lat_mc = timed(lambda: run(args.steps), sync, barrier)
+    t_mc, lat_mc = timed(lambda: run(model, layout, args.steps), sync, barrier)
     model._run = fwd
     skipped = int(sum(1 for m in modes if m == 1))
     if world > 1:
         # one count per CFG branch / per job: the first rank of every sequence-parallel group reports
-        cnt = torch.tensor([skipped if layout.sp_rank == 0 else 0], device=device, dtype=torch.int64)
+        first = layout.sp_rank == 0 and (layout.cfg_size == 2 or rank == 0)
+        cnt = torch.tensor([skipped if first else 0], device=device, dtype=torch.int64)
         dist.all_reduce(cnt)
         skipped = int(cnt[0])
     # ---- timed region 2: the same K steps with the cache off
@@ -283,16 +355,15 @@ def main():
         M.disable_magcache(model)
         # hipEvent pairs around every self-attention launch of THIS timed region, on the launch stream
         model.engine.profile(True)
-        t_nc, lat_nc = timed(lambda: run(args.steps), sync, barrier)
+        t_nc, lat_nc = timed(lambda: run(model, layout, args.steps), sync, barrier)
         attn_live = model.engine.profile_read()
         model.engine.profile(False)
         mse = float(((lat_mc - lat_nc) ** 2).mean())
         rng = float(lat_nc.abs().max())
         psnr = 100.0 if mse < 1e-10 else float(20 * np.log10(rng / np.sqrt(mse)))
     if world > 1:
-        tt = torch.tensor([t_mc, t_nc or 0.0], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_mc, t_nc = float(tt[0]), (float(tt[1]) if t_nc is not None else None)
+        t_mc = max_over_ranks(t_mc)
+        t_nc = max_over_ranks(t_nc) if t_nc is not None else None
 
     if rank == 0:
         fl = flops_forward(cfg, SEQ)
@@ -319,6 +390,7 @@ def main():
             "model_tflops_per_s_nocache": (2 * args.steps * fl / t_nc / 1e12 / world) if t_nc else None,
             "model_tflops_per_s_magcache_ran": ran * fl / t_mc / 1e12 / world,
         }
+        line.update(extra)
         if world == 1 and not args.no_kernels:
             k = kernel_rooflines(cfg, device)
             line["roofline"] = {kk: k["attention"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic")}

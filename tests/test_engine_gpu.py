@@ -402,8 +402,10 @@ def test_generate_entry_point_vace_task(tmp_path):
     assert tuple(got.shape) == (16, 2, 60, 104) and bool(torch.isfinite(got).all()) and torch.equal(got, lat.cpu())
 
 
-@pytest.mark.parametrize("nproc,extra,par", [(2, [], "cfg2 x sp1"), (2, ["--no_cfg_parallel"], "sequence-parallel sp2"),
-                                             (4, [], "cfg2 x sp2")])
+@pytest.mark.parametrize("nproc,extra,par", [(2, ["--layout", "cfg2sp"], "cfg2 x sp1"),
+                                             (2, ["--layout", "sp"], "sequence-parallel sp2"),
+                                             (4, ["--layout", "cfg2sp"], "cfg2 x sp2"),
+                                             (2, [], None), (4, [], None)])
 def test_bench_two_ranks_one_gpu(nproc, extra, par):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per process), here
     with all ranks on cuda:0 over gloo: one JSON line from rank 0, the reference skip schedule, and the
@@ -422,9 +424,21 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     got = json.loads(lines[0])
-    assert got["n_gpus"] == nproc and got["config"]["parallelism"].startswith(par)
+    assert got["n_gpus"] == nproc
     assert got["forwards_skipped"] == ref["forwards_skipped"] and got["forwards_total"] == 20
     assert abs(got["psnr_vs_nocache_db"] - ref["psnr_vs_nocache_db"]) < 0.5
+    # the line verifies itself for the driver's scaling run: ranks that joined the communicator, the layout that ran
+    assert got["rccl_world"] == nproc and got["comm_backend"] == "gloo"
+    if par is not None:
+        assert got["config"]["parallelism"].startswith(par) and got["layout"] == extra[1]
+    else:
+        # --layout auto (what the driver launches): both layouts timed on 2 no-cache steps, the faster one benchmarked
+        abl = got["layout_ablation_nocache_steps_per_s"]
+        assert set(abl) == {"sp", "cfg2sp"} and all(v > 0 for v in abl.values())
+        assert got["layout"] == max(abl, key=abl.get)
+    if got["layout"] == "sp" or nproc > 2 or par is None:
+        # overlapped (local-shard attention beside the K/V all-gather) vs serialised sequence-parallel forward
+        assert got["sp_selfcheck_rel"] <= 3e-3 and got["sp_overlap"] is True
 
 
 def test_wan22_two_experts_i2v_vs_oracle():
