@@ -2,14 +2,21 @@
 //   C[M,N] = A[M,K] * W[N,K]^T  (+ the fused epilogues of gemm_epilogue.h),  N % 256 == 0; a partial last M
 //   tile re-reads row M-1 for its missing rows and does not write them.
 //
-// This is the kernel behind the large Linears of the Wan DiT block (QKV, cross-Q, FFN-1, FFN-2 at
+// This is the kernel behind the large Linears of the Wan DiT block (QKV, cross-Q, O, FFN-1, FFN-2 at
 // M = 32768 tokens; reference call site MagCache4Wan2.1/magcache_generate.py:297-298, the Linear
 // layers themselves are upstream wan/modules/model.py).  The 128x128 kernel in gemm_bf16.hip drains
 // its LDS-DMA queue (vmcnt(0)) before every barrier; this one never does inside the main loop.
 //
+// MFMA shape (round 2): v_mfma_f32_16x16x32_bf16, not 32x32x16.  Both shapes have the same peak rate, but this chip
+// runs these kernels at its package power limit, and there the shape decides the clock: a register-only MFMA loop on
+// every SIMD sustains 2095 TFLOP/s with 16x16x32 and 1296 TFLOP/s with 32x32x16 on random operands
+// (tools/ubench_mfma_power.cpp, profiles/r02/ubench_mfma_power.log) -- a 32x32x16 moves 8 KB of accumulator per
+// 16 K MACs through the register file, a 16x16x32 2 KB per 8 K MACs.  Round 1's kernel was the same pipeline on
+// 32x32x16 (kept as tools/kernels_ab/gemm_bf16_big_32x32.hip for A/B) and stopped at ~1.2 PFLOP/s in its main loop.
+//
 // Geometry
 //   * workgroup = 8 waves (2 along M x 4 along N), one 256x256 output tile, 1 workgroup per CU
-//     (128 KiB LDS); wave tile 128(M) x 64(N) = 2x2x2 MFMA 32x32x16 blocks = 128 fp32 accumulators.
+//     (128 KiB LDS); wave tile 128(M) x 64(N) = 8 x 4 MFMA blocks of 16x16 = 128 fp32 accumulators.
 //   * MFMA issued "swapped" (operand A = weight rows, B = activation rows) like the 128^2 kernel, so
 //     a lane owns 4 consecutive n of one m and the epilogues are 8/16-byte vector accesses.
 //   * a K tile (64 k) of each operand is split into two 16 KiB "halves" by WHEN a wave needs them:
@@ -18,10 +25,13 @@
 //     LDS = 2 stages x 4 halves x 16 KiB.  Each half is 16 pieces of 1 KiB (8 rows x 128 B); a wave
 //     moves 2 pieces per half with global_load_lds_dwordx4 (HBM/L2 -> LDS, no VGPR round trip).
 //   * LDS rows are 128 B; the image is XOR-swizzled, chunk' = chunk ^ ((row >> 1) & 7), applied to
-//     the SOURCE address (LDS-DMA writes lane-linear) and to the ds_read_b128 address.
+//     the SOURCE address (LDS-DMA writes lane-linear) and to the ds_read_b128 address.  A 16x16x32 fragment is 16 rows
+//     x 4 consecutive 16-byte chunks (lane -> row lane%16, chunk 4*kstep + lane/16): conflict-free under this swizzle
+//     for every ds_read_b128 lane group (checked by enumeration).
 //
-// Pipeline (one "interval" = the code between two barriers; 4 intervals per K tile kt)
-//     interval   MFMA block (8 MFMAs)     ds_read for later      LDS-DMA issued
+// Pipeline (one "interval" = the code between two barriers; 4 intervals per K tile kt; an interval multiplies one
+// 64(m) x 32(n) quadrant of the wave tile over the 64 k of the tile = 16 MFMAs)
+//     interval   MFMA block               ds_read for later      LDS-DMA issued
 //       q0       (m0,n0): Am0 x Wn0       Wn1(kt)                Wn0(kt+2)
 //       q1       (m0,n1): Am0 x Wn1       Am1(kt)                Am0(kt+2)
 //       q2       (m1,n1): Am1 x Wn1       Wn0(kt+1)              Wn1(kt+2)
@@ -53,16 +63,28 @@ constexpr int OFF_AM0 = 0, OFF_AM1 = HALF_BYTES, OFF_WN0 = 2 * HALF_BYTES, OFF_W
 #define MC_GROUP_M 8
 #endif
 constexpr int GROUP_M = MC_GROUP_M;
-// E8M0 block scale 127 = 2^0 in all four bytes: the MX-scaled MFMA with unit scales
-#define MC_F8_UNIT_SCALE 0x7f7f7f7f
-typedef __attribute__((ext_vector_type(8))) int i32x8;
-typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+#ifndef MC_ABL
+#define MC_ABL 0
+#endif
+// Diagnostic build variants (tools/build_variants.py --define MC_VAR=<bits>; results stay CORRECT, only the
+// synchronisation changes -- used by tools/race_repro.cpp to bisect the two-stream nondeterminism of DESIGN 3.2):
+//   1: WITHOUT the barrier between the prologue's fragment reads and the first refill (the round-1 kernel)
+//   2: every steady-state wait retires one more half (vmcnt(8) instead of (10)): masks an under-counted wait
+//   4: the LDS-DMA loads carry sc0 sc1 (served by L2, the CU's vector L1 is bypassed): masks a stale L1 line
+//  16: vmcnt(0) at the end of every interval: no LDS-DMA is ever in flight across a barrier
+// Timing ablations (tools/build_variants.py gemm_bf16_big.hip <bits>, macro MC_ABL; results are WRONG by
+// construction): 1: no A fragment reads, 2: no W fragment reads, 4: no LDS-DMA refills, 8: no workgroup barriers --
+// all in the steady-state loop only; the prologue always runs, so every register holds finite data.
+#ifndef MC_VAR
+#define MC_VAR 0
+#endif
 
 // end-of-interval wait: at most n LDS-DMA instructions of this wave still in flight.  (ds_reads need
 // no wait here: a region is re-filled two barriers after its last read, and every read has been
 // consumed by an MFMA -- i.e. waited for -- one barrier earlier.)
 #define MC_WAIT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define MC_WAIT(n, r)                                    \
+#define MC_WAIT(n)                                       \
   do {                                                   \
     if (MC_VAR & 16) MC_WAIT_(0);                        \
     else if ((MC_VAR & 2) && (n) == 10) MC_WAIT_(8);     \
@@ -78,41 +100,21 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 #define MC_PIN() __builtin_amdgcn_sched_barrier(0)
 
-// Timing ablations (tools/build_variants.py gemm_bf16_big.hip <bits>; results are WRONG by construction): what the
-// steady-state LDS traffic costs.  1: no A fragment reads, 2: no W fragment reads, 4: no LDS-DMA refills,
-// 8: no workgroup barriers.  The prologue always runs, so every register holds finite data.
-#ifndef MC_ABL
-#define MC_ABL 0
-#endif
-// Diagnostic build variants (tools/build_variants.py --define MC_VAR=<bits>; results stay CORRECT, only the
-// synchronisation changes -- used by tools/race_repro.cpp to bisect the two-stream nondeterminism of DESIGN 3.2):
-//   1: WITHOUT the barrier between the prologue's fragment reads and the first refill (the round-1 kernel)
-//   2: every steady-state wait retires one more half (vmcnt(8) instead of (10)): masks an under-counted wait
-//   4: the LDS-DMA loads carry sc0 sc1 (served by L2, the CU's vector L1 is bypassed): masks a stale L1 line
-//  16: vmcnt(0) at the end of every interval: no LDS-DMA is ever in flight across a barrier
-#ifndef MC_VAR
-#define MC_VAR 0
-#endif
-
-struct Frag4 {  // one 32-row block x 64 k = 4 MFMA operands
-  bf16x8 v[4];
+struct FragA {  // one A half of a wave: 64 rows x 64 k = [m block of 16][k step of 32]
+  bf16x8 v[4][2];
+};
+struct FragW {  // one W half of a wave: 32 rows x 64 k = [n block of 16][k step of 32]
+  bf16x8 v[2][2];
 };
 
-// F8: the same pipeline on fp8 (OCP e4m3) operands.  A K tile is still 128 bytes per row (128 k instead of 64), the
-// LDS image, the DMA pieces and the ds_read_b128 fragment reads are byte-identical; a wave issues 4
-// v_mfma_f32_32x32x64_f8f6f4 per interval (unit block scales; 64 k each, twice the MACs per pipe cycle of the bf16
-// form) instead of 8 bf16 MFMAs.  Per-row activation scales and per-output-channel weight scales (fp32) are applied
-// to the fp32 accumulator in the epilogue.  p.A / p.W point to bytes, lda / ldw / K count fp8 elements.
-template <int EPI, bool F8>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tilesM, int tilesN) {
-  constexpr int EL = F8 ? 1 : 2;        // bytes per element
-  constexpr int KE = 128 / EL;          // elements per K tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int l31 = lane & 31;
+  const int l15 = lane & 15;
+  const int kgrp = lane >> 4;  // which 8 of the 32 k of an MFMA this lane feeds / which 4 n of a 16-block it owns
   const int wr = wv >> 2, wc = wv & 3;
 
   // ---- tile mapping: XCD-contiguous, grouped along M so neighbouring tiles share W panels in L2
@@ -138,47 +140,42 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
       const int chunk = (lane & 7) ^ ((r >> 1) & 7);
       const int ra = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
       const int rw = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-      srcA[h][j] = ((uint32_t)ra * (uint32_t)p.lda) * EL + chunk * 16;
-      srcW[h][j] = ((uint32_t)rw * (uint32_t)p.ldw) * EL + chunk * 16;
+      srcA[h][j] = ((uint32_t)ra * (uint32_t)p.lda) * 2 + chunk * 16;
+      srcW[h][j] = ((uint32_t)rw * (uint32_t)p.ldw) * 2 + chunk * 16;
     }
   }
   // LDS byte address (M0 value) of this wave's two pieces inside half 0 of stage 0
   const uint32_t dma_lds = (uint32_t)(uintptr_t)MC_LDS_PTR(smem) + wv * 2048;
 
-  // ---- fragment read offsets inside a half: image row = blk*32 + l31 (+64 for wave row 1 of an
-  // A half / + wc*32 for W), 16-B chunk (2*ks + half) ^ ((row>>1)&7); (row>>1)&7 == (lane>>1)&7
-  const int sw = (lane >> 1) & 7;
-  int fo[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    // bf16: fragment ks = k-substep ks, 16-B chunk 2*ks + half.  fp8: fragments (2s, 2s+1) = the 32 bytes of
-    // k-substep s that this lane half owns, chunks 4s + 2*half + {0, 1}
-    const int chunk = F8 ? 4 * (ks >> 1) + 2 * half + (ks & 1) : 2 * ks + half;
-    fo[ks] = l31 * 128 + ((chunk ^ sw) << 4);
-  }
+  // ---- fragment read offsets inside a half: image row = blk*16 + l15 (+ wr*64 for an A half / + wc*32 for W),
+  // 16-B chunk (4*ks + kgrp) ^ ((row>>1)&7); (row>>1)&7 == l15>>1 because every block starts at a multiple of 16 rows
+  const int sw = l15 >> 1;
   // per-wave bases folded into the lane offsets: every ds_read below is base VGPR + immediate
   // (one set per stage: the second stage starts at 64 KiB, beyond the 16-bit DS offset field)
-  int foa[2][4], fow[2][4];
+  int foa[2][2], fow[2][2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      foa[st][ks] = fo[ks] + wr * (64 * 128) + st * STAGE_BYTES;  // + ms*32*128
-      fow[st][ks] = fo[ks] + wc * (32 * 128) + st * STAGE_BYTES;
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fo = l15 * 128 + (((4 * ks + kgrp) ^ sw) << 4);
+      foa[st][ks] = fo + wr * (64 * 128) + st * STAGE_BYTES;  // + mb*16*128
+      fow[st][ks] = fo + wc * (32 * 128) + st * STAGE_BYTES;  // + nb*16*128
     }
   }
 
-  f32x16 acc[2][2][2];  // [m half][ms][n half]
+  f32x4 acc[2][4][2][2];  // [m half][m block][n half][n block]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[a][b][c][d][r] = 0.f;
 
-  const int nk = p.K / KE;
+  const int nk = p.K / BK;
 
   // LDS-DMA issue in inline asm: hipcc's waitcnt pass makes every ds_read that follows a
   // __builtin_amdgcn_global_load_lds wait for it (vmcnt(0) in the loop); an asm DMA is invisible to
@@ -214,49 +211,43 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   };
   auto dma_a = [&](int kt, int st, int h) { dma_a1(kt, st, h, 0); dma_a1(kt, st, h, 1); };  // prologue
   auto dma_w = [&](int kt, int st, int h) { dma_w1(kt, st, h, 0); dma_w1(kt, st, h, 1); };
-  // fragment i = 4*ms + ks of this wave's A half h / fragment ks of its W half h
-  auto read_a1 = [&](int st, int h, int i, Frag4 (&f)[2]) {
-    f[i >> 2].v[i & 3] =
-        *(const bf16x8*)(smem + (h ? OFF_AM1 : OFF_AM0) + (i >> 2) * (32 * 128) + foa[st][i & 3]);
+  // fragment i = 2*mb + ks (0..7) of this wave's A half h / fragment i = 2*nb + ks (0..3) of its W half h
+  auto read_a1 = [&](int st, int h, int i, FragA& f) {
+    f.v[i >> 1][i & 1] = *(const bf16x8*)(smem + (h ? OFF_AM1 : OFF_AM0) + (i >> 1) * (16 * 128) + foa[st][i & 1]);
   };
-  auto read_w1 = [&](int st, int h, int ks, Frag4& f) {
-    f.v[ks] = *(const bf16x8*)(smem + (h ? OFF_WN1 : OFF_WN0) + fow[st][ks]);
+  auto read_w1 = [&](int st, int h, int i, FragW& f) {
+    f.v[i >> 1][i & 1] = *(const bf16x8*)(smem + (h ? OFF_WN1 : OFF_WN0) + (i >> 1) * (16 * 128) + fow[st][i & 1]);
   };
-  auto read_a = [&](int st, int h, Frag4 (&f)[2]) {  // prologue
+  auto read_a = [&](int st, int h, FragA& f) {  // prologue
 #pragma unroll
     for (int i = 0; i < 8; ++i) read_a1(st, h, i, f);
   };
-  auto read_w = [&](int st, int h, Frag4& f) {
+  auto read_w = [&](int st, int h, FragW& f) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) read_w1(st, h, ks, f);
+    for (int i = 0; i < 4; ++i) read_w1(st, h, i, f);
   };
-  // MFMA i (0..7) of an interval: k-substep i/2, 32-row block i%2 -> two rotating accumulators
-  auto mma1 = [&](int i, const Frag4& w, const Frag4 (&a)[2], f32x16 (&c0), f32x16 (&c1)) {
-    if constexpr (F8) {
-      // slots 0, 2, 4, 6: k-substep s = i/4 (64 k), 32-row block (i/2)%2; odd slots are empty
-      if ((i & 1) == 0) {
-        const int s2 = (i >> 2) * 2, blk = (i >> 1) & 1;
-        const i32x8 wv = __builtin_shufflevector(__builtin_bit_cast(i32x4, w.v[s2]), __builtin_bit_cast(i32x4, w.v[s2 + 1]),
-                                                 0, 1, 2, 3, 4, 5, 6, 7);
-        const i32x8 av = __builtin_shufflevector(__builtin_bit_cast(i32x4, a[blk].v[s2]),
-                                                 __builtin_bit_cast(i32x4, a[blk].v[s2 + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
-        f32x16& c = blk ? c1 : c0;
-        c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, c, 0, 0, 0, MC_F8_UNIT_SCALE, 0, MC_F8_UNIT_SCALE);
-      }
-    } else {
-      if (i & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i >> 1], a[1].v[i >> 1], c1, 0, 0, 0);
-      else c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i >> 1], a[0].v[i >> 1], c0, 0, 0, 0);
-    }
+  // MFMA i (0..15) of an interval: k step i/8, m block (i/2)%4, n block i%2 -> the 8 accumulators of the quadrant in
+  // rotation (an accumulator is touched again 8 MFMAs later)
+  // The MFMA is an asm statement with the accumulator as a read-write operand: with the builtin, hipcc renames the
+  // 4-register accumulators freely (D != C), parks results in dying fragment registers and pays for it with ~35
+  // v_mov_b64, s_nop hazards and fragment spills per loop trip; "+v" pins every accumulator to its registers.  The
+  // operands come from ds_reads (hipcc's waitcnt pass sees asm operands and waits for them); hazards hipcc does not
+  // pad for an asm statement: accumulator zero-init -> first MFMA (far apart: the whole prologue lies between) and
+  // last MFMA -> epilogue VALU reads (the s_nop block behind the main loop).
+  auto mma1 = [&](int i, const FragW& w, const FragA& a, f32x4 (&c)[4][2][2], int nh) {
+    const int ks = i >> 3, mb = (i >> 1) & 3, nb = i & 1;
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[mb][nh][nb]) : "v"(w.v[nb][ks]), "v"(a.v[mb][ks]));
   };
 
   // ---- prologue: K tiles 0 and 1 in the steady-state issue order; Wn0(0), Am0(0), Wn1(0) landed
   dma_w(0, 0, 0); dma_a(0, 0, 0); dma_w(0, 0, 1); dma_a(0, 0, 1);
   dma_w(1, 1, 0); dma_a(1, 1, 0); dma_w(1, 1, 1); dma_a(1, 1, 1);
-  MC_WAIT(10, 0);
+  MC_WAIT(10);
   MC_BARRIER();
   // A0/A1: this wave's m0/m1 halves; W0/W1: n0/n1 of the current tile, W2: n0 of the next (W0 is
   // still live when it is read, so W0/W2 ping-pong by renaming; A0 is dead by then and is reused)
-  Frag4 A0[2], A1[2], W0, W1, W2;
+  FragA A0, A1;
+  FragW W0, W1, W2;
   read_w(0, 0, W0);
   read_a(0, 0, A0);
   // Wn0 of stage 0 is re-filled (K tile 2) by the FIRST interval below: every wave must have issued its reads of
@@ -265,120 +256,48 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   // wave delayed by that much behind its workgroup could hit.)
   if (!(MC_VAR & 1)) MC_BARRIER();
 
+  // One interval = 16 MFMA slots of quadrant (MH, NH) with the fragment sets WF / AF.  RDW / RDA: the fragment read
+  // issued in slot i_ for a LATER interval (4 W fragments in the even slots 0..6, or 8 A fragments in slots 0..7 + 8 --
+  // see the call sites); D0 / D1: the two LDS-DMA pieces of the half this interval refills, in slots 9 and 13, where
+  // no ds_read is issued.
+#define MC_INTERVAL(WF, AF, MH, NH, READ_STMT, D0, D1)                         \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                          \
+    mma1(i_, WF, AF, acc[MH], NH);                                             \
+    READ_STMT;                                                                 \
+    if (i_ == 9) { D0; }                                                       \
+    if (i_ == 13) { D1; }                                                      \
+    MC_PIN();                                                                  \
+  }
+#define MC_RD_W(COND, ST_, H_, DST) if ((COND) && !(MC_ABL & 2) && (i_ & 1) == 0 && i_ < 8) read_w1(ST_, H_, i_ >> 1, DST)
+#define MC_RD_A(COND, ST_, H_, DST) if ((COND) && !(MC_ABL & 1) && i_ < 8) read_a1(ST_, H_, i_, DST)
+
   // TAIL 0: steady state (tile kt+2 exists); 1: kt == nk-2; 2: kt == nk-1.  ST = kt & 1, a literal.
   // Wait counts: at the end of an interval the half that is read in the NEXT interval must have
   // landed.  Steady state: 6 halves (12 DMAs) issued since, the oldest must be done -> vmcnt(10).
   // Tile nk-2 issues nothing: 4,3,2,1 halves may stay in flight -> 8,6,4,2; tile nk-1: 0 once.
-#define MC_TILE(TAIL, kt, ST, W0, W2) \
-  { \
-    /* q0: (m0,n0); reads Wn1(kt); DMA Wn0(kt+2) */ \
-    mma1(0, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (!(MC_ABL & 2)) read_w1(ST, 1, 0, W1); \
-    MC_PIN(); \
-    mma1(1, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    MC_PIN(); \
-    mma1(2, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (!(MC_ABL & 2)) read_w1(ST, 1, 1, W1); \
-    if (TAIL == 0 && !(MC_ABL & 4)) dma_w1((kt) + 2, ST, 0, 0); \
-    MC_PIN(); \
-    mma1(3, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    MC_PIN(); \
-    mma1(4, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (!(MC_ABL & 2)) read_w1(ST, 1, 2, W1); \
-    MC_PIN(); \
-    mma1(5, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (TAIL == 0 && !(MC_ABL & 4)) dma_w1((kt) + 2, ST, 0, 1); \
-    MC_PIN(); \
-    mma1(6, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    if (!(MC_ABL & 2)) read_w1(ST, 1, 3, W1); \
-    MC_PIN(); \
-    mma1(7, W0, A0, acc[0][0][0], acc[0][1][0]); \
-    MC_PIN(); \
-    if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(8, 0); else MC_WAIT(0, 0); \
-    MC_BARRIER(); \
-    /* q1: (m0,n1); reads Am1(kt); DMA Am0(kt+2) */ \
-    mma1(0, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (!(MC_ABL & 1)) read_a1(ST, 1, 0, A1); \
-    MC_PIN(); \
-    mma1(1, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (!(MC_ABL & 1)) read_a1(ST, 1, 1, A1); \
-    MC_PIN(); \
-    mma1(2, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (!(MC_ABL & 1)) read_a1(ST, 1, 2, A1); \
-    if (TAIL == 0 && !(MC_ABL & 4)) dma_a1((kt) + 2, ST, 0, 0); \
-    MC_PIN(); \
-    mma1(3, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (!(MC_ABL & 1)) read_a1(ST, 1, 3, A1); \
-    MC_PIN(); \
-    mma1(4, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (!(MC_ABL & 1)) read_a1(ST, 1, 4, A1); \
-    MC_PIN(); \
-    mma1(5, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (!(MC_ABL & 1)) read_a1(ST, 1, 5, A1); \
-    if (TAIL == 0 && !(MC_ABL & 4)) dma_a1((kt) + 2, ST, 0, 1); \
-    MC_PIN(); \
-    mma1(6, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (!(MC_ABL & 1)) read_a1(ST, 1, 6, A1); \
-    MC_PIN(); \
-    mma1(7, W1, A0, acc[0][0][1], acc[0][1][1]); \
-    if (!(MC_ABL & 1)) read_a1(ST, 1, 7, A1); \
-    MC_PIN(); \
-    if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(6, 0); \
-    MC_BARRIER(); \
-    /* q2: (m1,n1); reads Wn0(kt+1); DMA Wn1(kt+2) */ \
-    mma1(0, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL != 2 && !(MC_ABL & 2)) read_w1(1 - ST, 0, 0, W2); \
-    MC_PIN(); \
-    mma1(1, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    MC_PIN(); \
-    mma1(2, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL != 2 && !(MC_ABL & 2)) read_w1(1 - ST, 0, 1, W2); \
-    if (TAIL == 0 && !(MC_ABL & 4)) dma_w1((kt) + 2, ST, 1, 0); \
-    MC_PIN(); \
-    mma1(3, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    MC_PIN(); \
-    mma1(4, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL != 2 && !(MC_ABL & 2)) read_w1(1 - ST, 0, 2, W2); \
-    MC_PIN(); \
-    mma1(5, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL == 0 && !(MC_ABL & 4)) dma_w1((kt) + 2, ST, 1, 1); \
-    MC_PIN(); \
-    mma1(6, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    if (TAIL != 2 && !(MC_ABL & 2)) read_w1(1 - ST, 0, 3, W2); \
-    MC_PIN(); \
-    mma1(7, W1, A1, acc[1][0][1], acc[1][1][1]); \
-    MC_PIN(); \
-    if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(4, 0); \
-    MC_BARRIER(); \
-    /* q3: (m1,n0); reads Am0(kt+1); DMA Am1(kt+2) */ \
-    mma1(0, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 0, A0); \
-    MC_PIN(); \
-    mma1(1, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 1, A0); \
-    MC_PIN(); \
-    mma1(2, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 2, A0); \
-    if (TAIL == 0 && !(MC_ABL & 4)) dma_a1((kt) + 2, ST, 1, 0); \
-    MC_PIN(); \
-    mma1(3, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 3, A0); \
-    MC_PIN(); \
-    mma1(4, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 4, A0); \
-    MC_PIN(); \
-    mma1(5, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 5, A0); \
-    if (TAIL == 0 && !(MC_ABL & 4)) dma_a1((kt) + 2, ST, 1, 1); \
-    MC_PIN(); \
-    mma1(6, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 6, A0); \
-    MC_PIN(); \
-    mma1(7, W0, A1, acc[1][0][0], acc[1][1][0]); \
-    if (TAIL != 2 && !(MC_ABL & 1)) read_a1(1 - ST, 0, 7, A0); \
-    MC_PIN(); \
-    if (TAIL == 0) MC_WAIT(10, 0); else if (TAIL == 1) MC_WAIT(2, 0); \
-    MC_BARRIER(); \
+#define MC_DMA_OK(TAIL) ((TAIL) == 0 && !(MC_ABL & 4))
+#define MC_TILE(TAIL, kt, ST, W0, W2)                                                                         \
+  {                                                                                                           \
+    /* q0: (m0,n0); reads Wn1(kt); DMA Wn0(kt+2) */                                                           \
+    MC_INTERVAL(W0, A0, 0, 0, MC_RD_W(true, ST, 1, W1),                                                       \
+                if (MC_DMA_OK(TAIL)) dma_w1((kt) + 2, ST, 0, 0), if (MC_DMA_OK(TAIL)) dma_w1((kt) + 2, ST, 0, 1)) \
+    if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(8); else MC_WAIT(0);                              \
+    MC_BARRIER();                                                                                             \
+    /* q1: (m0,n1); reads Am1(kt); DMA Am0(kt+2) */                                                           \
+    MC_INTERVAL(W1, A0, 0, 1, MC_RD_A(true, ST, 1, A1),                                                       \
+                if (MC_DMA_OK(TAIL)) dma_a1((kt) + 2, ST, 0, 0), if (MC_DMA_OK(TAIL)) dma_a1((kt) + 2, ST, 0, 1)) \
+    if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(6);                                               \
+    MC_BARRIER();                                                                                             \
+    /* q2: (m1,n1); reads Wn0(kt+1); DMA Wn1(kt+2) */                                                         \
+    MC_INTERVAL(W1, A1, 1, 1, MC_RD_W(TAIL != 2, 1 - ST, 0, W2),                                              \
+                if (MC_DMA_OK(TAIL)) dma_w1((kt) + 2, ST, 1, 0), if (MC_DMA_OK(TAIL)) dma_w1((kt) + 2, ST, 1, 1)) \
+    if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(4);                                               \
+    MC_BARRIER();                                                                                             \
+    /* q3: (m1,n0); reads Am0(kt+1); DMA Am1(kt+2) */                                                         \
+    MC_INTERVAL(W0, A1, 1, 0, MC_RD_A(TAIL != 2, 1 - ST, 0, A0),                                              \
+                if (MC_DMA_OK(TAIL)) dma_a1((kt) + 2, ST, 1, 0), if (MC_DMA_OK(TAIL)) dma_a1((kt) + 2, ST, 1, 1)) \
+    if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(2);                                               \
+    MC_BARRIER();                                                                                             \
   }
 
   // nk is even (checked by the launcher): steady pairs, then the two tail tiles
@@ -390,47 +309,42 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   MC_TILE(1, kt, 0, W0, W2);
   MC_TILE(2, kt + 1, 1, W2, W0);
 #undef MC_TILE
+  // XDL write -> VALU read of the accumulators: the MFMAs are asm statements, hipcc pads nothing for them
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#undef MC_INTERVAL
+#undef MC_RD_W
+#undef MC_RD_A
+#undef MC_DMA_OK
 
-  // ---- epilogue.  acc[mh][ms][nh][r] = C[m][n], m = m0 + wr*128 + mh*64 + ms*32 + l31,
-  //      n = n0 + wc*64 + nh*32 + (r&3) + 8*(r>>2) + 4*half  -> 4 consecutive n per (r>>2)
+  // ---- epilogue.  acc[mh][mb][nh][nb][r] = C[m][n], m = m0 + wr*128 + mh*64 + mb*16 + l15,
+  //      n = n0 + wc*64 + nh*32 + nb*16 + 4*kgrp + r  -> 4 consecutive n per accumulator
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-      const int m = m0 + wr * 128 + mh * 64 + ms * 32 + l31;
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = m0 + wr * 128 + mh * 64 + mb * 16 + l15;
       if (m >= p.M) continue;
-      float sa = 1.f;
-      if constexpr (F8) sa = p.a_scale[m];
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wc * 64 + nh * 32 + 8 * g + 4 * half;
-          f32x4 val;
+        for (int nb = 0; nb < 2; ++nb) {
+          const int n = n0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp;
           f32x4 b = {0.f, 0.f, 0.f, 0.f};
           if (p.bias) b = *(const f32x4*)(p.bias + n);
-          if constexpr (F8) {
-            const f32x4 sw4 = *(const f32x4*)(p.w_scale + n);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) val[i] = acc[mh][ms][nh][4 * g + i] * (sa * sw4[i]) + b[i];
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) val[i] = acc[mh][ms][nh][4 * g + i] + b[i];
-          }
-          gemm_epilogue_quad<EPI>(p, m, n, val);
+          gemm_epilogue_quad<EPI>(p, m, n, acc[mh][mb][nh][nb] + b);
         }
       }
     }
   }
 }
 
-template <int EPI, bool F8 = false>
+template <int EPI>
 hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
   const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
   static std::atomic<uint64_t> lds_ready{0};
-  if (hipError_t e = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI, F8>, 2 * STAGE_BYTES, lds_ready); e != hipSuccess)
+  if (hipError_t e = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, 2 * STAGE_BYTES, lds_ready); e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((gemm_big_kernel<EPI, F8>), dim3(tilesM * tilesN), dim3(512), 2 * STAGE_BYTES, stream, p,
+  hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(tilesM * tilesN), dim3(512), 2 * STAGE_BYTES, stream, p,
                      tilesM, tilesN);
   return hipGetLastError();
 }
@@ -452,25 +366,6 @@ hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream
     case EPI_RESID_GATE: return launch_big_t<EPI_RESID_GATE>(p, stream);
     case EPI_RESID_CAPTURE: return launch_big_t<EPI_RESID_CAPTURE>(p, stream);
     case EPI_F32: return launch_big_t<EPI_F32>(p, stream);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-// fp8 variant: K in fp8 elements, two K tiles of 128 per loop trip
-bool gemm_fp8_supported(const GemmParams& p) {
-  return p.M > 0 && p.N > 0 && (p.N % TB) == 0 && (p.K % 256) == 0 && p.K >= 512 && (p.lda % 16) == 0 &&
-         (p.ldw % 16) == 0 && p.a_scale && p.w_scale && (size_t)p.M * (size_t)p.lda < (1ull << 32) &&
-         (size_t)p.N * (size_t)p.ldw < (1ull << 32);
-}
-
-hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream) {
-  if (!gemm_fp8_supported(p)) return hipErrorInvalidValue;
-  switch (epi) {
-    case EPI_BF16: return launch_big_t<EPI_BF16, true>(p, stream);
-    case EPI_GELU_BF16: return launch_big_t<EPI_GELU_BF16, true>(p, stream);
-    case EPI_RESID_GATE: return launch_big_t<EPI_RESID_GATE, true>(p, stream);
-    case EPI_RESID_CAPTURE: return launch_big_t<EPI_RESID_CAPTURE, true>(p, stream);
-    case EPI_F32: return launch_big_t<EPI_F32, true>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -73,12 +73,13 @@ __device__ __forceinline__ void calib_finalize(const double* sums, float* stats)
 
 // ONE launch (round 1 used three: partial sums, a one-block reduce, a one-thread finalize -- the two tails cost as much
 // as 20 % of the streaming pass).  One wave per token: |r|^2, |rp|^2, r.rp in one pass over both slabs (each byte read
-// once, non-temporal: nothing is re-read), rho = |r|/|rp| and 1-cos accumulated per wave in double; every block
-// publishes its 4 partial sums and draws an arrival ticket; the block that draws the last one reduces the partials IN
-// INDEX ORDER (so the result does not depend on which block that is), writes sums[4] (+ stats[3]) and rearms the
-// ticket.  Hand-off = the agent-scope release / acquire pair of the CDNA4 guide (per-XCD L2s are not coherent):
-// plain stores -> __syncthreads -> lane 0: release fence, asm vmcnt(0), relaxed ticket add; last arriver: acquire
-// fence -> __syncthreads -> plain loads.
+// once), rho = |r|/|rp| and 1-cos accumulated per wave in double; every block publishes its 4 partial sums and draws an
+// arrival ticket; the block that draws the last one reduces the partials IN INDEX ORDER (so the result does not depend
+// on which block that is), writes sums[4] (+ stats[3]) and rearms the ticket.
+// Hand-off (per-XCD L2s are not coherent; CDNA4 guide, Guideline 16 form R1): the partials are 8-byte WRITE-THROUGH
+// stores (relaxed agent-scope atomic stores = global_store_dwordx2 sc1), drained with an asm vmcnt(0) before the
+// relaxed ticket add -- no release fence: a per-block buffer_wbl2 (2048 L2 write-backs) measured +40 % on the whole
+// kernel; the last arriver issues ONE agent acquire and reads the partials with sc1 loads.
 // ticket: one zero-initialised uint32 (the engine zeroes its workspace once; standalone callers zero the scratch).
 __global__ __launch_bounds__(256) void calib_stats_kernel(const float* __restrict__ r, long ldr,
                                                           const float* __restrict__ rp, long ldrp, int M, int D,
@@ -101,8 +102,13 @@ __global__ __launch_bounds__(256) void calib_stats_kernel(const float* __restric
         // out-of-range chunks re-read chunk 0 (always valid) and are zeroed by a select: no branch around a load
         const int e = e0 + u * 256;
         const int ec = e < D ? e : 0;
+#ifdef MC_CALIB_NT
         av[u] = __builtin_nontemporal_load((const f32x4*)(a + ec));
         bv[u] = __builtin_nontemporal_load((const f32x4*)(b + ec));
+#else
+        av[u] = *(const f32x4*)(a + ec);
+        bv[u] = *(const f32x4*)(b + ec);
+#endif
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -138,13 +144,13 @@ __global__ __launch_bounds__(256) void calib_stats_kernel(const float* __restric
     red[wv][0] = s_rho; red[wv][1] = s_rho2; red[wv][2] = s_cos; red[wv][3] = s_cnt;
   }
   __syncthreads();
-  if (threadIdx.x < 4)
-    partial[blockIdx.x * 4 + threadIdx.x] =
-        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 4) {
+    const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    __hip_atomic_store(&partial[blockIdx.x * 4 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have left before the ticket moves
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back must be complete before the ticket moves
     const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == gridDim.x - 1);
     if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -155,7 +161,8 @@ __global__ __launch_bounds__(256) void calib_stats_kernel(const float* __restric
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] += partial[i * 4 + k];
+    for (int k = 0; k < 4; ++k)
+      acc[k] += __hip_atomic_load(&partial[i * 4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = wave_sum_d(acc[k]);

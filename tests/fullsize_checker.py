@@ -126,14 +126,23 @@ def _hy_joint_attention(bf16_mode):
     return joint_attention
 
 
+def _hy_timestep_embedding(t, dim, max_period=10000):
+    """oracle.hunyuan_ref.timestep_embedding with the frequency table created on t's device"""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32, device=t.device) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
 @contextmanager
 def hunyuan_on_gpu(bf16_mode):
-    saved = HR.joint_attention
+    saved = (HR.joint_attention, HR.timestep_embedding)
     HR.joint_attention = _hy_joint_attention(bf16_mode)
+    HR.timestep_embedding = _hy_timestep_embedding
     try:
         yield
     finally:
-        HR.joint_attention = saved
+        HR.joint_attention, HR.timestep_embedding = saved
 
 
 def rel_l2(a, b):

@@ -166,8 +166,10 @@ int main(int argc, char** argv) {
 
   // reference: strictly serial
   one_pass(false);
+  // (on the SAME stream: a device-to-device hipMemcpy on the null stream is asynchronous to the host and not ordered
+  // with non-blocking streams -- the first replay's poison memset would race with it)
+  CK(hipMemcpyAsync(ref, qkv, (size_t)S * N * 2, hipMemcpyDeviceToDevice, sa));
   CK(hipStreamSynchronize(sa));
-  CK(hipMemcpy(ref, qkv, (size_t)S * N * 2, hipMemcpyDeviceToDevice));
   // serial replays must reproduce it (otherwise the kernel itself is not deterministic)
   size_t bad_replays = 0, bad_groups = 0, bad_poison = 0, bad_img = 0, bad_txt = 0;
   std::vector<std::string> samples;

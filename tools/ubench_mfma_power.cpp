@@ -98,12 +98,13 @@ int main() {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const int iters = 20000;
+  const bool quick = getenv("UBENCH_QUICK") != nullptr;   // one short round per configuration (for a PMC pass)
   // per launch: blocks * 8 waves * iters * 16 MFMA(32x32x16: 32768 FLOP) or 32 MFMA(16x16x32: 16384 FLOP)
   const double flop = (double)blocks * 8 * iters * 16 * 2.0 * 32 * 32 * 16;
   for (int zero = 0; zero < 2; ++zero) {
     fill<<<1024, 256>>>((uint32_t*)src, (size_t)blocks * threads * 8 * 4, zero);
     CK(hipDeviceSynchronize());
-    for (int round = 0; round < 3; ++round) {
+    for (int round = 0; round < (quick ? 1 : 3); ++round) {
       for (int shape = 0; shape < 2; ++shape) {
         float ms_total = 0;
         int n = 0;
@@ -115,7 +116,7 @@ int main() {
           CK(hipEventRecord(e1, nullptr));
           CK(hipEventSynchronize(e1));
           CK(hipEventElapsedTime(&ms_total, e0, e1));
-        } while (ms_total < 1500.f);
+        } while (ms_total < (quick ? 300.f : 1500.f));
         printf("%s operands, round %d: %s  %.3f ms per launch  %.0f TFLOP/s\n", zero ? "zero  " : "random", round,
                shape == 0 ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x32_bf16", ms_total / n,
                flop * n / (ms_total * 1e-3) * 1e-12);
