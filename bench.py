@@ -107,7 +107,14 @@ def kernel_rooflines(cfg, device):
     by = SEQ * d * 10.0
     res["skip_add"] = dict(bound="hbm", achieved=by / t / 1e9, peak=8000.0, unit="GB/s", frac=by / t / 8e12,
                            ms=t * 1e3, shape=f"[{SEQ},{d}] bf16+fp32->fp32")
-    t = ev_time(lambda: H.calib_stats(r, out), 20)
+    # raw op, buffers allocated once (H.calib_stats copies its result to the host: a sync per call)
+    from magcache_amd import _lib as L
+    lib = L.load()
+    part = torch.zeros(4 * 2048 + 1, dtype=torch.float64, device=device)
+    sums = torch.empty(4, dtype=torch.float64, device=device)
+    stats = torch.empty(3, dtype=torch.float32, device=device)
+    t = ev_time(lambda: L.check(lib.mc_op_calib_stats(H.P(r), r.stride(0), H.P(out), out.stride(0), SEQ, d, H.P(part), 2048,
+                                                      H.P(sums), H.P(stats), H.S())), 20)
     by = SEQ * d * 8.0
     res["calib_stats"] = dict(bound="hbm", achieved=by / t / 1e9, peak=8000.0, unit="GB/s", frac=by / t / 8e12,
                               ms=t * 1e3, shape=f"2x[{SEQ},{d}] fp32")

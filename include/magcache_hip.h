@@ -73,7 +73,8 @@ const char* mc_last_error(void);
 const char* mc_version(void);
 /* Process-wide tuning knobs (no reference counterpart; results are identical for every setting up
  * to fp32 summation order): "gemm_kernel" 0 = chosen by shape, 1 = 128x128-tile kernel, 2 = 256x256
- * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 (= 3) = the one attention kernel shipped.  Used by the
+ * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 (= 4) = the 16x16x32-MFMA attention kernel, 3 = the same
+ * pipeline on 32x32x16 (round 1's kernel, kept for A/B).  Used by the
  * parity tests and the A/B micro-benchmarks (tools/build_ab_lib.py builds a library that also answers to the
  * retired kernel generations under tools/kernels_ab/). */
 mc_status mc_set_option(const char* key, int value);

@@ -520,8 +520,9 @@ hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// mc_set_option("attn_kernel", v): 0 / 3 = this kernel.  The A/B library (tools/build_ab_lib.py, -DMC_AB_KERNELS)
-// also links tools/kernels_ab/attention{,_v2}.hip as 1 / 2; the shipped library has this kernel only.
+// mc_set_option("attn_kernel", v): 0 / 4 = attention_v4.hip (16x16x32 MFMA shape, the default), 3 = this kernel
+// (32x32x16, round 1's default, kept selectable for the A/B of the MFMA shape).  The A/B library
+// (tools/build_ab_lib.py, -DMC_AB_KERNELS) also links tools/kernels_ab/attention{,_v2}.hip as 1 / 2.
 int g_attn_kernel = 0;
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
@@ -532,7 +533,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
   if (!two_phase && g_attn_kernel == 1) return launch_attention_v1(p, stream);
   if (!two_phase && g_attn_kernel == 2) return launch_attention_v2(p, stream);
 #endif
-  return launch_attention_v3(p, stream);
+  if (g_attn_kernel == 3) return launch_attention_v3(p, stream);
+  return launch_attention_v4(p, stream);
 }
 
 }  // namespace mc

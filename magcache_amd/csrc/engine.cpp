@@ -1221,9 +1221,10 @@ mc_status mc_set_option(const char* key, int value) {
     mc::g_gemm_kernel = value;
   } else if (k == "attn_kernel") {
 #ifndef MC_AB_KERNELS
-    if (value != 0 && value != 3) return fail(MC_EINVAL, "attn_kernel must be 0 or 3 (one attention kernel is shipped)");
+    if (value != 0 && value != 3 && value != 4)
+      return fail(MC_EINVAL, "attn_kernel must be 0 / 4 (16x16x32 MFMA kernel) or 3 (32x32x16 kernel)");
 #endif
-    if (value < 0 || value > 3) return fail(MC_EINVAL, "attn_kernel must be 0..3");
+    if (value < 0 || value > 4) return fail(MC_EINVAL, "attn_kernel must be 0..4");
     mc::g_attn_kernel = value;
   } else {
     return fail(MC_EINVAL, "unknown option '%s'", key);

@@ -59,10 +59,13 @@ constexpr int BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // Am0 | Am1 | Wn0 | Wn1
 constexpr int OFF_AM0 = 0, OFF_AM1 = HALF_BYTES, OFF_WN0 = 2 * HALF_BYTES, OFF_WN1 = 3 * HALF_BYTES;
-#ifndef MC_GROUP_M
-#define MC_GROUP_M 8
+// tile rasterisation: an XCD walks groups of GROUP_M M-tiles x all N-tiles, M fastest.  Measured (kbench, M = 32768):
+// 8 for N = 4608 (QKV: 1176 vs 1168 TF), 4 for N = 8960 (FFN-1: 1138 vs 1096 TF), no difference for N = 1536.
+#ifdef MC_GROUP_M
+#define MC_GROUP_M_OF(tilesN) (MC_GROUP_M)
+#else
+#define MC_GROUP_M_OF(tilesN) ((tilesN) >= 32 ? 4 : 8)
 #endif
-constexpr int GROUP_M = MC_GROUP_M;
 
 #ifndef MC_ABL
 #define MC_ABL 0
@@ -108,7 +111,7 @@ struct FragW {  // one W half of a wave: 32 rows x 64 k = [n block of 16][k step
 };
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tilesM, int tilesN) {
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -345,7 +348,7 @@ hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
   if (hipError_t e = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, 2 * STAGE_BYTES, lds_ready); e != hipSuccess)
     return e;
   hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(tilesM * tilesN), dim3(512), 2 * STAGE_BYTES, stream, p,
-                     tilesM, tilesN);
+                     tilesM, tilesN, MC_GROUP_M_OF(tilesN));
   return hipGetLastError();
 }
 

@@ -102,13 +102,9 @@ __global__ __launch_bounds__(256) void calib_stats_kernel(const float* __restric
         // out-of-range chunks re-read chunk 0 (always valid) and are zeroed by a select: no branch around a load
         const int e = e0 + u * 256;
         const int ec = e < D ? e : 0;
-#ifdef MC_CALIB_NT
+        // non-temporal: both slabs are read exactly once (5.77 vs 5.40 TB/s, kbench calib)
         av[u] = __builtin_nontemporal_load((const f32x4*)(a + ec));
         bv[u] = __builtin_nontemporal_load((const f32x4*)(b + ec));
-#else
-        av[u] = *(const f32x4*)(a + ec);
-        bv[u] = *(const f32x4*)(b + ec);
-#endif
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {

@@ -522,3 +522,75 @@ def test_forward_is_graph_capturable(golden, hip_model):
         torch.cuda.synchronize()
         assert torch.equal(a, ea) and torch.equal(b, eb)
         assert not torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
+def test_sequence_parallel_overlap_is_deterministic_in_process():
+    """The one concurrency the engine ships: while the other ranks' K|V shards arrive -- RCCL writes
+    them into this rank's gather buffer on ITS stream -- the attention kernel already runs over the local shard on the
+    compute stream.  One process drives BOTH ranks' engines of a 2-way sequence-parallel forward on cuda:0 and plays
+    RCCL's part with asynchronous device copies on a side stream, so the copy really overlaps attn_fwd (same access
+    pattern as the in-place all-gather: a peer's rows land in the neighbouring slot of the buffer the kernel reads).
+    30 replays must be BIT-identical, at a size where both kernels run for a while (L = 8192 per rank, 12 heads), and
+    equal to the serialised schedule (copy first, then attention)."""
+    cfg = dict(W.WAN_T2V_1_3B, num_layers=2)
+    grid = (4, 64, 128)                     # 4 * 32 * 64 = 8192 tokens -> 4096 per rank
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    from magcache_amd.engine import synthetic_weights
+    sd = dict(synthetic_weights(cfg, seed=5, device=DEV))
+    eng = []
+    for r in range(2):
+        e = Engine(cfg, grid, device=DEV, sp_rank=r, sp_size=2, n_branches=2, calibration=False)
+        e.load_weights(sd)
+        eng.append(e)
+    d = cfg["dim"]
+    kv = [e.buffer("kv_gather", torch.bfloat16).view(2, -1, 2 * d) for e in eng]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    lat = torch.randn(16, *grid, generator=g, device=DEV)
+    ctx = torch.randn(77, cfg["text_dim"], generator=g, device=DEV)
+    t = torch.tensor([611.0], device=DEV)
+    side = torch.cuda.Stream(device=DEV)
+    main = torch.cuda.current_stream()
+
+    def forward(overlap):
+        outs = []
+        for e in eng:
+            e.embed(lat, t, ctx)
+        for layer in range(cfg["num_layers"]):
+            for e in eng:
+                e.block_pre_attn(layer)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            done = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                kv[0][1].copy_(kv[1][1], non_blocking=True)     # rank 1's shard -> rank 0's gather buffer
+                kv[1][0].copy_(kv[0][0], non_blocking=True)     # and vice versa
+                done.record(side)
+            if not overlap:
+                main.wait_event(done)
+            for e in eng:
+                e.block_attn_local(layer)                       # overlaps the copies
+            main.wait_event(done)
+            for e in eng:
+                e.block_post_attn(layer, 0, MC_MODE_FULL)
+        for e in eng:
+            e.head(0, MC_MODE_FULL)
+            outs.append(e.buffer("head_tokens", torch.float32).view(-1, 64)[:L // 2].clone())
+        torch.cuda.synchronize()
+        return torch.cat(outs)
+
+    ref = forward(overlap=False)
+    assert bool(torch.isfinite(ref).all())
+    for rep in range(30):
+        got = forward(overlap=True)
+        assert torch.equal(got, ref), f"replay {rep}: overlapped forward differs from the serialised one"
+    # and the sharded result is the 1-rank engine's up to the extra bf16 rounding of the partial attention output
+    e1 = Engine(cfg, grid, device=DEV, n_branches=2, calibration=False)
+    e1.load_weights(sd)
+    e1.embed(lat, t, ctx)
+    for layer in range(cfg["num_layers"]):
+        e1.block_pre_attn(layer)
+        e1.block_post_attn(layer, 0, MC_MODE_FULL)
+    e1.head(0, MC_MODE_FULL)
+    one = e1.buffer("head_tokens", torch.float32).view(-1, 64)[:L]
+    assert rel_l2(ref, one) < 3e-3

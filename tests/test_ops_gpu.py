@@ -39,6 +39,16 @@ def kernel_variant(request):
     _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
 
 
+@pytest.fixture(params=[4, 3], ids=["attn-16x16x32", "attn-32x32x16"])
+def attn_variant(request):
+    """The attention tests run on the shipped kernel (attention_v4.hip, v_mfma_f32_16x16x32_bf16) and on round 1's
+    kernel (attention_v3.hip, 32x32x16), which stays selectable for the A/B of the MFMA shape."""
+    lib = _lib.load()
+    _lib.check(lib.mc_set_option(b"attn_kernel", request.param))
+    yield request.param
+    _lib.check(lib.mc_set_option(b"attn_kernel", 0))
+
+
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (512, 1536, 1536), (1000, 384, 4096),
                                    (77, 8960, 1536), (256, 1536, 8960), (768, 512, 256), (256, 256, 4096),
@@ -191,7 +201,7 @@ def attn_ref(q, k, v, n_heads, valid_idx):
                                                                 (256, 3, 128, 77, 3), (768, 2, 512, 512, 1),
                                                                 (256, 2, 256, 193, 2), (256, 1, 64, 1, 1),
                                                                 (512, 2, 448, 448, 1), (256, 2, 192, 129, 4)])
-def test_attention_vs_fp32_reference(Lq, heads, shard_rows, valid, n_shards):
+def test_attention_vs_fp32_reference(Lq, heads, shard_rows, valid, n_shards, attn_variant):
     d = heads * 128
     q = rnd(Lq, d, seed=1, dtype=torch.bfloat16)
     k = rnd(n_shards * shard_rows, d, seed=2, dtype=torch.bfloat16)
@@ -213,7 +223,7 @@ def test_attention_vs_fp32_reference(Lq, heads, shard_rows, valid, n_shards):
 @pytest.mark.parametrize("Lq,heads,shard_rows,valid,n_shards,local", [(256, 2, 256, 193, 2, 0), (256, 2, 256, 193, 2, 1),
                                                                       (512, 1, 128, 77, 4, 2), (256, 3, 192, 192, 3, 2),
                                                                       (256, 1, 64, 1, 8, 5)])
-def test_attention_two_phase_local_then_remote(Lq, heads, shard_rows, valid, n_shards, local):
+def test_attention_two_phase_local_then_remote(Lq, heads, shard_rows, valid, n_shards, local, attn_variant):
     """Sequence-parallel overlap: the local shard first (writes O and the log2-sum-exp), then all shards but the
     local one merged in the kernel epilogue == one pass over all shards == the fp32 reference."""
     d = heads * 128
@@ -258,7 +268,7 @@ def test_attention_two_phase_rejects_bad_selection():
         H.attention_partial(q, q, q, o, 1, 64, 64, 4, 0.1, 64 * 128, skip_shard=4)
 
 
-def test_attention_strided_qkv_and_online_softmax_rescale():
+def test_attention_strided_qkv_and_online_softmax_rescale(attn_variant):
     """q/k/v interleaved in one [L, 3d] buffer (the engine's layout) and a key whose score dwarfs all
     earlier tiles, forcing the running-max rescale late in the loop"""
     L, heads = 512, 2
