@@ -73,8 +73,8 @@ const char* mc_last_error(void);
 const char* mc_version(void);
 /* Process-wide tuning knobs (no reference counterpart; results are identical for every setting up
  * to fp32 summation order): "gemm_kernel" 0 = chosen by shape, 1 = 128x128-tile kernel, 2 = 256x256
- * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 (= 4) = the 16x16x32-MFMA attention kernel, 3 = the same
- * pipeline on 32x32x16 (round 1's kernel, kept for A/B).  Used by the
+ * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 (= 3) = the attention kernel (32x32x16 MFMA), 4 = the same
+ * pipeline on 16x16x32 (attention_v4.hip, kept for A/B: not faster on this workload).  Used by the
  * parity tests and the A/B micro-benchmarks (tools/build_ab_lib.py builds a library that also answers to the
  * retired kernel generations under tools/kernels_ab/). */
 mc_status mc_set_option(const char* key, int value);
@@ -115,6 +115,16 @@ mc_status mc_set_clip_fea(mc_engine* e, const void* clip_dev, mc_dtype dtype, in
  * change the scale only. */
 mc_status mc_set_vace_context(mc_engine* e, const float* vace_dev, float context_scale, mc_stream stream);
 
+/* Wan2.2 TI2V-5B: per-token timesteps.  The Wan2.2 forward takes t [B, seq_len] and builds e [B, seq_len, d] /
+ * e0 [B, seq_len, 6, d] (MagCache4Wan2.2/magcache_generate.py:261-270); the upstream pipeline passes t * mask, i.e. the
+ * tokens of the conditioning frame carry t = 0 and all others the step's t: at most TWO distinct values per forward.
+ * The engine evaluates the time MLP for max(t) and min(t) and selects per token (LayerNorm modulation, both gated
+ * residual epilogues, the head) instead of materialising e0 (9.3 GB fp32 at 14B / 720p).  t_tokens_dev: fp32
+ * [seq_len of the whole video] that must stay valid until the forward has run, or NULL to return to the scalar t of
+ * mc_forward.  "tok_t2" (3 floats: max, min, number of tokens that are NEITHER -- must read 0) is the device-side
+ * record of what was found. */
+mc_status mc_set_token_timesteps(mc_engine* e, const float* t_tokens_dev, mc_stream stream);
+
 /* Measurement hook: with profiling on, every SELF-attention launch of a forward is bracketed by a hipEvent pair on the
  * launch stream (sequence parallel: the local-shard and the remote-shards launch of a layer each; up to 8192 launches
  * between reads); mc_profile_read waits for them, returns the summed kernel time
@@ -137,7 +147,8 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
 mc_status mc_vace_block_pre(mc_engine* e, int i, mc_stream stream);
 mc_status mc_vace_block_post(mc_engine* e, int i, int branch, mc_mode mode, mc_stream stream);
 mc_status mc_head(mc_engine* e, int branch, mc_mode mode, mc_stream stream); /* -> "head_tokens" */
-/* tokens_dev: fp32 [n_tok, 4*out_dim] for tokens tok0..tok0+n_tok-1 -> out_dev [out_dim,F,H,W] */
+/* tokens_dev: fp32 [n_tok, row stride = 4*out_dim rounded up to 64] for tokens tok0..tok0+n_tok-1 ->
+ * out_dev [out_dim,F,H,W] */
 mc_status mc_unpatchify(mc_engine* e, const float* tokens_dev, int tok0, int n_tok, float* out_dev,
                         mc_stream stream);
 

@@ -520,8 +520,9 @@ hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// mc_set_option("attn_kernel", v): 0 / 4 = attention_v4.hip (16x16x32 MFMA shape, the default), 3 = this kernel
-// (32x32x16, round 1's default, kept selectable for the A/B of the MFMA shape).  The A/B library
+// mc_set_option("attn_kernel", v): 0 / 3 = this kernel (the default); 4 = attention_v4.hip, the same pipeline on the
+// 16x16x32 MFMA shape -- correct (same parity tests), equal in the contiguous-layout micro-benchmark (1246 vs 1250 TF)
+// but 6-11 % slower on the engine's strided q|k|v layout (profiles/r02), so it is not dispatched.  The A/B library
 // (tools/build_ab_lib.py, -DMC_AB_KERNELS) also links tools/kernels_ab/attention{,_v2}.hip as 1 / 2.
 int g_attn_kernel = 0;
 
@@ -533,8 +534,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
   if (!two_phase && g_attn_kernel == 1) return launch_attention_v1(p, stream);
   if (!two_phase && g_attn_kernel == 2) return launch_attention_v2(p, stream);
 #endif
-  if (g_attn_kernel == 3) return launch_attention_v3(p, stream);
-  return launch_attention_v4(p, stream);
+  if (g_attn_kernel == 4) return launch_attention_v4(p, stream);
+  return launch_attention_v3(p, stream);
 }
 
 }  // namespace mc

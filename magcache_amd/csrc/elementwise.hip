@@ -22,10 +22,17 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
                                                           const float* __restrict__ sc,
                                                           const float* __restrict__ sh, int mode, float eps,
                                                           bf16_t* __restrict__ out, long ldo,
-                                                          float* __restrict__ out_f32, long ldof, int M, int D) {
+                                                          float* __restrict__ out_f32, long ldof, int M, int D,
+                                                          const float* __restrict__ sc2,
+                                                          const float* __restrict__ sh2,
+                                                          const uint8_t* __restrict__ sel) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  if (sel && sel[row]) {   // per-token modulation (one wave per row: uniform)
+    sc = sc2;
+    sh = sh2;
+  }
   const float* xr = x + (size_t)row * ldx;
   f32x4 v[NV];
 #pragma unroll
@@ -359,8 +366,8 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restri
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = f32_to_bf16(src[n4 * 4 + threadIdx.x]);
 }
 
-// ------------------------------------------------------------------ head Linear, fp32, small N (<= 64)
-// block = 256 threads -> 64 rows x 64 cols, K chunked by 32 through LDS; thread = 4x4 outputs.
+// ------------------------------------------------------------------ head Linear, fp32, small N
+// block = 256 threads -> 64 rows x 64 cols (blockIdx.y = column block), K chunked by 32 through LDS; thread = 4x4 outputs.
 __global__ __launch_bounds__(256) void head_linear_kernel(const float* __restrict__ xn, long ldx,
                                                           const float* __restrict__ Wt,
                                                           const float* __restrict__ b, float* __restrict__ out,
@@ -369,6 +376,11 @@ __global__ __launch_bounds__(256) void head_linear_kernel(const float* __restric
   __shared__ float ws[32][65];
   const int tid = threadIdx.x;
   const int m0 = blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  Wt += (size_t)n0 * K;
+  b += n0;
+  out += n0;
+  N -= n0;
   const int tr = tid >> 4, tc = tid & 15;  // thread -> rows tr*4.., cols tc*4..
   float acc[4][4];
 #pragma unroll
@@ -464,13 +476,14 @@ inline int grid_for(long total, int block, int cap = 2048) {
 
 hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long ldx0, const float* sc,
                               const float* sh, int mode, float eps, bf16_t* out, long ldo, float* out_f32,
-                              long ldof, int M, int D, hipStream_t stream) {
-  if (M <= 0 || D <= 0 || (D % 256) != 0) return hipErrorInvalidValue;
+                              long ldof, int M, int D, hipStream_t stream, const float* sc2, const float* sh2,
+                              const uint8_t* sel) {
+  if (M <= 0 || D <= 0 || (D % 256) != 0 || (sel && (!sc2 || !sh2))) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
 #define MC_LN_CASE(NV)                                                                                      \
   case NV:                                                                                                  \
     hipLaunchKernelGGL((ln_modulate_kernel<NV>), grid, block, 0, stream, x, ldx, x0, ldx0, sc, sh, mode, eps, out, \
-                       ldo, out_f32, ldof, M, D);                                                           \
+                       ldo, out_f32, ldof, M, D, sc2, sh2, sel);                                                           \
     break;
   switch (D / 256) {
     MC_LN_CASE(1)
@@ -581,9 +594,59 @@ hipError_t launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t
 
 hipError_t launch_head_linear(const float* xn, long ldx, const float* W, const float* b, float* out, long ldo,
                               int M, int N, int K, hipStream_t stream) {
-  if (N > 64 || (K % 32) != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(head_linear_kernel, dim3((M + 63) / 64), dim3(256), 0, stream, xn, ldx, W, b, out, ldo, M, N,
-                     K);
+  if (N > 256 || N <= 0 || (K % 32) != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(head_linear_kernel, dim3((M + 63) / 64, (N + 63) / 64), dim3(256), 0, stream, xn, ldx, W, b, out,
+                     ldo, M, N, K);
+  return hipGetLastError();
+}
+
+// Wan2.2 TI2V per-token timesteps, see ops.h.  One block: n_all <= a few 100 k tokens, once per forward.
+__global__ __launch_bounds__(1024) void token_t_prepare_kernel(const float* __restrict__ t, int n_all, int row0, int n_rows,
+                                                               int n_rows_pad, float* __restrict__ t2,
+                                                               uint8_t* __restrict__ sel) {
+  __shared__ float s_max[16], s_min[16];
+  __shared__ int s_cnt[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float mx = -__builtin_huge_valf(), mn = __builtin_huge_valf();
+  for (int i = threadIdx.x; i < n_all; i += 1024) {
+    const float v = t[i];
+    mx = fmaxf(mx, v);
+    mn = fminf(mn, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+  }
+  if (lane == 0) { s_max[wv] = mx; s_min[wv] = mn; }
+  __syncthreads();
+  mx = s_max[0];
+  mn = s_min[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) {
+    mx = fmaxf(mx, s_max[w]);
+    mn = fminf(mn, s_min[w]);
+  }
+  int other = 0;
+  for (int i = threadIdx.x; i < n_all; i += 1024) other += (t[i] != mx && t[i] != mn);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) other += __shfl_xor(other, o, 64);
+  if (lane == 0) s_cnt[wv] = other;
+  for (int i = threadIdx.x; i < n_rows_pad; i += 1024) sel[i] = (i < n_rows && mn != mx && t[row0 + i] == mn) ? 1 : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < 16; ++w) c += s_cnt[w];
+    t2[0] = mx;
+    t2[1] = mn;
+    t2[2] = (float)c;
+  }
+}
+
+hipError_t launch_token_t_prepare(const float* t, int n_all, int row0, int n_rows, int n_rows_pad, float* t2, uint8_t* sel,
+                                  hipStream_t stream) {
+  if (!t || n_all <= 0 || row0 < 0 || n_rows <= 0 || row0 + n_rows > n_all || n_rows_pad < n_rows) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(token_t_prepare_kernel, dim3(1), dim3(1024), 0, stream, t, n_all, row0, n_rows, n_rows_pad, t2, sel);
   return hipGetLastError();
 }
 

@@ -86,6 +86,8 @@ struct mc_engine {
   int img_rows = 0;     // 257 image tokens padded to a multiple of 64
   bool have_clip = false;
   int local_attn_layer = -1;  // layer whose local-shard attention already ran (two-phase SP attention)
+  const float* tok_t = nullptr;  // Wan2.2 TI2V: per-token timesteps of the next forwards (mc_set_token_timesteps)
+  int HT = 64;                   // row stride of "head_tokens": 4*out_dim rounded up to 64
   // optional in-stream timing of the dominant kernel (self-attention): hipEvent pairs around every launch
   bool profile = false;
   std::vector<hipEvent_t> prof_ev;
@@ -242,6 +244,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   e->Lp = (int)align_up(e->Lr, 256);
   e->tok0 = e->rank * e->Lr;
   e->Kp = (int)align_up((size_t)c.in_dim * 4, 64);
+  e->HT = (int)align_up((size_t)c.out_dim * 4, 64);
   e->ctx_rows = (int)align_up(c.text_len, 64);
   const size_t d = e->d, ffn = e->ffn;
 
@@ -394,8 +397,12 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   add_buf(e, cur, "ctx_h", (size_t)e->ctx_rows * d * 2);
   add_buf(e, cur, "ctx", (size_t)e->ctx_rows * d * 2);
   add_buf(e, cur, "ckv", (size_t)e->ctx_rows * 2 * d * 2);
-  add_buf(e, cur, "temb", (size_t)(c.freq_dim + 2 * d + 6 * d) * 4);  // sinus | h1 | e | e0
-  add_buf(e, cur, "emod", (size_t)(e->NL + e->NV) * 6 * d * 4);
+  // two sets of everything that depends on t: set 0 for the (maximum) timestep, set 1 for the second value per-token
+  // timesteps may carry (Wan2.2 TI2V: the conditioning frame's tokens have t = 0)
+  add_buf(e, cur, "temb", (size_t)2 * (c.freq_dim + 2 * d + 6 * d) * 4);  // 2 x (sinus | h1 | e | e0)
+  add_buf(e, cur, "emod", (size_t)2 * (e->NL + e->NV) * 6 * d * 4);
+  add_buf(e, cur, "tok_sel", (size_t)Lp + 256);
+  add_buf(e, cur, "tok_t2", 64);
   if (c.fp8_linear) {
     add_buf(e, cur, "aq", Lp * std::max(d, ffn));            // e4m3 activations of the current fp8 GEMM
     add_buf(e, cur, "a_scale", Lp * 4);                      // their per-token scales
@@ -405,8 +412,8 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_buf(e, cur, "c0", Lp * d * 2);                       // vace_patch_embedding(vace_context), constant per video
     add_buf(e, cur, "vtokens", Lp * (size_t)e->Kvp * 2);
   }
-  add_buf(e, cur, "ehead", 2 * d * 4);
-  add_buf(e, cur, "head_tokens", Lp * 64 * 4);
+  add_buf(e, cur, "ehead", 2 * 2 * d * 4);
+  add_buf(e, cur, "head_tokens", (size_t)Lp * e->HT * 4);
   add_buf(e, cur, "kv_gather", e->P > 1 ? (size_t)e->P * Lp * 2 * d * 2 : 256);
   add_buf(e, cur, "residual0", Lp * d * 4);
   add_buf(e, cur, "residual1", c.n_branches > 1 ? Lp * d * 4 : 256);
@@ -619,22 +626,31 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
     p.m_valid = e->Lr;
     HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
   }
-  // e = time_embedding(sinusoidal(t)) ; e0 = time_projection(e)   (fp32, :249-253)
-  float* temb = e->buf<float>("temb");
-  float* sinus = temb;
-  float* h1 = temb + c.freq_dim;
-  float* ev = h1 + d;
-  float* e0 = ev + d;
-  HIP_TRY(mc::launch_sinusoid(t_dev, t_host, c.freq_dim, sinus, s));
-  HIP_TRY(mc::launch_gemv_f32(e->w_time0, sinus, e->b_time0, h1, d, c.freq_dim, 0, 1, s));
-  HIP_TRY(mc::launch_gemv_f32(e->w_time1, h1, e->b_time1, ev, d, d, 0, 0, s));
-  HIP_TRY(mc::launch_gemv_f32(e->w_tproj, ev, e->b_tproj, e0, 6 * d, d, 1, 0, s));
-  // per-layer modulation vectors (block.modulation + e0) and the head's (head.modulation + e)
-  float* emod = e->buf<float>("emod");
-  for (int l = 0; l < e->NL + e->NV; ++l)
-    HIP_TRY(mc::launch_add_bcast(e0, 6 * d, (l < e->NL ? e->layers[l] : e->vlayers[l - e->NL]).mod,
-                                 emod + (size_t)l * 6 * d, 6 * d, s));
-  HIP_TRY(mc::launch_add_bcast(ev, d, e->head_mod, e->buf<float>("ehead"), 2 * d, s));
+  // e = time_embedding(sinusoidal(t)) ; e0 = time_projection(e)   (fp32, :249-253).  With per-token timesteps
+  // (Wan2.2, MagCache4Wan2.2/magcache_generate.py:261-270: e [B, seq_len, d], e0 [B, seq_len, 6, d]) the same chain
+  // runs for the two values the tokens carry -- max (set 0) and min (set 1) -- and every consumer selects per token.
+  const int n_sets = e->tok_t ? 2 : 1;
+  float* t2 = e->buf<float>("tok_t2");
+  if (e->tok_t)
+    HIP_TRY(mc::launch_token_t_prepare(e->tok_t, e->L, e->tok0, e->Lr, e->Lp, t2, e->buf<uint8_t>("tok_sel"), s));
+  const size_t temb_set = (size_t)c.freq_dim + 2 * d + 6 * d, emod_set = (size_t)(e->NL + e->NV) * 6 * d;
+  for (int set = 0; set < n_sets; ++set) {
+    float* temb = e->buf<float>("temb") + set * temb_set;
+    float* sinus = temb;
+    float* h1 = temb + c.freq_dim;
+    float* ev = h1 + d;
+    float* e0 = ev + d;
+    HIP_TRY(mc::launch_sinusoid(e->tok_t ? t2 + set : t_dev, t_host, c.freq_dim, sinus, s));
+    HIP_TRY(mc::launch_gemv_f32(e->w_time0, sinus, e->b_time0, h1, d, c.freq_dim, 0, 1, s));
+    HIP_TRY(mc::launch_gemv_f32(e->w_time1, h1, e->b_time1, ev, d, d, 0, 0, s));
+    HIP_TRY(mc::launch_gemv_f32(e->w_tproj, ev, e->b_tproj, e0, 6 * d, d, 1, 0, s));
+    // per-layer modulation vectors (block.modulation + e0) and the head's (head.modulation + e)
+    float* emod = e->buf<float>("emod") + set * emod_set;
+    for (int l = 0; l < e->NL + e->NV; ++l)
+      HIP_TRY(mc::launch_add_bcast(e0, 6 * d, (l < e->NL ? e->layers[l] : e->vlayers[l - e->NL]).mod,
+                                   emod + (size_t)l * 6 * d, 6 * d, s));
+    HIP_TRY(mc::launch_add_bcast(ev, d, e->head_mod, e->buf<float>("ehead") + set * 2 * d, 2 * d, s));
+  }
   // context = text_embedding(zero-padded context)   (:256-262)
   bf16_t* ctx_in = e->buf<bf16_t>("ctx_in");
   if (ctx_dtype == MC_F32) {
@@ -672,11 +688,20 @@ static mc_status gemm_fp8_rows(mc_engine* e, const bf16_t* A, long lda, int M, i
 
 // l / em / x: the block's weights, its 6 modulation vectors and the residual stream it works on (the main stream
 // "x", or the VACE control stream "xc")
+// em2 / sel: the second modulation set (em + one "emod" set) and the per-token selector when per-token timesteps are on
+static const float* second_set(const mc_engine* e, const float* em) {
+  return e->tok_t ? em + (size_t)(e->NL + e->NV) * 6 * e->d : nullptr;
+}
+static const uint8_t* tok_sel(const mc_engine* e) { return e->tok_t ? e->buf<uint8_t>("tok_sel") : nullptr; }
+
 static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float* x, hipStream_t s) {
   const int d = e->d, Lp = e->Lp;
   bf16_t* xn = e->buf<bf16_t>("xn");
   bf16_t* qkv = e->buf<bf16_t>("qkv");
-  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + d, em, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s));
+  const float* em2 = second_set(e, em);
+  const uint8_t* sel = tok_sel(e);
+  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + d, em, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s,
+                                 em2 ? em2 + d : nullptr, em2, sel));
   if (e->P == 1) {
     mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
@@ -747,6 +772,8 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
   bf16_t* qkv = e->buf<bf16_t>("qkv");
   bf16_t* ao = e->buf<bf16_t>("ao");
   const float scale = 1.0f / std::sqrt(128.0f);
+  const float* em2 = second_set(e, em);
+  const uint8_t* sel = tok_sel(e);
 
   // ---- self attention over the full sequence
   {
@@ -781,6 +808,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
   {  // x = x + o(attn) * e[2]
     mc::GemmParams p = gp(ao, d, l.wo, d, l.bo, Lp, d, d);
     p.X = x; p.ldx = d; p.gate = em + 2 * d;
+    if (em2) { p.gate2 = em2 + 2 * d; p.gate_sel = sel; }
     HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_RESID_GATE, s));
   }
   // ---- cross attention: x = x + o(attn(norm_q(q(norm3(x))), norm_k(k(ctx)), v(ctx)))
@@ -821,7 +849,8 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
   }
   // ---- FFN: x = x + ffn(LN(x)*(1+e[4])+e[3]) * e[5]
-  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + 4 * d, em + 3 * d, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s));
+  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + 4 * d, em + 3 * d, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s,
+                                 em2 ? em2 + 4 * d : nullptr, em2 ? em2 + 3 * d : nullptr, sel));
   bf16_t* h = e->buf<bf16_t>("h");
   {
     mc::GemmParams p = gp(xn, d, l.w1, d, l.b1, Lp, ffn, d);
@@ -834,6 +863,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     }
     mc::GemmParams q = gp(h, ffn, l.w2, ffn, l.b2, Lp, d, ffn);
     q.X = x; q.ldx = d; q.gate = em + 5 * d;
+    if (em2) { q.gate2 = em2 + 5 * d; q.gate_sel = sel; }
     const bool f8 = l.q_w2 != nullptr;
     auto ffn2 = [&](int epi) -> mc_status {
       if (f8) return gemm_fp8_rows(e, h, ffn, Lp, ffn, l.q_w2, l.s_w2, q, epi, s);
@@ -963,17 +993,19 @@ mc_status mc_head(mc_engine* e, int branch, mc_mode mode, mc_stream stream_) {
   if (branch < 0 || branch >= e->cfg.n_branches) return fail(MC_EINVAL, "branch %d out of range", branch);
   const int d = e->d;
   const float* eh = e->buf<float>("ehead");
+  const float* eh2 = e->tok_t ? eh + 2 * d : nullptr;
+  const uint8_t* sel = tok_sel(e);
   float* hn = e->buf<float>("h");
   if (mode == MC_MODE_SKIP) {
     // skipped step: x = ori_x + residual_cache[branch] (:294-295), folded into the LayerNorm load
     if (!e->have_res[branch]) return fail(MC_ESTATE, "skip requested but residual_cache[%d] is empty", branch);
     HIP_TRY(mc::launch_ln_modulate(e->residual(e->res_slot[branch]), d, e->buf<bf16_t>("x0"), d, eh + d, eh, 0,
-                                   e->cfg.eps, nullptr, 0, hn, d, e->Lr, d, s));
+                                   e->cfg.eps, nullptr, 0, hn, d, e->Lr, d, s, eh2 ? eh2 + d : nullptr, eh2, sel));
   } else {
     HIP_TRY(mc::launch_ln_modulate(e->buf<float>("x"), d, nullptr, 0, eh + d, eh, 0, e->cfg.eps, nullptr, 0, hn, d,
-                                   e->Lr, d, s));
+                                   e->Lr, d, s, eh2 ? eh2 + d : nullptr, eh2, sel));
   }
-  HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, e->buf<float>("head_tokens"), 64, e->Lr,
+  HIP_TRY(mc::launch_head_linear(hn, d, e->w_head, e->b_head, e->buf<float>("head_tokens"), e->HT, e->Lr,
                                  e->cfg.out_dim * 4, d, s));
   return MC_OK;
 }
@@ -983,7 +1015,7 @@ mc_status mc_unpatchify(mc_engine* e, const float* tokens_dev, int tok0, int n_t
   if (!e || !tokens_dev || !out_dev) return fail(MC_EINVAL, "null argument");
   if (tok0 < 0 || n_tok <= 0 || tok0 + n_tok > e->L) return fail(MC_EINVAL, "token range out of bounds");
   const mc_config& c = e->cfg;
-  HIP_TRY(mc::launch_unpatchify(tokens_dev, 64, c.out_dim, c.latent_f, c.latent_h, c.latent_w, tok0, n_tok, out_dev,
+  HIP_TRY(mc::launch_unpatchify(tokens_dev, e->HT, c.out_dim, c.latent_f, c.latent_h, c.latent_w, tok0, n_tok, out_dev,
                                 (hipStream_t)stream_));
   return MC_OK;
 }
@@ -1041,6 +1073,13 @@ mc_status mc_import_residual(mc_engine* e, int branch, const float* src_dev, mc_
     HIP_TRY(hipMemcpyAsync(dst, src_dev, (size_t)e->Lr * e->d * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
   e->have_res[branch] = true;
+  return MC_OK;
+}
+
+mc_status mc_set_token_timesteps(mc_engine* e, const float* t_tokens_dev, mc_stream) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (t_tokens_dev && e->NV > 0) return fail(MC_EINVAL, "per-token timesteps are not defined for the VACE model");
+  e->tok_t = t_tokens_dev;
   return MC_OK;
 }
 
@@ -1222,7 +1261,7 @@ mc_status mc_set_option(const char* key, int value) {
   } else if (k == "attn_kernel") {
 #ifndef MC_AB_KERNELS
     if (value != 0 && value != 3 && value != 4)
-      return fail(MC_EINVAL, "attn_kernel must be 0 / 4 (16x16x32 MFMA kernel) or 3 (32x32x16 kernel)");
+      return fail(MC_EINVAL, "attn_kernel must be 0 / 3 (32x32x16 MFMA kernel) or 4 (16x16x32 kernel)");
 #endif
     if (value < 0 || value > 4) return fail(MC_EINVAL, "attn_kernel must be 0..4");
     mc::g_attn_kernel = value;

@@ -45,7 +45,7 @@ __device__ __forceinline__ void gemm_epilogue_quad(const GemmParams& p, int m, i
     *(u32x2*)(p.Cb + (size_t)m * p.ldc + n) = o;
   } else if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
     f32x4 gt = {1.f, 1.f, 1.f, 1.f};
-    if (p.gate) gt = *(const f32x4*)(p.gate + n);
+    if (p.gate) gt = *(const f32x4*)(((p.gate_sel && p.gate_sel[m]) ? p.gate2 : p.gate) + n);
     float* xp = p.X + (size_t)m * p.ldx + n;
     f32x4 xv = *(const f32x4*)xp;
 #pragma unroll

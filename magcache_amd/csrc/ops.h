@@ -33,6 +33,9 @@ struct GemmParams {
   float* R; long ldr;
   bf16_t* X0out; long ldx0out;
   int m_valid;  // EPI_EMBED: rows >= m_valid are written as zeros (sequence padding)
+  // per-token modulation (Wan2.2 TI2V: two timestep values per forward): rows with gate_sel[m] != 0 use gate2
+  const float* gate2;
+  const uint8_t* gate_sel;
   // fp8 GEMM (launch_gemm_fp8): A / W point to OCP e4m3 bytes, C = (A W^T) * a_scale[m] * w_scale[n] + bias
   const float* a_scale;
   const float* w_scale;
@@ -77,16 +80,22 @@ hipError_t launch_attention_v4(const AttnParams& p, hipStream_t stream);  // 8 w
 hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream);  // the same pipeline on 32x32x16 (round 1)
 hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)
 hipError_t launch_attention_v2(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)
-extern int g_attn_kernel;  // 0 / 4: attention_v4.hip, 3: attention_v3.hip (1, 2: A/B library only)
+extern int g_attn_kernel;  // 0 / 3: attention_v3.hip, 4: attention_v4.hip (1, 2: A/B library only)
 
 // ---------------------------------------------------------------- token-wise ops (elementwise.hip)
 // out[m,:] = bf16( LN(x[m,:]) * a + b ),  a = 1+scale (modulate) or weight (affine)
 //   mode 0: a = 1 + sc[d], b = sh[d]      (AdaLN modulate; sc/sh fp32 vectors)
 //   mode 1: a = sc[d],     b = sh[d]      (affine LayerNorm: weight / bias)
 // If x0 != null the row is x0[m,:] (bf16) + x[m,:] (fp32): the fused MagCache skip path.
+// sel != null: rows with sel[m] != 0 take (sc2, sh2) instead of (sc, sh) -- per-token modulation (Wan2.2 TI2V)
 hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long ldx0, const float* sc,
                               const float* sh, int mode, float eps, bf16_t* out, long ldo, float* out_f32,
-                              long ldof, int M, int D, hipStream_t stream);
+                              long ldof, int M, int D, hipStream_t stream, const float* sc2 = nullptr,
+                              const float* sh2 = nullptr, const uint8_t* sel = nullptr);
+// Wan2.2 TI2V per-token timesteps (at most two distinct values per forward): t2[0] = max, t2[1] = min of t[0, n_all);
+// sel[i] = 1 where t[row0 + i] == min and min != max (rows >= n_rows: 0); t2[2] = number of tokens that are neither
+hipError_t launch_token_t_prepare(const float* t, int n_all, int row0, int n_rows, int n_rows_pad, float* t2, uint8_t* sel,
+                                  hipStream_t stream);
 
 // in-place RMSNorm over D (all heads) + optional 3-D RoPE on bf16 rows.
 //   y = bf16(x * rsqrt(mean(x^2)+eps)) * w ; rope pairs (2i,2i+1) with cs[token][64] (cos,sin)
@@ -127,7 +136,7 @@ hipError_t launch_cast_pad_bf16(const float* src, long lds, int rows_valid, int 
 hipError_t launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
 // a[i] = bf16(float(a[i]) + float(b[i]))   (sum of two attention outputs, Wan I2V cross-attention)
 hipError_t launch_add_bf16(bf16_t* a, const bf16_t* b, size_t n, hipStream_t stream);
-// head: out[m, n] = dot(xn[m,:], W[n,:]) + b[n], fp32, N small (<= 64)
+// head: out[m, n] = dot(xn[m,:], W[n,:]) + b[n], fp32, N <= 256 (64 columns per block)
 hipError_t launch_head_linear(const float* xn, long ldx, const float* W, const float* b, float* out, long ldo,
                               int M, int N, int K, hipStream_t stream);
 // sampler: eps = u + g (c - u);  x = x + dt * eps  (flow-matching Euler step)
