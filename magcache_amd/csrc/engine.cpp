@@ -220,7 +220,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     return fail(MC_EINVAL, "latent grid %dx%dx%d not divisible by patch (1,2,2)", c.latent_f, c.latent_h, c.latent_w);
   if (c.sp_size < 1 || c.sp_rank < 0 || c.sp_rank >= c.sp_size) return fail(MC_EINVAL, "bad sp rank/size");
   if (c.n_branches != 1 && c.n_branches != 2) return fail(MC_EINVAL, "n_branches must be 1 or 2");
-  if (c.out_dim * 4 > 64) return fail(MC_EINVAL, "out_dim*4 > 64 unsupported by the head kernel");
+  if (c.out_dim * 4 > 256) return fail(MC_EINVAL, "out_dim*4 > 256 unsupported by the head kernel");
   if (c.clip_dim < 0 || (c.clip_dim % 256) != 0) return fail(MC_EINVAL, "clip_dim %d must be 0 or a multiple of 256", c.clip_dim);
   if (c.vace_layers < 0 || (c.vace_layers > 0 && (c.vace_stride <= 0 || c.vace_in_dim <= 0 ||
                                                    (c.vace_layers - 1) * c.vace_stride >= c.num_layers)))

@@ -126,6 +126,8 @@ class Engine:
         self.ws.zero_()
         check(self.lib.mc_set_workspace(self.h, _ptr(self.ws), nbytes))
         self.tokens_per_rank = self.seq_len // sp_size
+        self.head_stride = (4 * cfg["out_dim"] + 63) // 64 * 64    # row stride of "head_tokens" (fp32 elements)
+        self._tok_t = None
 
     def __del__(self):
         try:
@@ -179,6 +181,24 @@ class Engine:
         c = clip_fea.detach().to(self.device, torch.float32).reshape(-1, clip_fea.shape[-1]).contiguous()
         check(self.lib.mc_set_clip_fea(self.h, _ptr(c), MC_F32, c.shape[0], _stream()))
         torch.cuda.current_stream().synchronize()
+
+    def set_token_timesteps(self, t_tokens):
+        """Wan2.2 TI2V: per-token timesteps for the following forwards (fp32 [seq_len], at most two distinct values
+        -- the conditioning frame's tokens carry t = 0), or None for the scalar t of forward()."""
+        if t_tokens is None:
+            if self._tok_t is not None:
+                check(self.lib.mc_set_token_timesteps(self.h, C.c_void_p(0), _stream()))
+                self._tok_t = None
+            return
+        t = t_tokens.detach().reshape(-1).to(self.device, torch.float32).contiguous()
+        assert t.numel() >= self.seq_len, f"per-token timesteps: {t.numel()} < seq_len {self.seq_len}"
+        check(self.lib.mc_set_token_timesteps(self.h, _ptr(t), _stream()))
+        self._tok_t = t               # the engine reads it during the forward: keep it alive
+
+    def token_timestep_record(self):
+        """(max t, min t, number of tokens carrying neither) found by the last per-token forward (device sync)"""
+        r = self.buffer("tok_t2", torch.float32)[:3].cpu()
+        return float(r[0]), float(r[1]), int(r[2])
 
     def profile(self, on=True):
         """bracket every self-attention launch with hipEvents on the launch stream (see mc_profile_read)"""

@@ -35,14 +35,15 @@ import time
 
 # upstream wan/configs: SIZE_CONFIGS / SUPPORTED_SIZES for the tasks this engine implements
 SIZE_CONFIGS = {"720*1280": (720, 1280), "1280*720": (1280, 720), "480*832": (480, 832), "832*480": (832, 480),
-                "1024*1024": (1024, 1024)}
+                "1024*1024": (1024, 1024), "704*1280": (704, 1280), "1280*704": (1280, 704)}
 SUPPORTED_SIZES = {"t2v-14B": ("720*1280", "1280*720", "480*832", "832*480"), "t2v-1.3B": ("480*832", "832*480"),
                    "t2i-14B": tuple(SIZE_CONFIGS.keys()),
                    "i2v-14B": ("720*1280", "1280*720", "480*832", "832*480"),
                    "vace-1.3B": ("480*832", "832*480"), "vace-14B": ("720*1280", "1280*720", "480*832", "832*480"),
-                   # Wan2.2 two-expert models (MagCache4Wan2.2/magcache_generate.py); ti2v-5B is not implemented
+                   # Wan2.2 (MagCache4Wan2.2/magcache_generate.py): the two-expert A14B models and the dense TI2V-5B
                    "t2v-A14B": ("720*1280", "1280*720", "480*832", "832*480"),
-                   "i2v-A14B": ("720*1280", "1280*720", "480*832", "832*480")}
+                   "i2v-A14B": ("720*1280", "1280*720", "480*832", "832*480"),
+                   "ti2v-5B": ("704*1280", "1280*704")}
 EXAMPLE_PROMPT = "Two anthropomorphic cats in comfy boxing gear and bright gloves fight intensely on a spotlighted stage."
 
 
@@ -59,14 +60,18 @@ def str2bool(v):
 def _validate_args(args):
     """magcache_generate.py:563-595"""
     assert args.task in SUPPORTED_SIZES, f"Unsupport task: {args.task} (this engine: {', '.join(SUPPORTED_SIZES)})"
-    if args.task.endswith("A14B"):
+    if args.task.endswith("A14B") or args.task == "ti2v-5B":
         # MagCache4Wan2.2/magcache_generate.py:409-419: the defaults come from the task's upstream config
         from magcache_amd.wan22 import WAN22_DEFAULTS
         d = WAN22_DEFAULTS[args.task]
         args.sample_steps = d["sample_steps"] if args.sample_steps is None else args.sample_steps
         args.sample_shift = d["sample_shift"] if args.sample_shift is None else args.sample_shift
         g = args.sample_guide_scale
-        args.sample_guide_scale = d["guide_scale"] if g is None else (g, g)     # (low-noise, high-noise expert)
+        if args.task == "ti2v-5B":
+            args.sample_guide_scale = d["guide_scale"] if g is None else g
+            args.frame_num = d["frame_num"] if args.frame_num is None else args.frame_num
+        else:
+            args.sample_guide_scale = d["guide_scale"] if g is None else (g, g)     # (low-noise, high-noise expert)
     if args.sample_guide_scale is None:
         args.sample_guide_scale = 5.0
     if args.sample_steps is None:
@@ -167,6 +172,8 @@ def generate(args):
 
     if args.task.endswith("A14B"):
         return _generate_wan22(args, device, rank, world, layout)
+    if args.task == "ti2v-5B":
+        return _generate_ti2v(args, device, rank, world, layout)
     is_i2v, is_vace = "i2v" in args.task, "vace" in args.task
     if is_i2v:
         cfg = WAN_I2V_14B
@@ -244,6 +251,61 @@ def generate(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return latent
+
+
+def _generate_ti2v(args, device, rank, world, layout):
+    """--task ti2v-5B: MagCache4Wan2.2/magcache_generate.py:719-745 -- one dense 5B model on the 48-channel latent of the
+    Wan2.2 VAE (stride 4 x 16 x 16).  Text-to-video by default; --y_file (torch tensor [48, 1, H/16, W/16]: the VAE latent
+    of the conditioning image, which the absent VAE would produce from --image) switches to image-to-video, where the
+    first latent frame is re-imposed every step and its tokens carry timestep 0 (per-token timesteps).  The reference
+    picks the mag_ratios table by the same condition (:735-738)."""
+    import torch
+    import torch.distributed as dist
+    from magcache_amd import model as M
+    from magcache_amd import wan22
+    from magcache_amd.engine import synthetic_weights
+    assert world == 1, "ti2v-5B runs on one GPU in this repository"
+    cfg = wan22.WAN22_TI2V_5B
+    H, W = SIZE_CONFIGS[args.size][1], SIZE_CONFIGS[args.size][0]
+    grid = ((args.frame_num - 1) // 4 + 1, H // 16, W // 16)
+    logging.info(f"Generation job args: {args}")
+    cls = type("WanModelHIP_TI2V", (M.WanModelHIP,), {})
+    model = cls(cfg, grid, device=device, calibration=args.magcache_calibration)
+    files = sorted(glob.glob(os.path.join(args.ckpt_dir or "", "*.safetensors")))
+    if files:
+        from safetensors.torch import load_file
+        sd = {}
+        for f in files:
+            sd.update(load_file(f, device="cpu"))
+        model.load_state_dict(sd)
+    else:
+        logging.warning("no *.safetensors under --ckpt_dir: seeded RANDOM-INIT weights of the architecture")
+        model.engine.load_weights(synthetic_weights(cfg, seed=0, device=device))
+    i2v = args.y_file is not None
+    if args.use_magcache:
+        table = wan22.table_without_pad("wan2.2_ti2v_5B_i2v" if i2v else "wan2.2_ti2v_5B_t2v")     # :735-738
+        wan22.init_magcache(model, table, args.sample_steps, args.magcache_thresh, args.magcache_K, args.retention_ratio,
+                            split_steps=None, mode="t2v")                                             # :739
+    if args.magcache_calibration:
+        wan22.init_magcache_calibration(model, args.sample_steps)                                    # :742
+    prompt = args.prompt or EXAMPLE_PROMPT
+    ctx = _context(args.context_file, prompt, args.base_seed, cfg["text_dim"], device)
+    ctx_null = _context(args.context_null_file, "", args.base_seed + 1, cfg["text_dim"], device)
+    g = torch.Generator(device=device).manual_seed(args.base_seed)
+    noise = torch.randn(cfg["in_dim"], *grid, dtype=torch.float32, device=device, generator=g)
+    z = torch.load(args.y_file, map_location="cpu").float().to(device) if i2v else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    latent = wan22.sample_ti2v(model, noise, ctx, ctx_null, sampling_steps=args.sample_steps, shift=args.sample_shift,
+                               guide_scale=args.sample_guide_scale, z_first=z, solver=args.sample_solver,
+                               sigma_grid="upstream")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    logging.info(f"denoising: {dt:.2f} s, {args.sample_steps / dt:.3f} steps/s")
+    out = args.save_file or f"{args.task}_{args.size.replace('*', 'x')}_{args.base_seed}_latent.pt"
+    torch.save(latent.cpu(), out)
+    logging.info(f"Saving the final latent to {out} (no VAE decoder in this repository)")
     return latent
 
 

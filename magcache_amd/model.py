@@ -129,6 +129,14 @@ class WanModelHIP:
             if self._clip_key is None or not _same_tensor(self._clip_key, clip_fea):
                 self.engine.set_clip_fea(clip_fea)
                 self._clip_key = _tensor_key(clip_fea)
+        if torch.is_tensor(t) and t.numel() > 1:
+            # Wan2.2: t [B, seq_len] = per-token timesteps (MagCache4Wan2.2/magcache_generate.py:259-270; TI2V passes
+            # t * mask).  The engine takes them as a device vector and selects between two modulation sets per token.
+            assert t.shape[0] == 1 or t.dim() == 1, "one sample per call"
+            self.engine.set_token_timesteps(t.reshape(-1)[:self.engine.seq_len])
+            t = t.reshape(-1)[-1:]
+        elif hasattr(self.engine, "set_token_timesteps"):
+            self.engine.set_token_timesteps(None)
         t = t if not torch.is_tensor(t) else t.to(self.device)
         ctx = context[0].to(self.device)
         if self.engine.sp_size > 1:

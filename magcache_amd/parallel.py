@@ -100,7 +100,8 @@ class SequenceParallelForward:
         self.L = engine.seq_len
         self.Lr = self.L // self.P
         self.kv = engine.buffer("kv_gather", torch.bfloat16).view(self.P, -1, 2 * self.d)   # [P, Lp, 2d]
-        self.tokens_full = torch.empty(self.L, 64, dtype=torch.float32, device=self.kv.device)
+        self.HT = getattr(engine, "head_stride", 64)
+        self.tokens_full = torch.empty(self.L, self.HT, dtype=torch.float32, device=self.kv.device)
 
     def _all_gather_kv(self):
         """Start the K/V all-gather; returns a work handle to wait on (None: already complete)."""
@@ -143,7 +144,7 @@ class SequenceParallelForward:
                     dist.all_reduce(sums, group=self.group)
                     e.calib_finalize(branch)
         e.head(branch, mode)
-        local = e.buffer("head_tokens", torch.float32).view(-1, 64)[:self.Lr]
+        local = e.buffer("head_tokens", torch.float32).view(-1, self.HT)[:self.Lr]
         if self.inplace:
             dist.all_gather_into_tensor(self.tokens_full.view(-1), local.reshape(-1), group=self.group)
         else:

@@ -28,8 +28,12 @@ from .model import WanModelHIP, nearest_interp
 # upstream wan/configs/wan_t2v_A14B.py / wan_i2v_A14B.py [UPSTREAM, not in the reference tree]
 WAN22_T2V_A14B = dict(WAN_T2V_14B)
 WAN22_I2V_A14B = dict(WAN_T2V_14B, in_dim=36)
+# upstream wan/configs/wan_ti2v_5B.py: one dense model, 48-channel latent of the Wan2.2 VAE (stride 4 x 16 x 16)
+WAN22_TI2V_5B = dict(dim=3072, ffn_dim=14336, freq_dim=256, num_heads=24, num_layers=30, text_len=512, in_dim=48,
+                     out_dim=48, text_dim=4096, eps=1e-6)
 WAN22_DEFAULTS = {"t2v-A14B": dict(boundary=0.875, sample_steps=40, sample_shift=12.0, guide_scale=(3.0, 4.0)),
-                  "i2v-A14B": dict(boundary=0.900, sample_steps=40, sample_shift=5.0, guide_scale=(3.5, 3.5))}
+                  "i2v-A14B": dict(boundary=0.900, sample_steps=40, sample_shift=5.0, guide_scale=(3.5, 3.5)),
+                  "ti2v-5B": dict(boundary=None, sample_steps=50, sample_shift=5.0, guide_scale=5.0, frame_num=121)}
 
 
 def get_timesteps(shift, num_inference_steps, num_train_timesteps=1000, sigma_max=1.0, sigma_min=0.01):
@@ -249,4 +253,39 @@ def sample(high, low, noise, context, context_null, boundary, sampling_steps=40,
             eps_u = model([latent], t=t_dev[i:i + 1], context=[context_null], seq_len=seq_len, **kw)[0]
         v = lincomb_hip([1.0 - g, g], [eps_u.contiguous(), eps_c.contiguous()])
         latent = fs.step(i, latent, v)
+    return latent
+
+
+def sample_ti2v(model, noise, context, context_null, sampling_steps=50, shift=5.0, guide_scale=5.0, z_first=None,
+                seq_len=None, solver="unipc", lincomb=None, sigma_grid="reference"):
+    """The TI2V-5B denoising loop (upstream wan/textimage2video.py; reference patch site
+    MagCache4Wan2.2/magcache_generate.py:719-745).  Text-to-video: one scalar timestep per call.  Image-to-video
+    (z_first = the image's latent [48, 1, H, W]): the first latent frame is the conditioning frame -- it is re-imposed
+    on the latent before every model call and after the last step, and its tokens carry timestep 0, i.e. the model
+    receives per-token timesteps t * mask ([1, seq_len]; the Wan2.2 wrapper builds e / e0 per token, :259-270)."""
+    from .sampler import FlowSolver, flow_timesteps, lincomb_hip
+    lc = lincomb or lincomb_hip
+    sig, ts = flow_timesteps(sampling_steps, shift, sigma_grid=sigma_grid)
+    device = noise.device
+    latent = noise.clone().float().contiguous()
+    seq_len = seq_len or model.engine.seq_len
+    fs = FlowSolver(sig, solver, lincomb=lc)
+    mask_tok = None
+    if z_first is not None:
+        F_, H_, W_ = latent.shape[1:]
+        mask_lat = torch.ones(1, F_, H_, W_, device=device)
+        mask_lat[:, 0] = 0.0                                           # upstream masks_like(..., zero=True): frame 0
+        z = torch.zeros_like(latent)
+        z[:, :1] = z_first.to(device).float()
+        mask_tok = mask_lat[0][:, ::2, ::2].reshape(1, -1)             # one value per (1, 2, 2) patch = per token
+        latent = (1.0 - mask_lat) * z + mask_lat * latent
+    for i in range(sampling_steps):
+        t = torch.tensor([float(ts[i])], device=device)
+        tt = t if mask_tok is None else mask_tok * t                   # [1, seq_len]: 0 on the conditioning frame
+        eps_c = model([latent], t=tt, context=[context], seq_len=seq_len)[0]
+        eps_u = model([latent], t=tt, context=[context_null], seq_len=seq_len)[0]
+        v = lc([1.0 - guide_scale, guide_scale], [eps_u.contiguous(), eps_c.contiguous()])
+        latent = fs.step(i, latent, v)
+        if mask_tok is not None:
+            latent = (1.0 - mask_lat) * z + mask_lat * latent
     return latent

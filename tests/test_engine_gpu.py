@@ -594,3 +594,59 @@ def test_sequence_parallel_overlap_is_deterministic_in_process():
     e1.head(0, MC_MODE_FULL)
     one = e1.buffer("head_tokens", torch.float32).view(-1, 64)[:L]
     assert rel_l2(ref, one) < 3e-3
+
+
+def test_wan22_ti2v_per_token_timesteps_vs_reference_golden(golden_dir):
+    """Wan2.2 TI2V-5B path: t [1, seq_len] with t = 0 on the conditioning frame's tokens.  The golden is the
+    reference's own Wan2.2 magcache_forward run around the per-token oracle (oracle/gen_golden_wan22.py, fp32); the
+    engine selects between the two modulation sets per token.  Geometry with the 48-channel latent of the Wan2.2 VAE
+    (patch-embed K = 192, head N = 192).  Checks: (i) same FULL / SKIP sequence as the reference run, every call within
+    3e-2, (ii) engine error vs the fp32 oracle not above twice the oracle's own bf16-autocast error, (iii) the device
+    record says the timesteps held exactly two values, (iv) a scalar t equals uniform per-token t bit for bit."""
+    from magcache_amd import wan22
+    from oracle import wan22_dit_ref as W22
+    g = np.load(os.path.join(golden_dir, "wan22_ti2v_forward_golden.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg, grid = meta["cfg"], (meta["F"], meta["H"], meta["W"])
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    oracle = W22.init_synthetic_(W22.WanModel22(**cfg), seed=meta["weight_seed"], std=meta["weight_std"]).eval()
+    cls = type("WanModelHIP_TI2V_UnderTest", (M.WanModelHIP,), {})
+    m = cls(cfg, grid, device=DEV, calibration=False)
+    m.load_state_dict(oracle.state_dict())
+    lat, ctx, ctxn = (torch.from_numpy(g[k]).to(DEV) for k in ("latent0", "ctx", "ctx_null"))
+    mask = torch.from_numpy(g["mask"]).to(DEV)
+    ts, sig = g["timesteps"], g["sigmas"]
+    # (ii) one plain forward against the fp32 oracle and its autocast mode
+    t0 = (mask * float(ts[0])).unsqueeze(0)
+    got = m([lat], t=t0, context=[ctx], seq_len=L)[0]
+    ref32 = oracle.forward([lat.cpu()], t0.cpu(), [ctx.cpu()], L, autocast=False)[0]
+    refbf = oracle.forward([lat.cpu()], t0.cpu(), [ctx.cpu()], L, autocast=True)[0]
+    e_hip, e_bf = rel_l2(got.cpu(), ref32), rel_l2(refbf, ref32)
+    assert e_hip < 2 * e_bf + 1e-3 and e_hip < 2e-2, (e_hip, e_bf)
+    assert m.engine.token_timestep_record() == (float(ts[0]), 0.0, 0)                     # (iii)
+    # (iv) scalar t == uniform per-token t
+    a = m([lat], t=torch.tensor([float(ts[2])], device=DEV), context=[ctx], seq_len=L)[0].clone()
+    b = m([lat], t=torch.full((1, L), float(ts[2]), device=DEV), context=[ctx], seq_len=L)[0]
+    assert torch.equal(a, b)
+    assert rel_l2(a.cpu(), torch.from_numpy(g["uniform_t_out"])) < 2e-2
+    # (i) the MagCache loop of the reference's TI2V patch (split_step None: the branch its own init cannot reach)
+    wan22.init_magcache(m, wan22.table_without_pad(meta["table"]), meta["steps"], meta["thresh"], meta["K"], meta["R"],
+                        split_steps=None, mode="t2v")
+    modes, errs = [], []
+    run = m._run
+    m._run = lambda x, t, c, branch, mode, **kw: (modes.append(mode), run(x, t, c, branch, mode, **kw))[1]
+    x = lat.clone()
+    try:
+        for i in range(meta["steps"]):
+            t = (mask * float(ts[i])).unsqueeze(0)
+            ec = m([x], t=t, context=[ctx], seq_len=L)[0]
+            eu = m([x], t=t, context=[ctxn], seq_len=L)[0]
+            errs += [rel_l2(ec.cpu(), torch.from_numpy(g["outs"][2 * i])), rel_l2(eu.cpu(), torch.from_numpy(g["outs"][2 * i + 1]))]
+            x = x + float(sig[i + 1] - sig[i]) * (eu + meta["guide"] * (ec - eu))
+    finally:
+        m._run = run
+        cls.forward = M.plain_forward
+    assert [int(mo == MC_MODE_SKIP) for mo in modes] == g["skipped"].tolist()
+    assert int(cls.cnt) == 0
+    assert max(errs) < 3e-2, errs
+    assert MR.psnr(x.cpu().numpy(), g["final_latent"], data_range=float(np.abs(g["final_latent"]).max())) > 35.0

@@ -294,3 +294,35 @@ def test_mmdit_calibration_matches_reference_run(golden_dir, family):
     np.testing.assert_allclose(mc.norm_ratio, want["norm_ratio"], atol=2e-5)
     np.testing.assert_allclose(mc.norm_std, want["norm_std"], atol=2e-5)
     np.testing.assert_allclose(mc.cos_dis, want["cos_dis"], atol=2e-5)
+
+
+def test_wan22_ti2v_oracle_vs_reference_golden(golden_dir):
+    """Per-token timesteps (Wan2.2 TI2V-5B): the golden was produced by the reference's own Wan2.2 magcache_forward
+    (oracle/gen_golden_wan22.py imports MagCache4Wan2.2/magcache_generate.py) around oracle.wan22_dit_ref.WanModel22.
+    Here the oracle's plain forward + the oracle rule must reproduce the calls that ran the blocks, and a scalar
+    timestep must equal uniform per-token timesteps."""
+    import json as _json
+    from oracle import wan22_dit_ref as W22
+    g = np.load(os.path.join(golden_dir, "wan22_ti2v_forward_golden.npz"))
+    meta = _json.loads(str(g["meta"]))
+    cfg = meta["cfg"]
+    model = W22.init_synthetic_(W22.WanModel22(**cfg), seed=meta["weight_seed"], std=meta["weight_std"]).eval()
+    L = meta["F"] * (meta["H"] // 2) * (meta["W"] // 2)
+    lat, ctx, ctx_null = (torch.from_numpy(g[k]) for k in ("latent0", "ctx", "ctx_null"))
+    mask, ts, sig = torch.from_numpy(g["mask"]), g["timesteps"], g["sigmas"]
+    skipped = g["skipped"].tolist()
+    assert skipped[:3] == [0, 0, 0] and sum(skipped) > 0            # retention 0.2 * 16 calls = 3 full calls first
+    # the first step ran both branches through the blocks: the oracle forward must reproduce them exactly
+    t0 = (mask * float(ts[0])).unsqueeze(0)
+    for j, c in enumerate((ctx, ctx_null)):
+        out = model.forward([lat], t0, [c], L, autocast=False)[0]
+        torch.testing.assert_close(out, torch.from_numpy(g["outs"][j]), rtol=1e-5, atol=1e-5)
+    # scalar t == uniform per-token t
+    uni = model.forward([lat], torch.full((1, L), float(ts[2])), [ctx], L, autocast=False)[0]
+    torch.testing.assert_close(uni, torch.from_numpy(g["uniform_t_out"]), rtol=1e-5, atol=1e-5)
+    # the conditioning frame's t = 0 matters
+    assert float((uni - model.forward([lat], (mask * float(ts[2])).unsqueeze(0), [ctx], L, autocast=False)[0]).abs().max()) > 1e-3
+    # the rule variant replays the reference's skip decisions
+    rule = MR.RuleState("wan22_ti2v", meta["steps"] * 2, meta["thresh"], meta["K"], meta["R"],
+                        MR.interp_cfg_table(TABLES[meta["table"]], meta["steps"]))
+    assert [int(rule.step()[0]) for _ in range(2 * meta["steps"])] == skipped
