@@ -393,7 +393,8 @@ def main():
             "nocache_steps_per_s": (args.steps / t_nc) if t_nc else None,
             "speedup_vs_nocache": (t_nc / t_mc) if t_nc else None,
             "psnr_vs_nocache_db": psnr,
-            "lpips_vs_nocache": "unavailable offline (lpips needs AlexNet weights; PSNR/SSIM in magcache_amd.metrics)",
+            "lpips_vs_nocache": "unavailable offline (magcache_amd.metrics.LPIPSAlex needs AlexNet + lpips weights, none ship "
+                                "here; it raises rather than invent a number)",
             "model_tflops_per_s_nocache": (2 * args.steps * fl / t_nc / 1e12 / world) if t_nc else None,
             "model_tflops_per_s_magcache_ran": ran * fl / t_mc / 1e12 / world,
         }

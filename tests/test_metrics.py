@@ -62,3 +62,36 @@ def test_latent_psnr():
     a = np.linspace(-2, 2, 1000)
     assert MT.latent_psnr(a, a) == 100.0
     assert MT.latent_psnr(a + 0.02, a) == pytest.approx(20 * np.log10(2 / 0.02), abs=1e-9)
+
+
+def test_lpips_alexnet_structure_and_properties():
+    """LPIPS (calculate_lpips.py: lpips.LPIPS(net='alex', spatial=True)) restated in magcache_amd.metrics.  No AlexNet /
+    lpips weights exist offline, so the VALUE is unpinned; with random weights in the published shapes the code path
+    must have the metric's defining properties: identical inputs -> 0, symmetric, non-negative (the linear layers are
+    non-negative), a spatial map of the input size, grey-scale videos broadcast to 3 channels, the reference's result
+    dictionary; and without weights it must refuse instead of inventing a number."""
+    import torch
+    from magcache_amd import metrics as MT
+    with pytest.raises(RuntimeError):
+        MT.calculate_lpips(np.zeros((1, 1, 3, 64, 64)), np.zeros((1, 1, 3, 64, 64)))
+    g = torch.Generator().manual_seed(0)
+    alex = {}
+    for idx, (o, i, k, _, _) in MT.LPIPSAlex.CONVS.items():
+        alex[f"features.{idx}.weight"] = torch.randn(o, i, k, k, generator=g) * (2.0 / (i * k * k)) ** 0.5
+        alex[f"features.{idx}.bias"] = torch.randn(o, generator=g) * 0.01
+    lin = {f"lin{n}.model.1.weight": torch.rand(1, c, 1, 1, generator=g) for n, c in enumerate(MT.LPIPSAlex.CHNS)}
+    m = MT.LPIPSAlex(spatial=True).load_state_dicts(alex, lin)
+    a = torch.rand(2, 3, 96, 128, generator=g) * 2 - 1
+    b = torch.rand(2, 3, 96, 128, generator=g) * 2 - 1
+    dab, dba, daa = m.forward(a, b), m.forward(b, a), m.forward(a, a)
+    assert tuple(dab.shape) == (2, 1, 96, 128)
+    assert float(daa.abs().max()) == 0.0
+    torch.testing.assert_close(dab, dba)
+    assert float(dab.min()) >= 0.0 and float(dab.mean()) > 0.0
+    # a small perturbation is closer than an unrelated image
+    assert float(m.forward(a, a + 0.01 * torch.randn(a.shape, generator=g)).mean()) < float(dab.mean())
+    v1, v2 = torch.rand(2, 3, 1, 64, 64, generator=g), torch.rand(2, 3, 1, 64, 64, generator=g)   # grey-scale video
+    res = MT.calculate_lpips(v1, v2, model=m)
+    assert set(res) == {"value", "value_std", "video_setting", "video_setting_name"} and len(res["value"]) == 3
+    assert all(v > 0 for v in res["value"].values())
+    assert MT.calculate_lpips(v1, v1, model=m)["value"][0] == 0.0
