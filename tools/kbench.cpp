@@ -213,32 +213,44 @@ static void bench_gemm(const char* name, int M, int N, int K, int epi, int round
 }
 
 // ------------------------------------------------------------------------------------- attention
-static void bench_attn(const char* name, int Lq_pad, int H, int valid, float q_amp, int rounds, int launches) {
+// strided: q | k | v interleaved in one [Lq_pad, 3D] buffer (the engine's layout, row stride 3D) instead of three
+// contiguous [Lq_pad, D] tensors
+static void bench_attn(const char* name, int Lq_pad, int H, int valid, float q_amp, int rounds, int launches,
+                       bool strided = false) {
   const int D = H * 128;
-  uint16_t *Q, *K, *V, *O, *Oref;
-  CK(hipMalloc(&Q, (size_t)Lq_pad * D * 2));
-  CK(hipMalloc(&K, (size_t)Lq_pad * D * 2));
-  CK(hipMalloc(&V, (size_t)Lq_pad * D * 2));
+  const int LD = strided ? 3 * D : D;
+  uint16_t *Q, *K, *V, *O, *Oref, *QKV = nullptr;
+  if (strided) {
+    CK(hipMalloc(&QKV, (size_t)Lq_pad * 3 * D * 2));
+    fill_bf16<<<2048, 256>>>(QKV, (size_t)Lq_pad * 3 * D, 14, 1.0f * g_amp);
+    Q = QKV; K = QKV + D; V = QKV + 2 * D;
+  } else {
+    CK(hipMalloc(&Q, (size_t)Lq_pad * D * 2));
+    CK(hipMalloc(&K, (size_t)Lq_pad * D * 2));
+    CK(hipMalloc(&V, (size_t)Lq_pad * D * 2));
+  }
   CK(hipMalloc(&O, (size_t)Lq_pad * D * 2));
   CK(hipMalloc(&Oref, (size_t)Lq_pad * D * 2));
   unsigned long long* dcount;
   CK(hipMalloc(&dcount, 8));
-  fill_bf16<<<2048, 256>>>(Q, (size_t)Lq_pad * D, 11, q_amp * g_amp);   // post-RMSNorm q, k: unit variance
-  fill_bf16<<<2048, 256>>>(K, (size_t)Lq_pad * D, 12, 1.0f * g_amp);
-  fill_bf16<<<2048, 256>>>(V, (size_t)Lq_pad * D, 13, 1.0f * g_amp);
+  if (!strided) {
+    fill_bf16<<<2048, 256>>>(Q, (size_t)Lq_pad * D, 11, q_amp * g_amp);   // post-RMSNorm q, k: unit variance
+    fill_bf16<<<2048, 256>>>(K, (size_t)Lq_pad * D, 12, 1.0f * g_amp);
+    fill_bf16<<<2048, 256>>>(V, (size_t)Lq_pad * D, 13, 1.0f * g_amp);
+  }
   CK(hipDeviceSynchronize());
   const float scale = 1.0f / std::sqrt(128.0f);
   auto launch = [&](int l) {
-    MCL(g_libs[l], g_libs[l].attn(Q, D, K, D, 0, V, D, 0, O, D, Lq_pad, H, Lq_pad, valid, 1, scale, nullptr));
+    MCL(g_libs[l], g_libs[l].attn(Q, LD, K, LD, 0, V, LD, 0, O, D, Lq_pad, H, Lq_pad, valid, 1, scale, nullptr));
   };
   char what[64];
   snprintf(what, sizeof(what), "attn_%s", name);
   printf("# %s: Lq_pad=%d heads=%d valid keys=%d q_amp=%.1f\n", what, Lq_pad, H, valid, q_amp);
   measure(what, 4.0 * (double)valid * valid * D, "TF", 1e-12, rounds, launches, launch);
   std::vector<uint16_t> hq((size_t)Lq_pad * D), hk((size_t)Lq_pad * D), hv((size_t)Lq_pad * D), ho((size_t)Lq_pad * D);
-  CK(hipMemcpy(hq.data(), Q, hq.size() * 2, hipMemcpyDeviceToHost));
-  CK(hipMemcpy(hk.data(), K, hk.size() * 2, hipMemcpyDeviceToHost));
-  CK(hipMemcpy(hv.data(), V, hv.size() * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy2D(hq.data(), (size_t)D * 2, Q, (size_t)LD * 2, (size_t)D * 2, Lq_pad, hipMemcpyDeviceToHost));
+  CK(hipMemcpy2D(hk.data(), (size_t)D * 2, K, (size_t)LD * 2, (size_t)D * 2, Lq_pad, hipMemcpyDeviceToHost));
+  CK(hipMemcpy2D(hv.data(), (size_t)D * 2, V, (size_t)LD * 2, (size_t)D * 2, Lq_pad, hipMemcpyDeviceToHost));
   for (size_t l = 0; l < g_libs.size(); ++l) {
     CK(hipMemset(O, 0xff, (size_t)Lq_pad * D * 2));
     launch((int)l);
@@ -285,7 +297,8 @@ static void bench_attn(const char* name, int Lq_pad, int H, int valid, float q_a
     }
   }
   fflush(stdout);
-  CK(hipFree(Q)); CK(hipFree(K)); CK(hipFree(V)); CK(hipFree(O)); CK(hipFree(Oref)); CK(hipFree(dcount));
+  if (strided) { CK(hipFree(QKV)); } else { CK(hipFree(Q)); CK(hipFree(K)); CK(hipFree(V)); }
+  CK(hipFree(O)); CK(hipFree(Oref)); CK(hipFree(dcount));
 }
 
 // ------------------------------------------------------------------------------------- calibration statistics
@@ -361,6 +374,9 @@ int main(int argc, char** argv) {
     bench_attn("self480p", 32768, 12, 32760, 1.0f, rounds, std::max(1, launches / 4));
     bench_attn("self480p_q6", 32768, 12, 32760, 6.0f, rounds, std::max(1, launches / 4));
   }
+  if (what == "attn_strided" || what == "all") bench_attn("self480p_qkv", 32768, 12, 32760, 1.0f, rounds, std::max(1, launches / 4), true);
+  if (what == "attn1") bench_attn("self480p", 32768, 12, 32760, 1.0f, rounds, launches);          // one shape (PMC passes)
+  if (what == "gemm1") bench_gemm("qkv", M, 4608, 1536, 0, rounds, launches);
   if (what == "calib" || what == "all") bench_calib(32760, 1536, rounds, launches * 2);
   return 0;
 }
