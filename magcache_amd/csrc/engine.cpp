@@ -204,6 +204,8 @@ mc_status set_error_v(mc_status s, const char* fmt, va_list ap) {
 }
 }  // namespace mc
 
+extern int g_mmdit_two_streams;   // mmdit_engine.cpp: mc_set_option("mmdit_two_streams", v)
+
 extern "C" {
 
 const char* mc_last_error(void) { return g_err; }
@@ -1265,6 +1267,9 @@ mc_status mc_set_option(const char* key, int value) {
 #endif
     if (value < 0 || value > 4) return fail(MC_EINVAL, "attn_kernel must be 0..4");
     mc::g_attn_kernel = value;
+  } else if (k == "mmdit_two_streams") {
+    if (value != 0 && value != 1) return fail(MC_EINVAL, "mmdit_two_streams must be 0 or 1");
+    g_mmdit_two_streams = value;
   } else {
     return fail(MC_EINVAL, "unknown option '%s'", key);
   }

@@ -40,6 +40,8 @@ namespace mc {
 mc_status set_error_v(mc_status s, const char* fmt, va_list ap);  // engine.cpp
 }
 
+int g_mmdit_two_streams = 0;   // mc_set_option("mmdit_two_streams", v)
+
 namespace {
 
 mc_status fail(mc_status s, const char* fmt, ...) {
@@ -108,6 +110,12 @@ struct mc_mmdit {
   mc_mode mode = MC_MODE_FULL;                               // of the forward in progress (begin .. end)
   int txt_valid = 0, dst = 0, local_attn_blk = -1;
   bool begun = false;
+  // optional second compute stream: the text stream of a double block next to the image stream (mc_set_option
+  // "mmdit_two_streams"); a ring of event pairs so that an event is not re-recorded while an earlier wait on it may
+  // still be queued
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork[8] = {}, ev_join[8] = {};
+  int ev_i = 0;
   size_t mod_rows = 0;  // rows of the fused modulation matrix
   std::vector<Stream> dimg, dtxt;
   std::vector<Single> singles;
@@ -380,6 +388,13 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
 
 void mc_mmdit_destroy(mc_mmdit* e) {
   if (!e) return;
+  if (e->side) {
+    (void)hipStreamDestroy(e->side);
+    for (int i = 0; i < 8; ++i) {
+      (void)hipEventDestroy(e->ev_fork[i]);
+      (void)hipEventDestroy(e->ev_join[i]);
+    }
+  }
   for (void* p : e->owned) (void)hipFree(p);
   delete e;
 }
@@ -603,6 +618,32 @@ mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod,
   return MC_OK;
 }
 
+// Image stream and text stream of a double block touch disjoint rows of every buffer: with "mmdit_two_streams" the text
+// half runs on the engine's side stream between a fork and a join event (capturable: the side stream joins back).
+template <class FI, class FT>
+mc_status run_two(mc_mmdit* e, hipStream_t s, FI&& img_part, FT&& txt_part) {
+  if (!g_mmdit_two_streams) {
+    MC_TRY(img_part(s));
+    return txt_part(s);
+  }
+  if (!e->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+    }
+  }
+  const int i = e->ev_i;
+  e->ev_i = (e->ev_i + 1) & 7;
+  HIP_TRY(hipEventRecord(e->ev_fork[i], s));
+  HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork[i], 0));
+  MC_TRY(img_part(s));
+  MC_TRY(txt_part(e->side));
+  HIP_TRY(hipEventRecord(e->ev_join[i], e->side));
+  HIP_TRY(hipStreamWaitEvent(s, e->ev_join[i], 0));
+  return MC_OK;
+}
+
 }  // namespace
 
 // ================================================================================================ forward, in phases
@@ -692,8 +733,9 @@ mc_status mc_mmdit_block_pre(mc_mmdit* e, int blk, mc_stream stream_) {
   const float* emod = e->buf<float>("emod");
   bf16_t* qkv = e->buf<bf16_t>("qkv");
   if (blk < c.n_double) {
-    MC_TRY(stream_pre_attn(e, e->dimg[blk], emod + e->mod_double(blk, 0), e->img0, Li, s));
-    MC_TRY(stream_pre_attn(e, e->dtxt[blk], emod + e->mod_double(blk, 1), e->txt0, Lt, s));
+    MC_TRY(run_two(
+        e, s, [&](hipStream_t q) { return stream_pre_attn(e, e->dimg[blk], emod + e->mod_double(blk, 0), e->img0, Li, q); },
+        [&](hipStream_t q) { return stream_pre_attn(e, e->dtxt[blk], emod + e->mod_double(blk, 1), e->txt0, Lt, q); }));
   } else {
     const int i = blk - c.n_double;
     const Single& g = e->singles[i];
@@ -795,9 +837,13 @@ mc_status mc_mmdit_block_post(mc_mmdit* e, int blk, mc_stream stream_) {
   }
   const bool last = (blk == nb - 1);
   if (blk < c.n_double) {
-    MC_TRY(stream_post_attn(e, e->dimg[blk], emod + e->mod_double(blk, 0), e->img0, Li, s,
-                            last ? e->residual_joint(e->dst) : nullptr));
-    MC_TRY(stream_post_attn(e, e->dtxt[blk], emod + e->mod_double(blk, 1), e->txt0, Lt, s));
+    MC_TRY(run_two(
+        e, s,
+        [&](hipStream_t q) {
+          return stream_post_attn(e, e->dimg[blk], emod + e->mod_double(blk, 0), e->img0, Li, q,
+                                  last ? e->residual_joint(e->dst) : nullptr);
+        },
+        [&](hipStream_t q) { return stream_post_attn(e, e->dtxt[blk], emod + e->mod_double(blk, 1), e->txt0, Lt, q); }));
   } else {
     const int i = blk - c.n_double;
     const Single& g = e->singles[i];
