@@ -100,13 +100,24 @@ int mc_weights_missing(const mc_engine* e, char* buf, size_t buflen); /* count; 
 /* ---- one DiT evaluation = the body of magcache_forward (:229-305) ------------------------------
  * latent_dev : fp32 [in_dim, F, H, W]
  * t_dev      : fp32 scalar on device, or NULL to use t_host (no device sync either way)
- * context_dev: [ctx_len, text_dim] fp32 or bf16, ctx_len <= text_len (zero padded inside, :257-262)
+ * context_dev: [ctx_len, text_dim] fp32 or bf16, ctx_len <= text_len (zero padded inside, :257-262), or NULL to use
+ *             the cache slot selected by mc_set_context / mc_use_context
  * branch     : residual-cache slot, the reference's cnt % 2
  * out_dev    : fp32 [out_dim, F, H, W]                                                (:312)
  * Only for sp_size == 1; a sharded engine is driven through the phase calls below. */
 mc_status mc_forward(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
                      const void* context_dev, mc_dtype ctx_dtype, int ctx_len, int branch, mc_mode mode,
                      float* out_dev, mc_stream stream);
+
+/* Text-context cache.  The context is constant per CFG branch over a whole video, but the reference recomputes
+ * text_embedding(context) (:256-262) and every block's cross-attention k / v of it (upstream WanT2VCrossAttention) in
+ * every forward.  mc_set_context embeds `context_dev` once and stores norm_k(k(ctx)) | v(ctx) of every block in cache slot
+ * `slot` (0 or 1: one per CFG branch) and selects it; mc_use_context selects a filled slot (-1: none); a forward /
+ * mc_embed called with context_dev == NULL then reads the selected slot.  Passing a context pointer to the forward keeps
+ * the uncached behaviour.  mc_set_weight invalidates both slots. */
+mc_status mc_set_context(mc_engine* e, int slot, const void* context_dev, mc_dtype ctx_dtype, int ctx_len,
+                         mc_stream stream);
+mc_status mc_use_context(mc_engine* e, int slot);
 
 /* Wan2.1 I2V: clip_fea (upstream `clip_fea`, magcache_generate.py:203,264-266) = [n_tokens (257), clip_dim]
  * fp32 or bf16.  Runs img_emb on it and keeps the image-token context for the following forwards. */

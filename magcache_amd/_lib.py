@@ -51,6 +51,8 @@ SIGNATURES = {
     "mc_set_clip_fea": (_i, [_vp, _vp, _i, _i, _vp]),
     "mc_set_vace_context": (_i, [_vp, _vp, _f, _vp]),
     "mc_set_token_timesteps": (_i, [_vp, _vp, _vp]),
+    "mc_set_context": (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    "mc_use_context": (_i, [_vp, _i]),
     "mc_profile_enable": (_i, [_vp, _i]),
     "mc_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
     "mc_embed": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _vp]),

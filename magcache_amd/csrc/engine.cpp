@@ -86,6 +86,10 @@ struct mc_engine {
   int img_rows = 0;     // 257 image tokens padded to a multiple of 64
   bool have_clip = false;
   int local_attn_layer = -1;  // layer whose local-shard attention already ran (two-phase SP attention)
+  // text context cache (mc_set_context): per slot the embedded context and every block's normalised cross-attention
+  // K|V; a forward called with context_dev == NULL reads slot ctx_active instead of recomputing them
+  bool ctx_valid[2] = {false, false};
+  int ctx_active = -1;
   const float* tok_t = nullptr;  // Wan2.2 TI2V: per-token timesteps of the next forwards (mc_set_token_timesteps)
   int HT = 64;                   // row stride of "head_tokens": 4*out_dim rounded up to 64
   // optional in-stream timing of the dominant kernel (self-attention): hipEvent pairs around every launch
@@ -399,6 +403,8 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   add_buf(e, cur, "ctx_h", (size_t)e->ctx_rows * d * 2);
   add_buf(e, cur, "ctx", (size_t)e->ctx_rows * d * 2);
   add_buf(e, cur, "ckv", (size_t)e->ctx_rows * 2 * d * 2);
+  add_buf(e, cur, "ctx_cache", (size_t)2 * e->ctx_rows * d * 2);                              // [2 slots][ctx_rows][d]
+  add_buf(e, cur, "ckv_cache", (size_t)2 * (e->NL + e->NV) * e->ctx_rows * 2 * d * 2);        // [2][layers][ctx_rows][2d]
   // two sets of everything that depends on t: set 0 for the (maximum) timestep, set 1 for the second value per-token
   // timesteps may carry (Wan2.2 TI2V: the conditioning frame's tokens have t = 0)
   add_buf(e, cur, "temb", (size_t)2 * (c.freq_dim + 2 * d + 6 * d) * 4);  // 2 x (sinus | h1 | e | e0)
@@ -484,6 +490,10 @@ mc_status mc_buffer_info(const mc_engine* e, const char* name, size_t* offset, s
 
 mc_status mc_set_weight(mc_engine* e, const char* name, const void* src_dev, mc_dtype dtype, const int64_t* shape,
                         int ndim, mc_stream stream_) {
+  if (e) {  // any cached text context was computed with the old weights
+    e->ctx_valid[0] = e->ctx_valid[1] = false;
+    e->ctx_active = -1;
+  }
   hipStream_t stream = (hipStream_t)stream_;
   if (!e || !name || !src_dev || !shape) return fail(MC_EINVAL, "null argument");
   auto it = e->slots.find(name);
@@ -604,15 +614,47 @@ mc_status mc_set_vace_context(mc_engine* e, const float* vace_dev, float context
 
 // ------------------------------------------------------------------------------------------------
 // embeds: patch embedding, time embedding + projection, text embedding   (reference :236-262)
+// context = text_embedding(zero-padded context) -> dst [ctx_rows, d] bf16   (:256-262)
+static mc_status embed_context(mc_engine* e, const void* context_dev, mc_dtype ctx_dtype, int ctx_len, bf16_t* dst,
+                               hipStream_t s) {
+  const mc_config& c = e->cfg;
+  const int d = e->d;
+  if (ctx_len <= 0 || ctx_len > c.text_len)
+    return fail(MC_EINVAL, "context length %d exceeds text_len %d", ctx_len, c.text_len);
+  bf16_t* ctx_in = e->buf<bf16_t>("ctx_in");
+  if (ctx_dtype == MC_F32) {
+    HIP_TRY(mc::launch_cast_pad_bf16((const float*)context_dev, c.text_dim, ctx_len, e->ctx_rows, c.text_dim, ctx_in,
+                                     c.text_dim, s));
+  } else {
+    HIP_TRY(hipMemsetAsync(ctx_in, 0, (size_t)e->ctx_rows * c.text_dim * 2, s));
+    HIP_TRY(hipMemcpyAsync(ctx_in, context_dev, (size_t)ctx_len * c.text_dim * 2, hipMemcpyDeviceToDevice, s));
+  }
+  mc::GemmParams p = gp(ctx_in, c.text_dim, e->w_text0, c.text_dim, e->b_text0, e->ctx_rows, d, c.text_dim);
+  p.Cb = e->buf<bf16_t>("ctx_h"); p.ldc = d;
+  HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
+  mc::GemmParams q = gp(e->buf<bf16_t>("ctx_h"), d, e->w_text1, d, e->b_text1, e->ctx_rows, d, d);
+  q.Cb = dst; q.ldc = d;
+  HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+  return MC_OK;
+}
+
+// the cross-attention K|V of one block for a context: k = norm_k(k(ctx)), v = v(ctx)  (upstream WanT2VCrossAttention)
+static mc_status context_kv(mc_engine* e, const Layer& l, const bf16_t* ctx, bf16_t* ckv, hipStream_t s) {
+  const int d = e->d;
+  mc::GemmParams q = gp(ctx, d, l.wckv, d, l.bckv, e->ctx_rows, 2 * d, d);
+  q.Cb = ckv; q.ldc = 2 * d;
+  HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+  HIP_TRY(mc::launch_rmsnorm_rope(ckv, 2 * d, l.cnk, e->cfg.eps, nullptr, 0, e->ctx_rows, d, s));
+  return MC_OK;
+}
+
 mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
                    const void* context_dev, mc_dtype ctx_dtype, int ctx_len, mc_stream stream_) {
   hipStream_t s = (hipStream_t)stream_;
   mc_status st = check_ready(e);
   if (st != MC_OK) return st;
-  if (!latent_dev || !context_dev) return fail(MC_EINVAL, "null input");
+  if (!latent_dev) return fail(MC_EINVAL, "null input");
   const mc_config& c = e->cfg;
-  if (ctx_len <= 0 || ctx_len > c.text_len)
-    return fail(MC_EINVAL, "context length %d exceeds text_len %d", ctx_len, c.text_len);
   if (c.clip_dim > 0 && !e->have_clip)
     return fail(MC_ESTATE, "i2v model: mc_set_clip_fea must run before the forward (reference assert :226-227)");
   const int d = e->d;
@@ -653,22 +695,13 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
                                    emod + (size_t)l * 6 * d, 6 * d, s));
     HIP_TRY(mc::launch_add_bcast(ev, d, e->head_mod, e->buf<float>("ehead") + set * 2 * d, 2 * d, s));
   }
-  // context = text_embedding(zero-padded context)   (:256-262)
-  bf16_t* ctx_in = e->buf<bf16_t>("ctx_in");
-  if (ctx_dtype == MC_F32) {
-    HIP_TRY(mc::launch_cast_pad_bf16((const float*)context_dev, c.text_dim, ctx_len, e->ctx_rows, c.text_dim, ctx_in,
-                                     c.text_dim, s));
-  } else {
-    HIP_TRY(hipMemsetAsync(ctx_in, 0, (size_t)e->ctx_rows * c.text_dim * 2, s));
-    HIP_TRY(hipMemcpyAsync(ctx_in, context_dev, (size_t)ctx_len * c.text_dim * 2, hipMemcpyDeviceToDevice, s));
-  }
-  {
-    mc::GemmParams p = gp(ctx_in, c.text_dim, e->w_text0, c.text_dim, e->b_text0, e->ctx_rows, d, c.text_dim);
-    p.Cb = e->buf<bf16_t>("ctx_h"); p.ldc = d;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
-    mc::GemmParams q = gp(e->buf<bf16_t>("ctx_h"), d, e->w_text1, d, e->b_text1, e->ctx_rows, d, d);
-    q.Cb = e->buf<bf16_t>("ctx"); q.ldc = d;
-    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+  // context = text_embedding(zero-padded context)   (:256-262); NULL: the slot selected by mc_set_context / mc_use_context
+  if (context_dev) {
+    e->ctx_active = -1;
+    mc_status cst = embed_context(e, context_dev, ctx_dtype, ctx_len, e->buf<bf16_t>("ctx"), s);
+    if (cst != MC_OK) return cst;
+  } else if (e->ctx_active < 0 || !e->ctx_valid[e->ctx_active]) {
+    return fail(MC_ESTATE, "context_dev is NULL but no cached context is selected (mc_set_context)");
   }
   e->embedded = true;
   return MC_OK;
@@ -822,10 +855,14 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     p.Cb = cq; p.ldc = d;
     HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
     HIP_TRY(mc::launch_rmsnorm_rope(cq, d, l.cnq, e->cfg.eps, nullptr, 0, Lp, d, s));
-    mc::GemmParams q = gp(e->buf<bf16_t>("ctx"), d, l.wckv, d, l.bckv, e->ctx_rows, 2 * d, d);
-    q.Cb = ckv; q.ldc = 2 * d;
-    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
-    HIP_TRY(mc::launch_rmsnorm_rope(ckv, 2 * d, l.cnk, e->cfg.eps, nullptr, 0, e->ctx_rows, d, s));
+    if (e->ctx_active >= 0) {
+      // constant over a video for this context: computed once by mc_set_context
+      const size_t li = (size_t)(&l - (layer >= 0 ? e->layers.data() : e->vlayers.data())) + (layer >= 0 ? 0 : e->NL);
+      ckv = e->buf<bf16_t>("ckv_cache") + ((size_t)e->ctx_active * (e->NL + e->NV) + li) * e->ctx_rows * 2 * d;
+    } else {
+      mc_status kst = context_kv(e, l, e->buf<bf16_t>("ctx"), ckv, s);
+      if (kst != MC_OK) return kst;
+    }
     mc::AttnParams a;
     memset(&a, 0, sizeof(a));
     a.Q = cq; a.ldq = d; a.K = ckv; a.ldk = 2 * d; a.V = ckv + d; a.ldv = 2 * d;
@@ -1075,6 +1112,36 @@ mc_status mc_import_residual(mc_engine* e, int branch, const float* src_dev, mc_
     HIP_TRY(hipMemcpyAsync(dst, src_dev, (size_t)e->Lr * e->d * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
   e->have_res[branch] = true;
+  return MC_OK;
+}
+
+mc_status mc_set_context(mc_engine* e, int slot, const void* context_dev, mc_dtype ctx_dtype, int ctx_len,
+                         mc_stream stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  mc_status st = check_ready(e);
+  if (st != MC_OK) return st;
+  if (slot < 0 || slot > 1) return fail(MC_EINVAL, "context slot %d out of range (0, 1)", slot);
+  if (!context_dev) return fail(MC_EINVAL, "null context");
+  const int d = e->d;
+  bf16_t* ctx = e->buf<bf16_t>("ctx_cache") + (size_t)slot * e->ctx_rows * d;
+  e->ctx_valid[slot] = false;
+  st = embed_context(e, context_dev, ctx_dtype, ctx_len, ctx, s);
+  if (st != MC_OK) return st;
+  bf16_t* base = e->buf<bf16_t>("ckv_cache") + (size_t)slot * (e->NL + e->NV) * e->ctx_rows * 2 * d;
+  for (int l = 0; l < e->NL + e->NV; ++l) {
+    st = context_kv(e, l < e->NL ? e->layers[l] : e->vlayers[l - e->NL], ctx, base + (size_t)l * e->ctx_rows * 2 * d, s);
+    if (st != MC_OK) return st;
+  }
+  e->ctx_valid[slot] = true;
+  e->ctx_active = slot;
+  return MC_OK;
+}
+
+mc_status mc_use_context(mc_engine* e, int slot) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (slot < -1 || slot > 1) return fail(MC_EINVAL, "context slot %d out of range (-1, 0, 1)", slot);
+  if (slot >= 0 && !e->ctx_valid[slot]) return fail(MC_ESTATE, "context slot %d was never set (mc_set_context)", slot);
+  e->ctx_active = slot;
   return MC_OK;
 }
 

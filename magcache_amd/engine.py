@@ -221,16 +221,33 @@ class Engine:
             return context.contiguous(), MC_BF16
         return context.float().contiguous(), MC_F32
 
+    def set_context(self, slot, context):
+        """embed `context` [ctx_len, text_dim] once and cache every block's cross-attention K|V in slot 0 / 1; the
+        following forwards pass context=None (mc_set_context)"""
+        ctx, cdt = self._ctx(context.to(self.device))
+        check(self.lib.mc_set_context(self.h, int(slot), _ptr(ctx), cdt, ctx.shape[0], _stream()))
+        self._keep_ctx = ctx
+
+    def use_context(self, slot):
+        check(self.lib.mc_use_context(self.h, int(slot)))
+
+    def _ctx_args(self, context):
+        if context is None:                       # cached slot (set_context / use_context)
+            return None, MC_F32, 0
+        ctx, cdt = self._ctx(context)
+        return ctx, cdt, ctx.shape[0]
+
     def forward(self, latent, t, context, branch=0, mode=MC_MODE_FULL, out=None):
         """latent fp32 [C,F,H,W]; t python float or 1-element tensor on the device; context
-        [ctx_len, text_dim].  Returns fp32 [out_dim, F, H, W].  Asynchronous on the current stream."""
+        [ctx_len, text_dim] or None (cached slot).  Returns fp32 [out_dim, F, H, W].  Asynchronous on the current
+        stream."""
         assert self.sp_size == 1, "use magcache_amd.parallel.SequenceParallelForward for sp_size > 1"
         latent = latent.float().contiguous()
-        ctx, cdt = self._ctx(context)
+        ctx, cdt, clen = self._ctx_args(context)
         if out is None:
             out = torch.empty((self.cfg["out_dim"],) + self.grid, dtype=torch.float32, device=self.device)
         t_dev, t_host = self._t(t)
-        check(self.lib.mc_forward(self.h, _ptr(latent), _ptr(t_dev), t_host, _ptr(ctx), cdt, ctx.shape[0], branch,
+        check(self.lib.mc_forward(self.h, _ptr(latent), _ptr(t_dev), t_host, _ptr(ctx), cdt, clen, branch,
                                   mode, _ptr(out), _stream()))
         self._keep = (latent, ctx, t_dev)  # keep inputs alive until the stream has consumed them
         return out
@@ -245,9 +262,9 @@ class Engine:
     # ---- phase API (sequence parallel)
     def embed(self, latent, t, context):
         latent = latent.float().contiguous()
-        ctx, cdt = self._ctx(context)
+        ctx, cdt, clen = self._ctx_args(context)
         t_dev, t_host = self._t(t)
-        check(self.lib.mc_embed(self.h, _ptr(latent), _ptr(t_dev), t_host, _ptr(ctx), cdt, ctx.shape[0], _stream()))
+        check(self.lib.mc_embed(self.h, _ptr(latent), _ptr(t_dev), t_host, _ptr(ctx), cdt, clen, _stream()))
         self._keep = (latent, ctx, t_dev)
 
     def block_pre_attn(self, layer):

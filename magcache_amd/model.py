@@ -87,6 +87,8 @@ class WanModelHIP:
             self.model_type = cfg["model_type"]          # instance attribute, like upstream's self.model_type
         self._clip_key = None
         self._vace_key = None
+        self._ctx_keys = [None, None]     # text-context cache: identity of the tensor held by engine slot 0 / 1
+        self._ctx_lru = 0
         self.engine = engine or Engine(cfg, latent_grid, device=device, n_branches=2, calibration=calibration,
                                        sp_rank=sp_rank, sp_size=sp_size)
         self.device = self.engine.device
@@ -94,7 +96,26 @@ class WanModelHIP:
 
     def load_state_dict(self, state_dict):
         self.engine.load_weights(state_dict)
+        self._ctx_keys = [None, None]     # cached text K/V belong to the old weights
         return self
+
+    def _cached_context(self, ctx):
+        """The prompt / negative-prompt embeddings are the same two tensors in every step of a video: their text
+        embedding and per-block cross-attention K|V are computed once per tensor (engine cache slots 0 / 1, least
+        recently used replaced) instead of in every forward.  Identity + version counter, no content compare."""
+        for slot, key in enumerate(self._ctx_keys):
+            if key is not None and _same_tensor(key, ctx):
+                try:
+                    self.engine.use_context(slot)
+                except Exception:             # the engine dropped the slot (weights were reloaded behind the shim)
+                    self._ctx_keys[slot] = None
+                    break
+                self._ctx_lru = 1 - slot
+                return
+        slot = self._ctx_lru
+        self.engine.set_context(slot, ctx)
+        self._ctx_keys[slot] = _tensor_key(ctx)
+        self._ctx_lru = 1 - slot
 
     # -- input checks shared by all forwards (the reference's asserts :226-227, :242)
     def _check_inputs(self, x, context, seq_len, clip_fea, y):
@@ -138,7 +159,11 @@ class WanModelHIP:
         elif hasattr(self.engine, "set_token_timesteps"):
             self.engine.set_token_timesteps(None)
         t = t if not torch.is_tensor(t) else t.to(self.device)
-        ctx = context[0].to(self.device)
+        if hasattr(self.engine, "set_context"):
+            self._cached_context(context[0])
+            ctx = None
+        else:
+            ctx = context[0].to(self.device)
         if self.engine.sp_size > 1:
             if getattr(self, "_sp", None) is None:
                 from .parallel import SequenceParallelForward

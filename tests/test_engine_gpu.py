@@ -650,3 +650,42 @@ def test_wan22_ti2v_per_token_timesteps_vs_reference_golden(golden_dir):
     assert int(cls.cnt) == 0
     assert max(errs) < 3e-2, errs
     assert MR.psnr(x.cpu().numpy(), g["final_latent"], data_range=float(np.abs(g["final_latent"]).max())) > 35.0
+
+
+def test_text_context_cache_equals_uncached_forward():
+    """mc_set_context / mc_use_context: the text embedding and every block's cross-attention K|V of a context are
+    computed once and reused; the forward must be BIT-identical to the one that recomputes them (same kernels, same
+    inputs), also when cond / uncond contexts alternate like in the CFG loop and after a weight reload."""
+    cfg = W.tiny_config(num_layers=3, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64)
+    grid = (2, 16, 16)
+    oracle = W.init_synthetic_(W.WanModel(**cfg), seed=2, std=0.05)
+    e = Engine(cfg, grid, device=DEV, n_branches=2, calibration=False)
+    e.load_weights(oracle.state_dict())
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(16, *grid, generator=g).to(DEV)
+    c0, c1 = torch.randn(21, cfg["text_dim"], generator=g).to(DEV), torch.randn(9, cfg["text_dim"], generator=g).to(DEV)
+    want0 = e.forward(lat, 500.0, c0).clone()
+    want1 = e.forward(lat, 500.0, c1).clone()
+    e.set_context(0, c0)
+    e.set_context(1, c1)
+    for _ in range(3):
+        e.use_context(0)
+        assert torch.equal(e.forward(lat, 500.0, None), want0)
+        e.use_context(1)
+        assert torch.equal(e.forward(lat, 500.0, None), want1)
+    assert torch.equal(e.forward(lat, 500.0, c0), want0)             # an explicit context bypasses the cache
+    with pytest.raises(RuntimeError):                                 # ... and deselects it
+        e.forward(lat, 500.0, None)
+    e.load_weights(W.init_synthetic_(W.WanModel(**cfg), seed=3, std=0.05).state_dict())
+    with pytest.raises(RuntimeError):                                 # new weights: the cached K|V are stale
+        e.use_context(0)
+    # the shim caches by tensor identity: same results as the explicit path, through the model class
+    m = type("WanModelHIPCtxCache", (M.WanModelHIP,), {})(cfg, grid, device=DEV, calibration=False)
+    m.load_state_dict(oracle.state_dict())
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    tt = torch.tensor([500.0], device=DEV)
+    for _ in range(2):
+        assert torch.equal(m([lat], t=tt, context=[c0], seq_len=L)[0], want0)
+        assert torch.equal(m([lat], t=tt, context=[c1], seq_len=L)[0], want1)
+    c0.mul_(2.0)                                                      # in-place edit bumps the version: recomputed
+    assert not torch.equal(m([lat], t=tt, context=[c0], seq_len=L)[0], want0)
