@@ -52,15 +52,26 @@ constexpr int LDS_BYTES = 2 * NST * TILE_BYTES;  // 96 KiB
 constexpr float NEG_INF = -__builtin_huge_valf();
 constexpr float RTHR = 4.0f;  // rescale threshold in log2 units: P <= 2^4
 
-__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+// Maxima as asm: the scores come out of asm MFMAs, so hipcc cannot prove them canonical and would put a
+// v_max_f32 x, x, x in front of every fmaxf operand (27 extra VALU issues per key tile in the first build).
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // max / sum over the 4 lanes {l15 + 16 g}: v_permlane32_swap pairs g with g^2, v_permlane16_swap g with g^1; both
 // results of a swap are combined, so every lane ends with the full value
 __device__ __forceinline__ float group4_max(float v) {
   auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  v = max2(__uint_as_float(a[0]), __uint_as_float(a[1]));
   auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+  return max2(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float group4_sum(float v) {
   auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v4_kernel(AttnParams p, int n
     float t0 = max3(s[0][qb][0], s[0][qb][1], s[0][qb][2]), t1 = max3(s[0][qb][3], s[1][qb][0], s[1][qb][1]);
     float t2 = max3(s[1][qb][2], s[1][qb][3], s[2][qb][0]), t3 = max3(s[2][qb][1], s[2][qb][2], s[2][qb][3]);
     float t4 = max3(s[3][qb][0], s[3][qb][1], s[3][qb][2]);
-    return fmaxf(max3(t0, t1, t2), max3(t3, t4, s[3][qb][3]));
+    return max2(max3(t0, t1, t2), max3(t3, t4, s[3][qb][3]));
   };
   // keys >= nvalid of a tile are padding: -inf before the max and the exponentials
   auto mask_tail = [&](int nvalid, f32x4 (&s)[4][2]) {
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v4_kernel(AttnParams p, int n
       tb_[0] = max3(tb_[0], S[3][0][0], S[3][0][1]); tb_[1] = max3(tb_[1], S[3][1][0], S[3][1][1]);   \
     } else if ((part) == 3) {                                                                        \
       ta_[0] = max3(ta_[0], S[3][0][2], S[3][0][3]); ta_[1] = max3(ta_[1], S[3][1][2], S[3][1][3]);   \
-      ta_[0] = fmaxf(ta_[0], tb_[0]); ta_[1] = fmaxf(ta_[1], tb_[1]);                                 \
+      ta_[0] = max2(ta_[0], tb_[0]); ta_[1] = max2(ta_[1], tb_[1]);                                 \
     } else if ((part) == 4) {                                                                        \
       mx[0] = group4_max(ta_[0]);                                                                     \
     } else {                                                                                         \
