@@ -76,7 +76,8 @@ const char* mc_version(void);
  * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 (= 3) = the attention kernel (32x32x16 MFMA), 4 = the same
  * pipeline on 16x16x32 (attention_v4.hip, kept for A/B: not faster on this workload); "mmdit_two_streams" 1 = the
  * text stream of an MM-DiT double block (FLUX / HunyuanVideo) runs on a second HIP stream next to the image stream
- * (bit-identical results, checked by a determinism test; default 0).  Used by the
+ * (bit-identical results, checked by a determinism test; default 0; values 2..6 are the diagnostic splits of
+ * tests/two_stream_bisect.py: which pair of kernels overlaps).  Used by the
  * parity tests and the A/B micro-benchmarks (tools/build_ab_lib.py builds a library that also answers to the
  * retired kernel generations under tools/kernels_ab/). */
 mc_status mc_set_option(const char* key, int value);

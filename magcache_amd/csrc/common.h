@@ -21,6 +21,19 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define MC_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// Kernels that may share a CU with another stream's MFMA kernel (the two-stream MM-DiT double block: LayerNorm +
+// modulate and head norm + RoPE of one half beside the other half's GEMM) are built without packed-fp32 VALU
+// instructions.  Measured on MI355X (tests/two_stream_bisect.py, profiles/r02/two_stream_bisect_*.log): with
+// v_pk_mul_f32 / v_pk_fma_f32 in the head-norm kernel, about one forward in three had ONE (row, head) whose 16 lanes
+// 48..63 carried a wrong low result of the rotation's v_pk_fma_f32 -- only while the other stream's 128x128 GEMM was
+// resident; the one-stream result matched an fp64 restatement, the two-stream one did not; the same kernel compiled
+// with -packed-fp32-ops: 0 differences in 360 replays.  The scalar forms cost nothing here (latency-bound kernels).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MC_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define MC_NO_PK_F32
+#endif
 #define MC_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

@@ -17,7 +17,7 @@ namespace {
 // ------------------------------------------------------------------ LayerNorm (+ modulate / affine)
 // one wave per row; lane holds NV float4 (row element e = i*256 + lane*4 + j)
 template <int NV>
-__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, long ldx,
+MC_NO_PK_F32 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, long ldx,
                                                           const bf16_t* __restrict__ x0, long ldx0,
                                                           const float* __restrict__ sc,
                                                           const float* __restrict__ sh, int mode, float eps,
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
 
 // ------------------------------------------------------------------ MM-DiT per-head RMSNorm + RoPE (q and k)
 // One wave per row; a head is 128 channels = 64 lanes x one (2i, 2i+1) pair, i.e. exactly one RoPE pair per lane.
-__global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__ x, long ldx, long k_col0,
+MC_NO_PK_F32 __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__ x, long ldx, long k_col0,
                                                             const float* __restrict__ wq,
                                                             const float* __restrict__ wk, float eps,
                                                             const float* __restrict__ cs, int cs_row0, int M,

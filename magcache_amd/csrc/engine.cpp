@@ -1319,13 +1319,11 @@ mc_status mc_set_option(const char* key, int value) {
   if (!key) return fail(MC_EINVAL, "null key");
   const std::string k(key);
   if (k == "gemm_kernel") {
-#ifdef MC_AB_KERNELS
-    const int gemm_max = 3;
-#else
-    const int gemm_max = 2;
+#ifndef MC_AB_KERNELS
+    if (value == 3) return fail(MC_EINVAL, "gemm_kernel 3 exists only in the A/B library (tools/build_ab_lib.py)");
 #endif
-    if (value < 0 || value > gemm_max)
-      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128) or 2 (256x256)");
+    if (value < 0 || value > 4)
+      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 4 (256x256, 4 waves)");
     mc::g_gemm_kernel = value;
   } else if (k == "attn_kernel") {
 #ifndef MC_AB_KERNELS
@@ -1335,7 +1333,7 @@ mc_status mc_set_option(const char* key, int value) {
     if (value < 0 || value > 4) return fail(MC_EINVAL, "attn_kernel must be 0..4");
     mc::g_attn_kernel = value;
   } else if (k == "mmdit_two_streams") {
-    if (value != 0 && value != 1) return fail(MC_EINVAL, "mmdit_two_streams must be 0 or 1");
+    if (value < 0 || value > 6) return fail(MC_EINVAL, "mmdit_two_streams must be 0, 1 or a diagnostic mode 2..6");
     g_mmdit_two_streams = value;
   } else {
     return fail(MC_EINVAL, "unknown option '%s'", key);

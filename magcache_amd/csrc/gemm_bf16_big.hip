@@ -76,6 +76,7 @@ constexpr int OFF_AM0 = 0, OFF_AM1 = HALF_BYTES, OFF_WN0 = 2 * HALF_BYTES, OFF_W
 //   2: every steady-state wait retires one more half (vmcnt(8) instead of (10)): masks an under-counted wait
 //   4: the LDS-DMA loads carry sc0 sc1 (served by L2, the CU's vector L1 is bypassed): masks a stale L1 line
 //  16: vmcnt(0) at the end of every interval: no LDS-DMA is ever in flight across a barrier
+//  32: two barriers per K tile instead of four (after q1 and q3; see MC_TILE)
 // Timing ablations (tools/build_variants.py gemm_bf16_big.hip <bits>, macro MC_ABL; results are WRONG by
 // construction): 1: no A fragment reads, 2: no W fragment reads, 4: no LDS-DMA refills, 8: no workgroup barriers --
 // all in the steady-state loop only; the prologue always runs, so every register holds finite data.
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   // ---- prologue: K tiles 0 and 1 in the steady-state issue order; Wn0(0), Am0(0), Wn1(0) landed
   dma_w(0, 0, 0); dma_a(0, 0, 0); dma_w(0, 0, 1); dma_a(0, 0, 1);
   dma_w(1, 1, 0); dma_a(1, 1, 0); dma_w(1, 1, 1); dma_a(1, 1, 1);
-  MC_WAIT(10);
+  if (MC_VAR & 32) MC_WAIT_(8); else MC_WAIT(10);   // two-barrier form: q0 + q1 read Wn1(0) AND Am1(0) before the next barrier
   MC_BARRIER();
   // A0/A1: this wave's m0/m1 halves; W0/W1: n0/n1 of the current tile, W2: n0 of the next (W0 is
   // still live when it is read, so W0/W2 ping-pong by renaming; A0 is dead by then and is reused)
@@ -284,23 +285,37 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
     /* q0: (m0,n0); reads Wn1(kt); DMA Wn0(kt+2) */                                                           \
     MC_INTERVAL(W0, A0, 0, 0, MC_RD_W(true, ST, 1, W1),                                                       \
                 if (MC_DMA_OK(TAIL)) dma_w1((kt) + 2, ST, 0, 0), if (MC_DMA_OK(TAIL)) dma_w1((kt) + 2, ST, 0, 1)) \
-    if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(8); else MC_WAIT(0);                              \
-    MC_BARRIER();                                                                                             \
+    if (!(MC_VAR & 32)) {                                                                                     \
+      if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(8); else MC_WAIT(0);                            \
+      MC_BARRIER();                                                                                           \
+    }                                                                                                         \
     /* q1: (m0,n1); reads Am1(kt); DMA Am0(kt+2) */                                                           \
     MC_INTERVAL(W1, A0, 0, 1, MC_RD_A(true, ST, 1, A1),                                                       \
                 if (MC_DMA_OK(TAIL)) dma_a1((kt) + 2, ST, 0, 0), if (MC_DMA_OK(TAIL)) dma_a1((kt) + 2, ST, 0, 1)) \
-    if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(6);                                               \
-    MC_BARRIER();                                                                                             \
+    if (MC_VAR & 32) { /* groups in flight: [Wn0,Am0](kt+1) [Wn1,Am1](kt+1) [Wn0,Am0](kt+2); the first must land */ \
+      if (TAIL == 0) MC_WAIT_(8); else if (TAIL == 1) MC_WAIT_(4);                                            \
+      if (TAIL != 2) MC_BARRIER();                                                                            \
+    } else {                                                                                                  \
+      if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(6);                                             \
+      MC_BARRIER();                                                                                           \
+    }                                                                                                         \
     /* q2: (m1,n1); reads Wn0(kt+1); DMA Wn1(kt+2) */                                                         \
     MC_INTERVAL(W1, A1, 1, 1, MC_RD_W(TAIL != 2, 1 - ST, 0, W2),                                              \
                 if (MC_DMA_OK(TAIL)) dma_w1((kt) + 2, ST, 1, 0), if (MC_DMA_OK(TAIL)) dma_w1((kt) + 2, ST, 1, 1)) \
-    if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(4);                                               \
-    MC_BARRIER();                                                                                             \
+    if (!(MC_VAR & 32)) {                                                                                     \
+      if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(4);                                             \
+      MC_BARRIER();                                                                                           \
+    }                                                                                                         \
     /* q3: (m1,n0); reads Am0(kt+1); DMA Am1(kt+2) */                                                         \
     MC_INTERVAL(W0, A1, 1, 0, MC_RD_A(TAIL != 2, 1 - ST, 0, A0),                                              \
                 if (MC_DMA_OK(TAIL)) dma_a1((kt) + 2, ST, 1, 0), if (MC_DMA_OK(TAIL)) dma_a1((kt) + 2, ST, 1, 1)) \
-    if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(2);                                               \
-    MC_BARRIER();                                                                                             \
+    if (MC_VAR & 32) { /* [Wn1,Am1](kt+1) must land: [Wn0,Am0](kt+2) [Wn1,Am1](kt+2) may stay in flight */    \
+      if (TAIL == 0) MC_WAIT_(8); else if (TAIL == 1) MC_WAIT_(0);                                            \
+      if (TAIL != 2) MC_BARRIER();                                                                            \
+    } else {                                                                                                  \
+      if (TAIL == 0) MC_WAIT(10); else if (TAIL == 1) MC_WAIT(2);                                             \
+      MC_BARRIER();                                                                                           \
+    }                                                                                                         \
   }
 
   // nk is even (checked by the launcher): steady pairs, then the two tail tiles

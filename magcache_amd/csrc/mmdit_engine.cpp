@@ -577,16 +577,20 @@ mc_status run_refiner(mc_mmdit* e, const float* txt_dev, int txt_valid, float* v
 }
 
 // one stream of a double block, before the joint attention: LN + modulate, QKV, per-head q/k norm, RoPE
-mc_status stream_pre_attn(const mc_mmdit* e, const Stream& w, const float* mod, int row0, int rows, hipStream_t s) {
+// phases (diagnostic split, tests/two_stream_bisect.py): 1 = LN + QKV GEMM, 2 = head norm + RoPE, 3 = both
+mc_status stream_pre_attn(const mc_mmdit* e, const Stream& w, const float* mod, int row0, int rows, hipStream_t s,
+                          int phases = 3) {
   const int d = e->d;
   float* x = e->buf<float>("x") + (size_t)row0 * d;
   bf16_t* xn = e->buf<bf16_t>("xn") + (size_t)row0 * d;
   bf16_t* qkv = e->buf<bf16_t>("qkv") + (size_t)row0 * 3 * d;
-  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, mod + d, mod, 0, 1e-6f, xn, d, nullptr, 0, rows, d, s));
-  mc::GemmParams p = gp(xn, d, w.wqkv, d, w.bqkv, rows, 3 * d, d);
-  p.Cb = qkv; p.ldc = 3 * d;
-  HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
-  HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, w.qn, w.kn, 1e-6f, e->cs, row0, rows, e->H, s));
+  if (phases & 1) {
+    HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, mod + d, mod, 0, 1e-6f, xn, d, nullptr, 0, rows, d, s));
+    mc::GemmParams p = gp(xn, d, w.wqkv, d, w.bqkv, rows, 3 * d, d);
+    p.Cb = qkv; p.ldc = 3 * d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+  }
+  if (phases & 2) HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, w.qn, w.kn, 1e-6f, e->cs, row0, rows, e->H, s));
   return MC_OK;
 }
 
@@ -622,7 +626,7 @@ mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod,
 // half runs on the engine's side stream between a fork and a join event (capturable: the side stream joins back).
 template <class FI, class FT>
 mc_status run_two(mc_mmdit* e, hipStream_t s, FI&& img_part, FT&& txt_part) {
-  if (!g_mmdit_two_streams) {
+  if (!g_mmdit_two_streams || g_mmdit_two_streams > 2) {   // > 2: diagnostic modes split block_pre only
     MC_TRY(img_part(s));
     return txt_part(s);
   }
@@ -635,9 +639,15 @@ mc_status run_two(mc_mmdit* e, hipStream_t s, FI&& img_part, FT&& txt_part) {
   }
   const int i = e->ev_i;
   e->ev_i = (e->ev_i + 1) & 7;
-  HIP_TRY(hipEventRecord(e->ev_fork[i], s));
-  HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork[i], 0));
-  MC_TRY(img_part(s));
+  if (g_mmdit_two_streams == 2) {   // diagnostic: same streams and events, but the text half starts after the image half
+    MC_TRY(img_part(s));
+    HIP_TRY(hipEventRecord(e->ev_fork[i], s));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork[i], 0));
+  } else {
+    HIP_TRY(hipEventRecord(e->ev_fork[i], s));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork[i], 0));
+    MC_TRY(img_part(s));
+  }
   MC_TRY(txt_part(e->side));
   HIP_TRY(hipEventRecord(e->ev_join[i], e->side));
   HIP_TRY(hipStreamWaitEvent(s, e->ev_join[i], 0));
@@ -733,9 +743,33 @@ mc_status mc_mmdit_block_pre(mc_mmdit* e, int blk, mc_stream stream_) {
   const float* emod = e->buf<float>("emod");
   bf16_t* qkv = e->buf<bf16_t>("qkv");
   if (blk < c.n_double) {
-    MC_TRY(run_two(
-        e, s, [&](hipStream_t q) { return stream_pre_attn(e, e->dimg[blk], emod + e->mod_double(blk, 0), e->img0, Li, q); },
-        [&](hipStream_t q) { return stream_pre_attn(e, e->dtxt[blk], emod + e->mod_double(blk, 1), e->txt0, Lt, q); }));
+    const float* mi = emod + e->mod_double(blk, 0);
+    const float* mt = emod + e->mod_double(blk, 1);
+    auto img = [&](hipStream_t q, int ph) { return stream_pre_attn(e, e->dimg[blk], mi, e->img0, Li, q, ph); };
+    auto txt = [&](hipStream_t q, int ph) { return stream_pre_attn(e, e->dtxt[blk], mt, e->txt0, Lt, q, ph); };
+    const int mode = g_mmdit_two_streams;
+    if (mode <= 2) {
+      MC_TRY(run_two(e, s, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 3); }));
+    } else {   // diagnostic splits: which pair of kernels must overlap for the results to change
+      g_mmdit_two_streams = 1;
+      mc_status st = MC_OK;
+      if (mode == 3) {          // text LN + GEMM beside the image half; text head norm afterwards, serial
+        st = run_two(e, s, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 1); });
+        if (st == MC_OK) st = txt(s, 2);
+      } else if (mode == 4) {   // text LN + GEMM first, serial; text head norm beside the whole image half
+        st = txt(s, 1);
+        if (st == MC_OK) st = run_two(e, s, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 2); });
+      } else if (mode == 5) {   // image LN + GEMM beside the whole text half; image head norm afterwards, serial
+        st = run_two(e, s, [&](hipStream_t q) { return img(q, 1); }, [&](hipStream_t q) { return txt(q, 3); });
+        if (st == MC_OK) st = img(s, 2);
+      } else {                  // 6: LN + GEMM of both halves serial; the two head norm kernels beside each other
+        st = img(s, 1);
+        if (st == MC_OK) st = txt(s, 1);
+        if (st == MC_OK) st = run_two(e, s, [&](hipStream_t q) { return img(q, 2); }, [&](hipStream_t q) { return txt(q, 2); });
+      }
+      g_mmdit_two_streams = mode;
+      MC_TRY(st);
+    }
   } else {
     const int i = blk - c.n_double;
     const Single& g = e->singles[i];

@@ -263,12 +263,14 @@ def test_mmdit_full_width_block_shapes():
 
 def test_mmdit_two_streams_is_bit_identical_and_deterministic():
     """VERDICT r01 item 2.  Round 1 withdrew a two-stream double block because "one 64-byte chunk of one image q row
-    differs run to run"; the suspected kernels (a 256x256 GEMM next to a 128x128 GEMM) are exonerated by
-    tools/race_repro.cpp (4000 bit-exact replays of every pairing, profiles/r02/race_repro.log).  This is the engine-level
-    check of the re-built option: FLUX.1-dev width (d = 3072, 24 heads) at 512x512 size (1024 image + 512 text tokens:
-    the image stream's GEMMs take the 256x256 kernel, the text stream's the 128x128 one), 2 double + 1 single block,
-    text stream on the side stream between a fork and a join event.  100 replays must equal the one-stream result bit
-    for bit."""
+    differs run to run".  Round 2 found the mechanism (tests/two_stream_bisect.py, profiles/r02/two_stream_bisect_*.log):
+    not the GEMMs (tools/race_repro.cpp: 4000 bit-exact replays of every pairing) but the head-norm + RoPE kernel of one
+    half while the OTHER half's 128x128 GEMM was resident on the same CU -- lanes 48..63 of one (row, head) carried a
+    wrong low result of a v_pk_fma_f32; the kernels of the fork region are now built without packed-fp32 instructions
+    (csrc/common.h MC_NO_PK_F32).  This is the engine-level check: FLUX.1-dev width (d = 3072, 24 heads) at 512x512
+    size (1024 image + 512 text tokens: the image stream's GEMMs take the 256x256 kernel, the text stream's the 128x128
+    one), 2 double + 1 single block, text stream on the side stream between a fork and a join event.  300 replays must
+    equal the one-stream result bit for bit (before the fix about one replay in three differed)."""
     lib = _lib.load()
     cfg = dict(FR.FLUX_DEV, num_layers=2, num_single_layers=1, joint_attention_dim=512)
     oracle = FR.init_synthetic_(FR.FluxTransformer2DModel(**cfg), seed=21, std=0.02)
@@ -287,7 +289,7 @@ def test_mmdit_two_streams_is_bit_identical_and_deterministic():
     assert bool(torch.isfinite(ref).all())
     try:
         _lib.check(lib.mc_set_option(b"mmdit_two_streams", 1))
-        for rep in range(100):
+        for rep in range(300):
             got = m(hidden_states=xd, timestep=td, return_dict=False, **kwd)[0]
             assert torch.equal(got, ref), f"replay {rep}: two-stream forward differs from the one-stream forward"
     finally:

@@ -44,10 +44,37 @@ def describe(name, a, b, width, txt_rows):
         prev = v
     runs.append((start, prev))
     msg += f"\n      row {r0}: column runs {runs[:8]}  max |delta| {float((a[r0].float() - b[r0].float()).abs().max()):.3e}"
+    if name == "qkv" and r0 >= txt_rows:     # position inside the 256x256 tile of the image stream's GEMM
+        mi, ni = (r0 - txt_rows) % 256, c[0] % 256
+        msg += (f"\n      in tile: m {mi} = wr {mi // 128} mh {(mi // 64) % 2} mb {(mi // 16) % 4} l15 {mi % 16}; "
+                f"n {ni} = wc {ni // 64} nh {(ni // 32) % 2} nb {(ni // 16) % 2} kgrp {(ni // 4) % 4} r {ni % 4}; "
+                f"tile ({(r0 - txt_rows) // 256}, {c[0] // 256})")
     c0 = max(0, c[0] - 2)
     msg += f"\n      got[{r0}, {c0}:{c0 + 12}] = {[round(float(v), 4) for v in a[r0, c0:c0 + 12].float()]}"
     msg += f"\n      ref[{r0}, {c0}:{c0 + 12}] = {[round(float(v), 4) for v in b[r0, c0:c0 + 12].float()]}"
     return msg
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def expected_q_chunk(oracle, rope, xn, blk, row, head, txt_len):
+    """fp64 restatement of (QKV GEMM -> bf16 -> head RMS norm -> RoPE -> bf16) for the q head `head` of joint row `row`
+    of double block `blk`, from the engine's own xn (LN + modulate output, untouched by the later kernels)."""
+    attn = oracle.transformer_blocks[blk].attn
+    lin, nrm = (attn.to_q, attn.norm_q) if row >= txt_len else (attn.add_q_proj, attn.norm_added_q)
+    w = bf16r(lin.weight.detach()[head * 128:(head + 1) * 128]).to(xn.device)
+    b = lin.bias.detach()[head * 128:(head + 1) * 128].double().to(xn.device)
+    q = bf16r(xn[row].double() @ w.T + b)                       # EPI_BF16 store
+    rstd = torch.rsqrt((q * q).mean() + 1e-6)
+    q = bf16r(bf16r(q * rstd) * nrm.weight.detach().double().to(xn.device))
+    cos, sin = rope[0][row].double().to(xn.device), rope[1][row].double().to(xn.device)
+    re, im = q[0::2], q[1::2]
+    out = torch.empty_like(q)
+    out[0::2] = re * cos[0::2] - im * sin[0::2]
+    out[1::2] = re * sin[0::2] + im * cos[0::2]
+    return bf16r(out)
 
 
 def main():
@@ -62,7 +89,8 @@ def main():
     m = MM.FluxTransformer2DModelHIP(cfg, h2 * w2, txt_len=txt_len, device=DEV, calibration=False)
     m.load_state_dict(oracle.state_dict())
     ids = torch.cat((torch.zeros(txt_len, 3), FR.prepare_latent_image_ids(h2, w2)), dim=0).to(DEV, torch.float32)
-    m.engine.set_rope(*MM.flux_rope(ids, tuple(cfg["axes_dims_rope"])))
+    rope = MM.flux_rope(ids, tuple(cfg["axes_dims_rope"]))
+    m.engine.set_rope(*rope)
     e = m.engine
     d = e.dim
     widths = {"x": d, "xn": d, "qkv": 3 * d, "am": 5 * d}
@@ -79,14 +107,27 @@ def main():
                 fn(blk)
                 if sync_between:
                     torch.cuda.synchronize()
-                    cur = {n: e.buffer(n, dt).clone() for n, dt in BUFS}
+                    cur = {n: e.buffer(n, dt).clone() for n, dt in BUFS if not (n == "am" and phase == "pre")}
                     snaps[(blk, phase)] = cur
                     if check is not None:
-                        bad = [n for n, _ in BUFS if not torch.equal(bits(cur[n]), bits(check[(blk, phase)][n]))]
+                        bad = [n for n in cur if not torch.equal(bits(cur[n]), bits(check[(blk, phase)][n]))]
                         if bad:
                             print(f"  first difference after block {blk} {phase}: buffers {bad}")
                             for n in bad:
                                 print(describe(n, cur[n], check[(blk, phase)][n], widths[n], txt_len))
+                            if bad == ["qkv"] and phase == "pre" and blk < cfg["num_layers"]:
+                                a, b = cur["qkv"].view(-1, 3 * d), check[(blk, phase)]["qkv"].view(-1, 3 * d)
+                                diff = bits(a) != bits(b)
+                                r0 = int(diff.any(dim=1).nonzero()[0])
+                                c0 = int(diff[r0].nonzero()[0])
+                                if c0 < d:
+                                    h = c0 // 128
+                                    want = expected_q_chunk(oracle, rope, cur["xn"].view(-1, d), blk, r0, h, txt_len)
+                                    g_, r_ = a[r0, h * 128:(h + 1) * 128].double(), b[r0, h * 128:(h + 1) * 128].double()
+                                    lo = (c0 % 128) // 32 * 32
+                                    print(f"      fp64 restatement, row {r0} head {h} cols {lo}..{lo + 31}: two-stream result differs from it in "
+                                          f"{int((g_ != want)[lo:lo + 32].sum())} of 32, one-stream result in {int((r_ != want)[lo:lo + 32].sum())} of 32 "
+                                          f"(whole head: {int((g_ != want).sum())} / {int((r_ != want).sum())} of 128)")
                             return None
         e.end(out)
         torch.cuda.synchronize()
@@ -97,18 +138,24 @@ def main():
     again = run(True, ref)
     print("one stream, phased, repeat:", "identical" if again is not None else "DIFFERS")
     ref_out = run(False)
-    for gk in [int(v) for v in os.environ.get("BISECT_GEMM_KERNELS", "0,1").split(",")]:
+    names = {1: "everything of the text half beside the image half", 2: "text half after the image half (same streams, events)",
+             3: "text LN+GEMM beside the image half, text head norm serial", 4: "text LN+GEMM serial, text head norm beside the image half",
+             5: "image LN+GEMM beside the text half, image head norm serial", 6: "LN+GEMM serial, the two head norm kernels beside each other"}
+    for mode in [int(v) for v in os.environ.get("BISECT_MODES", "1,3,4,5,6").split(",")]:
+        print(f"==== mmdit_two_streams = {mode}: {names[mode]}")
+        two_stream_replays(lib, run, ref, ref_out, mode)
+    for gk in [int(v) for v in os.environ.get("BISECT_GEMM_KERNELS", "1").split(",") if v]:
         _lib.check(lib.mc_set_option(b"gemm_kernel", gk))
         print(f"==== gemm_kernel = {gk} (0: engine's choice, 1: the 128x128 kernel everywhere)")
         run(False)
         ref = run(True)
         ref_out = run(False)
-        two_stream_replays(lib, run, ref, ref_out)
+        two_stream_replays(lib, run, ref, ref_out, 1)
     _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
 
 
-def two_stream_replays(lib, run, ref, ref_out):
-    _lib.check(lib.mc_set_option(b"mmdit_two_streams", 1))
+def two_stream_replays(lib, run, ref, ref_out, mode=1):
+    _lib.check(lib.mc_set_option(b"mmdit_two_streams", mode))
     try:
         bad = 0
         for rep in range(int(os.environ.get("BISECT_REPLAYS", "150"))):
