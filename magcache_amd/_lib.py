@@ -139,6 +139,10 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # MAGCACHE_HIP_OPTIONS="key=value,key=value": process-wide mc_set_option calls (A/B runs of bench.py and the tools)
+    for kv in filter(None, os.environ.get("MAGCACHE_HIP_OPTIONS", "").split(",")):
+        key, _, val = kv.partition("=")
+        check(lib.mc_set_option(key.strip().encode(), int(val)))
     return lib
 
 

@@ -1319,11 +1319,13 @@ mc_status mc_set_option(const char* key, int value) {
   if (!key) return fail(MC_EINVAL, "null key");
   const std::string k(key);
   if (k == "gemm_kernel") {
-#ifndef MC_AB_KERNELS
-    if (value == 3) return fail(MC_EINVAL, "gemm_kernel 3 exists only in the A/B library (tools/build_ab_lib.py)");
+#ifdef MC_AB_KERNELS
+    const int gemm_max = 3;
+#else
+    const int gemm_max = 2;
 #endif
-    if (value < 0 || value > 4)
-      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 4 (256x256, 4 waves)");
+    if (value < 0 || value > gemm_max)
+      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128) or 2 (256x256)");
     mc::g_gemm_kernel = value;
   } else if (k == "attn_kernel") {
 #ifndef MC_AB_KERNELS

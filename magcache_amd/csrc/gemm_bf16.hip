@@ -212,9 +212,6 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
       big = 1.3 * fill_efficiency(tiles_big, 256) >= fill_efficiency(tiles_small, 512);
     }
   }
-  if (g_gemm_kernel == 4 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
-      gemm_bf16_w4_supported(p))
-    return launch_gemm_bf16_w4(p, epi, stream);     // the 4-wave geometry: explicit request (A/B, tests)
 #ifdef MC_AB_KERNELS
   if (g_gemm_kernel == 3 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
       gemm_bf16_big_supported(p))

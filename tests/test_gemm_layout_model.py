@@ -89,3 +89,4 @@ def test_fragment_reads_are_bank_conflict_free():
                 off = l15 * ROW_BYTES + (((4 * ks + kgrp) ^ (l15 >> 1)) << 4)
                 slots.add((off // 16) % 16)
             assert len(slots) == 16
+

@@ -167,11 +167,12 @@ def two_stream_replays(lib, run, ref, ref_out, mode=1):
                     break
         print(f"two streams, host sync after every phase: {bad} differing replays")
         bad2 = 0
-        for rep in range(60):
+        soak = int(os.environ.get("BISECT_SOAK", "60"))
+        for rep in range(soak):
             o = run(False)
             if not torch.equal(o, ref_out):
                 bad2 += 1
-        print(f"two streams, no host sync inside a forward: {bad2} of 60 replays differ")
+        print(f"two streams, no host sync inside a forward: {bad2} of {soak} replays differ")
     finally:
         _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))
 

@@ -4,6 +4,7 @@ headline bench line):
 
     python tools/bench_mmdit.py flux      FLUX.1-dev 512x512, 28 steps: no-cache vs MagCache (thresh 0.24, K 5, R 0.1)
     python tools/bench_mmdit.py hunyuan   HunyuanVideo 720p 129 frames: full / skipped forward times, model TFLOP/s
+    (a trailing `two_streams` runs the text half of every double block on a second HIP stream)
 
 Synthetic inputs, seeded random-init weights of the real architecture (no checkpoints offline).  One JSON line each.
 Also checks the size-independent MagCache properties at full size: a skipped forward equals the final layer applied
@@ -195,6 +196,10 @@ def bench_hunyuan():
 
 
 if __name__ == "__main__":
-    load()
+    lib = load()
     which = sys.argv[1] if len(sys.argv) > 1 else "flux"
+    if "two_streams" in sys.argv[2:]:      # text half of every double block on a second HIP stream
+        from magcache_amd._lib import check
+        check(lib.mc_set_option(b"mmdit_two_streams", 1))
+        print("mmdit_two_streams = 1")
     {"flux": bench_flux, "hunyuan": bench_hunyuan}[which]()
