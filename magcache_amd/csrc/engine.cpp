@@ -1335,7 +1335,7 @@ mc_status mc_set_option(const char* key, int value) {
     if (value < 0 || value > 4) return fail(MC_EINVAL, "attn_kernel must be 0..4");
     mc::g_attn_kernel = value;
   } else if (k == "mmdit_two_streams") {
-    if (value < 0 || value > 6) return fail(MC_EINVAL, "mmdit_two_streams must be 0, 1 or a diagnostic mode 2..6");
+    if (value < -1 || value > 6) return fail(MC_EINVAL, "mmdit_two_streams must be -1 (by shape), 0, 1 or a diagnostic mode 2..6");
     g_mmdit_two_streams = value;
   } else {
     return fail(MC_EINVAL, "unknown option '%s'", key);

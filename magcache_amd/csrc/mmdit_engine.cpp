@@ -40,7 +40,9 @@ namespace mc {
 mc_status set_error_v(mc_status s, const char* fmt, va_list ap);  // engine.cpp
 }
 
-int g_mmdit_two_streams = 0;   // mc_set_option("mmdit_two_streams", v)
+// mc_set_option("mmdit_two_streams", v): -1 = by shape (default: on when the text half is at least 1/16 of the image
+// half -- FLUX; off for HunyuanVideo's 256 text tokens beside 118 800 image tokens), 0 off, 1 on, 2..6 diagnostic
+int g_mmdit_two_streams = -1;
 
 namespace {
 
@@ -626,7 +628,8 @@ mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod,
 // half runs on the engine's side stream between a fork and a join event (capturable: the side stream joins back).
 template <class FI, class FT>
 mc_status run_two(mc_mmdit* e, hipStream_t s, FI&& img_part, FT&& txt_part) {
-  if (!g_mmdit_two_streams || g_mmdit_two_streams > 2) {   // > 2: diagnostic modes split block_pre only
+  const bool by_shape = g_mmdit_two_streams < 0 && (long)e->Lt * 16 >= (long)e->Li && e->P == 1;
+  if (!(by_shape || g_mmdit_two_streams == 1 || g_mmdit_two_streams == 2)) {   // > 2: diagnostic modes split block_pre only
     MC_TRY(img_part(s));
     return txt_part(s);
   }

@@ -285,12 +285,13 @@ def test_mmdit_two_streams_is_bit_identical_and_deterministic():
     m.load_state_dict(oracle.state_dict())
     kwd = {k: dev(v) for k, v in kw.items()}
     xd, td = dev(x), dev(t)
-    ref = m(hidden_states=xd, timestep=td, return_dict=False, **kwd)[0].clone()
-    assert bool(torch.isfinite(ref).all())
     try:
+        _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))        # the default (-1, by shape) would already fork here
+        ref = m(hidden_states=xd, timestep=td, return_dict=False, **kwd)[0].clone()
+        assert bool(torch.isfinite(ref).all())
         _lib.check(lib.mc_set_option(b"mmdit_two_streams", 1))
         for rep in range(300):
             got = m(hidden_states=xd, timestep=td, return_dict=False, **kwd)[0]
             assert torch.equal(got, ref), f"replay {rep}: two-stream forward differs from the one-stream forward"
     finally:
-        _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))
+        _lib.check(lib.mc_set_option(b"mmdit_two_streams", -1))

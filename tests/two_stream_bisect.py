@@ -133,6 +133,7 @@ def main():
         torch.cuda.synchronize()
         return snaps if sync_between else out.clone()
 
+    _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))   # the references are one-stream runs
     run(False)          # warm-up: every buffer holds the end state of a forward from here on
     ref = run(True)
     again = run(True, ref)
@@ -174,7 +175,7 @@ def two_stream_replays(lib, run, ref, ref_out, mode=1):
                 bad2 += 1
         print(f"two streams, no host sync inside a forward: {bad2} of {soak} replays differ")
     finally:
-        _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))
+        _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))   # back to one stream for the next reference
 
 
 if __name__ == "__main__":
