@@ -222,8 +222,9 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernels", action="store_true")
     ap.add_argument("--no_nocache", action="store_true", help="skip the second (cache off) timed region")
-    ap.add_argument("--fp8_linear", action="store_true",
-                    help="OPTIONAL precision mode, never the headline: QKV / FFN Linears on the fp8 e4m3 MFMA path")
+    ap.add_argument("--fp8_linear", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2),
+                    help="OPTIONAL precision mode, never the headline: QKV / FFN Linears on an fp8 e4m3 MFMA path "
+                         "(1: per-row / per-channel scales, 2: MX block scales)")
     ap.add_argument("--layout", choices=("auto", "sp", "cfg2sp"), default="auto",
                     help="N > 1: 'sp' = the token sequence sharded over all N ranks, one K/V all-gather per layer "
                          "(north_star's split); 'cfg2sp' = CFG branches on two halves of the node x sequence parallel "
@@ -249,7 +250,7 @@ def main():
     from magcache_amd.mag_ratios import TABLES
     from magcache_amd.sampler import sample
 
-    cfg = dict(WAN_T2V_1_3B, fp8_linear=True) if args.fp8_linear else WAN_T2V_1_3B
+    cfg = dict(WAN_T2V_1_3B, fp8_linear=args.fp8_linear) if args.fp8_linear else WAN_T2V_1_3B
     g = torch.Generator(device=device).manual_seed(42)
     noise = torch.randn(16, *GRID, generator=g, device=device)
     ctx = torch.randn(512, cfg["text_dim"], generator=g, device=device)
@@ -380,7 +381,8 @@ def main():
             "value": args.steps / t_mc, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": t_mc / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16 + fp8(e4m3) QKV/FFN Linears (reduced precision: NOT the headline)" if args.fp8_linear else "bf16",
+            "dtype": (f"bf16 + {'MX block-scaled ' if args.fp8_linear == 2 else ''}fp8(e4m3) QKV/FFN Linears (reduced precision: NOT the headline)"
+                      if args.fp8_linear else "bf16"),
             "data": "synthetic",
             "config": {"workload": "Wan2.1-T2V-1.3B 832x480 81 frames: latent 16x21x60x104, 32760 tokens, "
                                    "30 layers d=1536 12 heads ffn=8960; cond+uncond per step, CFG 5.0, flow-Euler; "

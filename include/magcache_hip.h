@@ -66,7 +66,9 @@ typedef struct {
   int vace_in_dim;      /*   channels of vace_context (96)                                                             */
   int fp8_linear;       /* 1: the three large Linears of every block (QKV, FFN-1, FFN-2) run on the fp8 (OCP e4m3) MFMA
                            path: weights quantised per output channel at mc_set_weight, activations per token on the
-                           fly; a speed / quality option (~3 % relative error per GEMM), never the default */
+                           fly; a speed / quality option (~3 % relative error per GEMM), never the default.
+                           2: the same Linears on MX block-scaled fp8 (one E8M0 scale per 32 input features of every
+                           token and of every output channel, v_mfma_scale_f32_16x16x128_f8f6f4; mc_op_gemm_mxfp8) */
 } mc_config;
 
 const char* mc_last_error(void);
@@ -224,6 +226,16 @@ mc_status mc_op_quantize_rows_fp8(const void* x_dev, mc_dtype dtype, long ldx, i
 mc_status mc_op_gemm_fp8(const void* A_q_dev, long lda, const float* a_scale_dev, const void* W_q_dev, long ldw,
                          const float* w_scale_dev, const float* bias_dev, int M, int N, int K, int epi, void* Cb_dev,
                          long ldc, float* X_dev, long ldx, const float* gate_dev, mc_stream stream);
+/* MX block-scaled fp8 (OCP microscaling: e4m3 elements, one E8M0 scale byte per (row, 32 consecutive k), multiplied by the
+ * matrix core: v_mfma_scale_f32_16x16x128_f8f6f4; mc_config.fp8_linear = 2).  Scales are stored block-major:
+ * scales[kb * rows_pad + row].  quantize: e = ceil(log2(max|block| / 448)) (clamped to [-127, 127]), q = e4m3(x * 2^-e),
+ * scale byte e + 127.  gemm: C = sum_kb 2^(sa - 127) 2^(sw - 127) (A_q[:, kb] . W_q[:, kb]^T) + bias, same epilogues. */
+mc_status mc_op_quantize_rows_mx(const void* x_dev, mc_dtype dtype, long ldx, int M, int K, void* q_dev, long ldq,
+                                 void* scales_dev, long rows_pad, mc_stream stream);
+mc_status mc_op_gemm_mxfp8(const void* A_q_dev, long lda, const void* a_scales_dev, long rows_pad_a, const void* W_q_dev,
+                           long ldw, const void* w_scales_dev, long rows_pad_w, const float* bias_dev, int M, int N, int K,
+                           int epi, void* Cb_dev, long ldc, float* X_dev, long ldx, const float* gate_dev,
+                           mc_stream stream);
 /* attention: head_dim 128; Q rows Lq_pad (multiple of 256); KV = n_shards shards of shard_rows rows
  * (multiple of 64), the first shard_valid of each valid */
 mc_status mc_op_attention(const void* Q_dev, long ldq, const void* K_dev, long ldk, long k_shard_stride,

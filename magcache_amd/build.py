@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagcache_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_big.hip", "gemm_fp8_big.hip", "attention_v3.hip", "attention_v4.hip", "elementwise.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_big.hip", "gemm_fp8_big.hip", "gemm_mxfp8.hip", "attention_v3.hip", "attention_v4.hip", "elementwise.hip",
            "magcache_ops.hip", "engine.cpp", "mmdit_engine.cpp", "rule.cpp"]
 # the attention kernel's hand-interleaved VALU stream must stay scalar: the SLP vectoriser packs the row-sum
 # adds into v_pk_add_f32 and moves them out of the MFMA shadow

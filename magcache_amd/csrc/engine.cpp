@@ -50,6 +50,9 @@ struct Slot {  // one named parameter
   uint8_t* q8 = nullptr;
   float* q8_scale = nullptr;
   size_t q8_k = 0;  // row length (in_features)
+  // fp8_linear == 2 (MX): E8M0 block scales of the fused destination, block-major with mx_rows rows per k block
+  uint8_t* mx = nullptr;
+  size_t mx_rows = 0;
 };
 
 struct Layer {
@@ -61,6 +64,7 @@ struct Layer {
   // fp8_linear: e4m3 copies of the three large Linears + per-output-channel scales
   uint8_t *q_wqkv = nullptr, *q_w1 = nullptr, *q_w2 = nullptr;
   float *s_wqkv = nullptr, *s_w1 = nullptr, *s_w2 = nullptr;
+  uint8_t *m_wqkv = nullptr, *m_w1 = nullptr, *m_w2 = nullptr;   // fp8_linear == 2: MX block scales [K/32][N]
 };
 
 struct Buf {
@@ -231,6 +235,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (c.vace_layers < 0 || (c.vace_layers > 0 && (c.vace_stride <= 0 || c.vace_in_dim <= 0 ||
                                                    (c.vace_layers - 1) * c.vace_stride >= c.num_layers)))
     return fail(MC_EINVAL, "bad VACE geometry: %d blocks, stride %d, in_dim %d", c.vace_layers, c.vace_stride, c.vace_in_dim);
+  if (c.fp8_linear < 0 || c.fp8_linear > 2) return fail(MC_EINVAL, "fp8_linear must be 0, 1 (per-row scales) or 2 (MX block scales)");
   if (c.fp8_linear && ((c.dim % 256) || (c.ffn_dim % 256) || c.dim < 512 || c.ffn_dim < 512))
     return fail(MC_EINVAL, "fp8_linear needs dim and ffn_dim to be multiples of 256 and >= 512");
   if (c.vace_layers > 0 && c.sp_size > 1 && (c.vace_layers - 1) * c.vace_stride == c.num_layers - 1)
@@ -311,6 +316,15 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
       s1.q8 = l.q_w1; s1.q8_scale = l.s_w1; s1.q8_k = d;
       Slot& s2 = e->slots[p + "ffn.2.weight"];
       s2.q8 = l.q_w2; s2.q8_scale = l.s_w2; s2.q8_k = ffn;
+      if (c.fp8_linear == 2) {   // MX: one E8M0 byte per (output channel, 32 input features), block-major
+        ALLOC(l.m_wqkv, (d / 32) * 3 * d); ALLOC(l.m_w1, (d / 32) * ffn); ALLOC(l.m_w2, (ffn / 32) * d);
+        for (int j = 0; j < 3; ++j) {
+          Slot& sl = e->slots[p + qkv_names[j]];
+          sl.mx = l.m_wqkv; sl.mx_rows = 3 * d;
+        }
+        s1.mx = l.m_w1; s1.mx_rows = ffn;
+        s2.mx = l.m_w2; s2.mx_rows = d;
+      }
     }
     if (c.clip_dim > 0) {
       ALLOC(l.wckv_img, 2 * d * d); ALLOC(l.bckv_img, 2 * d); ALLOC(l.cnk_img, d);
@@ -414,6 +428,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (c.fp8_linear) {
     add_buf(e, cur, "aq", Lp * std::max(d, ffn));            // e4m3 activations of the current fp8 GEMM
     add_buf(e, cur, "a_scale", Lp * 4);                      // their per-token scales
+    if (c.fp8_linear == 2) add_buf(e, cur, "a_mx", (std::max(d, ffn) / 32) * Lp);   // MX: per (token, 32 k) block scales
   }
   if (e->NV > 0) {
     add_buf(e, cur, "xc", Lp * d * 4);                       // VACE control stream c (fp32 like x)
@@ -523,8 +538,13 @@ mc_status mc_set_weight(mc_engine* e, const char* name, const void* src_dev, mc_
     }
     if (s.q8) {  // fp8 weight path: e4m3 copy of the rows just stored, one scale per output channel
       const size_t rows = numel / s.q8_k, row0 = s.row_off / s.q8_k;
-      HIP_TRY(mc::launch_quantize_rows_fp8(dst, nullptr, (long)s.q8_k, (int)rows, (int)s.q8_k, s.q8 + s.row_off,
-                                           (long)s.q8_k, s.q8_scale + row0, stream));
+      if (s.mx) {  // MX: the e4m3 bytes are relative to the block scales, not to a row scale
+        HIP_TRY(mc::launch_quantize_rows_mx(dst, nullptr, (long)s.q8_k, (int)rows, (int)s.q8_k, s.q8 + s.row_off,
+                                            (long)s.q8_k, s.mx + row0, (long)s.mx_rows, stream));
+      } else {
+        HIP_TRY(mc::launch_quantize_rows_fp8(dst, nullptr, (long)s.q8_k, (int)rows, (int)s.q8_k, s.q8 + s.row_off,
+                                             (long)s.q8_k, s.q8_scale + row0, stream));
+      }
     }
   }
   s.loaded = true;
@@ -710,12 +730,21 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
 // LN + modulate -> q,k,v Linear -> RMSNorm(q), RMSNorm(k) -> RoPE(q,k)      (upstream WanSelfAttention)
 // fp8_linear: y = epilogue((quantise_rows(A) . Wq^T) * a_scale * w_scale + bias): per-token activation scales are
 // computed here (one pass over the bf16 rows), the weights were quantised per output channel at load time.
+// fp8_linear == 2 (wm != null): MX block scales instead -- activations per (token, 32 k), weights per (channel, 32 k),
+// multiplied inside the matrix core (gemm_mxfp8.hip).
 static mc_status gemm_fp8_rows(mc_engine* e, const bf16_t* A, long lda, int M, int K, const uint8_t* Wq, const float* ws,
-                               mc::GemmParams p, int epi, hipStream_t s) {
+                               const uint8_t* wm, mc::GemmParams p, int epi, hipStream_t s) {
   uint8_t* aq = e->buf<uint8_t>("aq");
+  p.A = (const bf16_t*)aq; p.lda = K; p.W = (const bf16_t*)Wq; p.ldw = K; p.K = K;
+  if (wm) {
+    uint8_t* am = e->buf<uint8_t>("a_mx");
+    HIP_TRY(mc::launch_quantize_rows_mx(A, nullptr, lda, M, K, aq, K, am, (long)e->Lp, s));
+    p.a_mx = am; p.mx_rows_a = (long)e->Lp; p.w_mx = wm; p.mx_rows_w = p.N;
+    HIP_TRY(mc::launch_gemm_mxfp8(p, epi, s));
+    return MC_OK;
+  }
   float* as = e->buf<float>("a_scale");
   HIP_TRY(mc::launch_quantize_rows_fp8(A, nullptr, lda, M, K, aq, K, as, s));
-  p.A = (const bf16_t*)aq; p.lda = K; p.W = (const bf16_t*)Wq; p.ldw = K; p.K = K;
   p.a_scale = as; p.w_scale = ws;
   HIP_TRY(mc::launch_gemm_fp8(p, epi, s));
   return MC_OK;
@@ -741,7 +770,7 @@ static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float*
     mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
     if (l.q_wqkv) {
-      mc_status st = gemm_fp8_rows(e, xn, d, Lp, d, l.q_wqkv, l.s_wqkv, p, mc::EPI_BF16, s);
+      mc_status st = gemm_fp8_rows(e, xn, d, Lp, d, l.q_wqkv, l.s_wqkv, l.m_wqkv, p, mc::EPI_BF16, s);
       if (st != MC_OK) return st;
     } else {
       HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
@@ -895,7 +924,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     mc::GemmParams p = gp(xn, d, l.w1, d, l.b1, Lp, ffn, d);
     p.Cb = h; p.ldc = ffn;
     if (l.q_w1) {
-      mc_status st = gemm_fp8_rows(e, xn, d, Lp, d, l.q_w1, l.s_w1, p, mc::EPI_GELU_BF16, s);
+      mc_status st = gemm_fp8_rows(e, xn, d, Lp, d, l.q_w1, l.s_w1, l.m_w1, p, mc::EPI_GELU_BF16, s);
       if (st != MC_OK) return st;
     } else {
       HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
@@ -905,7 +934,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     if (em2) { q.gate2 = em2 + 5 * d; q.gate_sel = sel; }
     const bool f8 = l.q_w2 != nullptr;
     auto ffn2 = [&](int epi) -> mc_status {
-      if (f8) return gemm_fp8_rows(e, h, ffn, Lp, ffn, l.q_w2, l.s_w2, q, epi, s);
+      if (f8) return gemm_fp8_rows(e, h, ffn, Lp, ffn, l.q_w2, l.s_w2, l.m_w2, q, epi, s);
       HIP_TRY(mc::launch_gemm_bf16(q, epi, s));
       return MC_OK;
     };
@@ -1233,6 +1262,31 @@ mc_status mc_op_gemm_fp8(const void* A, long lda, const float* a_scale, const vo
   hipError_t err = mc::launch_gemm_fp8(p, epi, (hipStream_t)s);
   if (err == hipErrorInvalidValue)
     return fail(MC_EINVAL, "gemm_fp8: needs N %% 256 == 0, K %% 256 == 0, K >= 512, lda/ldw %% 16 == 0, both scale vectors");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_quantize_rows_mx(const void* x, mc_dtype dtype, long ldx, int M, int K, void* q, long ldq, void* scales,
+                                 long rows_pad, mc_stream s) {
+  hipError_t err = mc::launch_quantize_rows_mx(dtype == MC_BF16 ? (const bf16_t*)x : nullptr,
+                                               dtype == MC_F32 ? (const float*)x : nullptr, ldx, M, K, (uint8_t*)q, ldq,
+                                               (uint8_t*)scales, rows_pad, (hipStream_t)s);
+  if (err == hipErrorInvalidValue)
+    return fail(MC_EINVAL, "quantize_rows_mx: K %% 32 == 0, ldx %% 8 == 0, ldq %% 16 == 0, rows_pad >= M");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_gemm_mxfp8(const void* A, long lda, const void* a_scales, long rows_pad_a, const void* W, long ldw,
+                           const void* w_scales, long rows_pad_w, const float* bias, int M, int N, int K, int epi, void* Cb,
+                           long ldc, float* X, long ldx, const float* gate, mc_stream s) {
+  mc::GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, M, N, K);
+  p.a_mx = (const uint8_t*)a_scales; p.mx_rows_a = rows_pad_a; p.w_mx = (const uint8_t*)w_scales; p.mx_rows_w = rows_pad_w;
+  p.Cb = (bf16_t*)Cb; p.ldc = ldc; p.X = X; p.ldx = ldx; p.gate = gate;
+  hipError_t err = mc::launch_gemm_mxfp8(p, epi, (hipStream_t)s);
+  if (err == hipErrorInvalidValue)
+    return fail(MC_EINVAL, "gemm_mxfp8: needs N %% 256 == 0, K %% 256 == 0, K >= 512, lda/ldw %% 16 == 0, block scales with "
+                           "rows_pad_a >= M rounded up to 256, rows_pad_w >= N, both multiples of 4");
   HIP_TRY(err);
   return MC_OK;
 }

@@ -39,6 +39,10 @@ struct GemmParams {
   // fp8 GEMM (launch_gemm_fp8): A / W point to OCP e4m3 bytes, C = (A W^T) * a_scale[m] * w_scale[n] + bias
   const float* a_scale;
   const float* w_scale;
+  // MX fp8 GEMM (launch_gemm_mxfp8): A / W point to e4m3 bytes (lda / ldw in bytes), a_mx / w_mx to E8M0 scale bytes,
+  // block-major: scale of (row, k block kb of 32) at [kb * mx_rows + row]
+  const uint8_t* a_mx; long mx_rows_a;
+  const uint8_t* w_mx; long mx_rows_w;
 };
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
@@ -54,6 +58,13 @@ bool gemm_fp8_supported(const GemmParams& p);
 // x bf16 (x_f32 null) or fp32.  Used for activations (per token) and for weights (per output channel).
 hipError_t launch_quantize_rows_fp8(const bf16_t* x, const float* x_f32, long ldx, int M, int K, uint8_t* q, long ldq,
                                     float* scale, hipStream_t stream);
+
+// MX block-scaled fp8 (gemm_mxfp8.hip): v_mfma_scale_f32_16x16x128_f8f6f4, one E8M0 scale per (row, 32 k)
+hipError_t launch_gemm_mxfp8(const GemmParams& p, int epi, hipStream_t stream);
+bool gemm_mxfp8_supported(const GemmParams& p);
+// q[m, kb*32 .. +31] = e4m3(x * 2^-e), e = ceil(log2(max|block| / 448)), scale byte e + 127 at s[kb * rows_pad + m]
+hipError_t launch_quantize_rows_mx(const bf16_t* x, const float* x_f32, long ldx, int M, int K, uint8_t* q, long ldq,
+                                   uint8_t* s, long rows_pad, hipStream_t stream);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 struct AttnParams {

@@ -42,6 +42,35 @@ def quantize_rows_fp8(x):
     return q, s
 
 
+def quantize_rows_mx(x):
+    """x [M, K] bf16 or fp32 -> (q uint8 [M, K] e4m3, scales uint8 [K/32, rows_pad] E8M0, block-major, rows interleaved
+    16 x 4 inside groups of 64: see mx_unpermute)"""
+    lib = _lib.load()
+    M, K = x.shape
+    rows_pad = (M + 255) // 256 * 256
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    s = torch.full((K // 32, rows_pad), 127, dtype=torch.uint8, device=x.device)
+    check(lib.mc_op_quantize_rows_mx(P(x), _lib.MC_BF16 if x.dtype == torch.bfloat16 else _lib.MC_F32, x.stride(0), M, K,
+                                     P(q), q.stride(0), P(s), rows_pad, S()))
+    return q, s
+
+
+def mx_unpermute(s, M):
+    """scales [K/32, rows_pad] in the kernel's row order -> [M, K/32] in natural order"""
+    rows = torch.arange(M, device=s.device)
+    pos = (rows & ~63) | ((rows & 15) << 2) | ((rows >> 4) & 3)
+    return s[:, pos].t().contiguous()
+
+
+def gemm_mxfp8(Aq, sa, Wq, sw, bias, epi, Cb=None, X=None, gate=None):
+    lib = _lib.load()
+    M, K = Aq.shape
+    N = Wq.shape[0]
+    check(lib.mc_op_gemm_mxfp8(P(Aq), Aq.stride(0), P(sa), sa.shape[1], P(Wq), Wq.stride(0), P(sw), sw.shape[1], P(bias),
+                               M, N, K, epi, P(Cb), Cb.stride(0) if Cb is not None else 0,
+                               P(X), X.stride(0) if X is not None else 0, P(gate), S()))
+
+
 def gemm_fp8(Aq, sa, Wq, sw, bias, epi, Cb=None, X=None, gate=None):
     lib = _lib.load()
     M, K = Aq.shape

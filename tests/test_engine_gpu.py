@@ -205,10 +205,11 @@ def test_wan21_vace_forward_and_magcache_run_vs_reference_golden(golden_dir):
 
 
 def test_fp8_linear_option_forward_vs_oracle():
-    """fp8_linear=1 (BASELINE.json config 4's "fp8 MFMA weight path"): QKV, FFN-1 and FFN-2 of every block run on the
-    e4m3 MFMA kernel (per-channel weight scales, per-token activation scales).  Tolerance: fp8 e4m3 carries 3 mantissa
-    bits (2^-4 relative per element), so the forward is held to 8e-2 relative L2 of the fp32 oracle -- and it must
-    differ measurably from the bf16 engine (the option really switches kernels)."""
+    """fp8_linear (BASELINE.json config 4's "fp8 MFMA weight path"): QKV, FFN-1 and FFN-2 of every block run on an e4m3
+    MFMA kernel -- 1: per-channel weight scales and per-token activation scales (gemm_fp8_big.hip), 2: MX block scales,
+    one E8M0 per 32 input features of every token / channel, multiplied inside the matrix core (gemm_mxfp8.hip).
+    Tolerance: fp8 e4m3 carries 3 mantissa bits (2^-4 relative per element), so the forward is held to 8e-2 relative L2
+    of the fp32 oracle -- and it must differ measurably from the bf16 engine (the option really switches kernels)."""
     cfg = W.tiny_config(num_layers=2, num_heads=4, ffn_dim=1024, text_len=64, text_dim=128, freq_dim=64)
     grid = (2, 16, 20)
     L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
@@ -220,17 +221,20 @@ def test_fp8_linear_option_forward_vs_oracle():
     oracle.set_fp32_attention(True)
     ref_32 = oracle.forward([lat], t, [ctx], L, autocast=False)[0]
     outs = {}
-    for fp8 in (False, True):
-        cls = type(f"WanHIPfp8_{int(fp8)}", (M.WanModelHIP,), {})
+    for fp8 in (0, 1, 2):
+        cls = type(f"WanHIPfp8_{fp8}", (M.WanModelHIP,), {})
         m = cls(dict(cfg, fp8_linear=fp8), grid, device=DEV, calibration=False)
         m.load_state_dict(oracle.state_dict())
         outs[fp8] = m([lat.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L)[0]
-    e16, e8 = rel_l2(outs[False], ref_32), rel_l2(outs[True], ref_32)
-    assert e16 < 2e-2 and e8 < 8e-2, (e16, e8)
-    assert rel_l2(outs[True], outs[False]) > 2e-3
-    assert MR.psnr(outs[True].cpu().numpy(), ref_32.numpy(), data_range=float(ref_32.abs().max())) > 25.0
-    with pytest.raises(_lib.MagCacheHipError):       # shapes the fp8 kernel cannot tile
+    e16, e8, emx = (rel_l2(outs[k], ref_32) for k in (0, 1, 2))
+    assert e16 < 2e-2 and e8 < 8e-2 and emx < 8e-2, (e16, e8, emx)
+    assert rel_l2(outs[1], outs[0]) > 2e-3 and rel_l2(outs[2], outs[0]) > 2e-3 and rel_l2(outs[2], outs[1]) > 1e-4
+    for k in (1, 2):
+        assert MR.psnr(outs[k].cpu().numpy(), ref_32.numpy(), data_range=float(ref_32.abs().max())) > 25.0
+    with pytest.raises(_lib.MagCacheHipError):       # shapes the fp8 kernels cannot tile
         Engine(dict(W.tiny_config(), fp8_linear=True), grid, device=DEV)
+    with pytest.raises(_lib.MagCacheHipError):
+        Engine(dict(cfg, fp8_linear=3), grid, device=DEV)
 
 
 @pytest.mark.parametrize("solver", ["unipc", "dpm++"])

@@ -90,3 +90,93 @@ def test_fragment_reads_are_bank_conflict_free():
                 slots.add((off // 16) % 16)
             assert len(slots) == 16
 
+
+
+# ------------------------------------------------------------------------------------- MX block-scaled fp8 kernel
+def mx_perm(row):
+    """row order of the E8M0 scale arrays (csrc/gemm_mxfp8.hip): groups of 64 rows, interleaved 16 x 4"""
+    return (row & ~63) | ((row & 15) << 2) | ((row >> 4) & 3)
+
+
+def test_mx_kernel_one_k_tile_reproduces_the_block_scaled_product():
+    """csrc/gemm_mxfp8.hip, one K tile (128 fp8 k = 4 MX blocks of 32): the LDS images are the bf16 kernel's with 16
+    one-byte elements per 16-byte chunk; a lane's fragment = chunk kgrp and (address ^ 64) = chunk 4 + kgrp; its scale
+    dword = the bytes of the four 16-row blocks of its 64-row group at k block kgrp, the MFMA's op_sel picks byte mb (A) /
+    2 nh + nb (W).  v_mfma_scale_f32_16x16x128_f8f6f4 as probed on the hardware (tools/ubench_mx_probe.cpp,
+    profiles/r02/mx_probe.log): lane (row i, group g) holds k = 16 g + 0..15 and 64 + 16 g + 0..15; the scale byte of
+    lane group g multiplies MX block g = k 32 g .. 32 g + 31 of its row:
+    D[i][j] += sum_b 2^(sA[i][b] + sB[j][b] - 254) * dot(A[i][32b..32b+31], B[j][32b..32b+31])."""
+    rng = np.random.default_rng(2)
+    A = rng.integers(-8, 9, size=(256, 128)).astype(np.float64)     # stand-ins for e4m3 values
+    W = rng.integers(-8, 9, size=(256, 128)).astype(np.float64)
+    eA = rng.integers(-3, 4, size=(256, 4))                         # block exponents (scale byte - 127)
+    eW = rng.integers(-3, 4, size=(256, 4))
+    want = np.zeros((256, 256))
+    for g in range(4):
+        want += (A[:, 32 * g:32 * g + 32] * 2.0 ** eA[:, g:g + 1]) @ (W[:, 32 * g:32 * g + 32] * 2.0 ** eW[:, g:g + 1]).T
+
+    def image(src, half, which):    # lds_image() of the bf16 kernel with 16 elements per chunk
+        img = np.zeros((HALF_ROWS, 8, 16))
+        for wv in range(8):
+            for j in range(2):
+                for lane in range(64):
+                    r = (wv * 2 + j) * 8 + (lane >> 3)
+                    chunk = (lane & 7) ^ ((r >> 1) & 7)
+                    row = (r >> 6) * 128 + half * 64 + (r & 63) if which == "A" else (r >> 5) * 64 + half * 32 + (r & 31)
+                    img[r, lane & 7] = src[row, chunk * 16:chunk * 16 + 16]
+        return img
+
+    def frag(img, base_row, blk, lane):
+        l15, kgrp = lane & 15, lane >> 4
+        off0 = (base_row + blk * 16 + l15) * ROW_BYTES + ((kgrp ^ (l15 >> 1)) << 4)
+        off1 = off0 ^ 64
+        return np.concatenate([img[off0 // ROW_BYTES, (off0 % ROW_BYTES) // 16], img[off1 // ROW_BYTES, (off1 % ROW_BYTES) // 16]])
+
+    def hw_rows(f):
+        """the 16 x 128 operand the hardware sees: lane (i, g) byte p -> k = 16 g + p (p < 16) / 64 + 16 g + p - 16"""
+        m = np.zeros((16, 128))
+        for lane in range(64):
+            i, g = lane & 15, lane >> 4
+            m[i, 16 * g:16 * g + 16] = f[lane][:16]
+            m[i, 64 + 16 * g:64 + 16 * g + 16] = f[lane][16:]
+        return m
+
+    def scale_image(e):             # [4 k blocks][256 permuted rows], as the quantiser stores a K tile's scales
+        img = np.zeros((4, 256), dtype=np.int64)
+        for row in range(256):
+            img[:, mx_perm(row)] = e[row]
+        return img
+    sA, sW = scale_image(eA), scale_image(eW)
+    halves = {("A", h): image(A, h, "A") for h in (0, 1)}
+    halves.update({("W", h): image(W, h, "W") for h in (0, 1)})
+    C = np.full((256, 256), np.nan)
+    for wv in range(8):
+        wr, wc = wv >> 2, wv & 3
+        for mh in range(2):
+            for nh in range(2):
+                for mb in range(4):
+                    for nb in range(2):
+                        Am = hw_rows(np.stack([frag(halves[("W", nh)], wc * 32, nb, l) for l in range(64)]))   # first operand = W
+                        Bm = hw_rows(np.stack([frag(halves[("A", mh)], wr * 64, mb, l) for l in range(64)]))
+                        D = np.zeros((16, 16))
+                        for b in range(4):          # MX block b: scale bytes supplied by lane group b
+                            sa = np.array([sW[b, wc * 64 + (l15 << 2) + (2 * nh + nb)] for l15 in range(16)])
+                            sb = np.array([sA[b, (2 * wr + mh) * 64 + (l15 << 2) + mb] for l15 in range(16)])
+                            D += (Am[:, 32 * b:32 * b + 32] * 2.0 ** sa[:, None]) @ (Bm[:, 32 * b:32 * b + 32] * 2.0 ** sb[:, None]).T
+                        for l in range(64):
+                            m = wr * 128 + mh * 64 + mb * 16 + (l & 15)
+                            n = wc * 64 + nh * 32 + nb * 16 + 4 * (l >> 4)
+                            assert np.isnan(C[m, n:n + 4]).all()
+                            C[m, n:n + 4] = [D[4 * (l >> 4) + reg, l & 15] for reg in range(4)]
+    assert not np.isnan(C).any()
+    np.testing.assert_allclose(C, want, rtol=1e-12, atol=1e-9)
+
+
+def test_mx_scale_reads_are_bank_conflict_free():
+    """ds_read_b32 is served 32 lanes at a time; address = kgrp * 320 + group * 64 + l15 * 4: 32 distinct banks"""
+    for half in (0, 1):
+        banks = set()
+        for lane in range(32 * half, 32 * half + 32):
+            addr = (lane >> 4) * 320 + (lane & 15) * 4
+            banks.add((addr // 4) % 64)
+        assert len(banks) == 32

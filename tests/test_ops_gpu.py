@@ -2,6 +2,7 @@
 op (floating-point kernels; tolerances stated per test), plus size-independent properties at the
 full Wan2.1-1.3B 480p shape (L = 32760, d = 1536, 12 heads)."""
 import math
+import os
 
 import numpy as np  # noqa: F401
 import pytest
@@ -130,6 +131,103 @@ def test_gemm_fp8_vs_dequantised_reference(M, N, K):
     x, gate = x0.clone(), rnd(N, seed=6)
     H.gemm_fp8(aq, sa, wq, sw, bias, 2, X=x, gate=gate)
     torch.testing.assert_close(x, x0 + gate * want.float().to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)
+
+
+def mx_quantize_ref(x):
+    """torch restatement of quantize_rows_mx: per (row, 32 k) block e = ceil(log2(amax / 448)) through frexp of
+    amax * fl32(1/448), elements e4m3fn(x * 2^-e), scale byte e + 127."""
+    M, K = x.shape
+    xb = x.float().view(M, K // 32, 32)
+    amax = xb.abs().amax(dim=-1)
+    f, ex = torch.frexp(amax * torch.tensor(1.0 / 448.0, dtype=torch.float32, device=x.device))
+    e = torch.where(f == 0.5, ex - 1, ex).clamp(-127, 127)
+    e = torch.where(amax > 0, e, torch.full_like(e, -127))
+    q = (xb * torch.exp2(-e.float())[..., None]).to(torch.float8_e4m3fn)
+    return q.view(M, K), (e + 127).to(torch.uint8)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (512, 512, 1024), (1024, 1536, 1536), (512, 256, 8960 - 8960 % 256)])
+def test_gemm_mxfp8_vs_dequantised_reference(M, N, K):
+    """MX block-scaled fp8 (v_mfma_scale_f32_16x16x128_f8f6f4, one E8M0 scale per row and 32 k): (1) the quantiser
+    equals its torch restatement byte for byte (elements and scales); (2) the GEMM equals the product of the
+    DEQUANTISED operands (exact products and power-of-two scales, fp32 accumulation order aside); (3) it is closer to
+    the unquantised product than the per-row-scaled fp8 path when a row mixes magnitudes (the point of block scales)."""
+    a = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    a[:, 3] *= 30.0                                   # an outlier column: only its own 32-block pays for it
+    a[5, 64:96] = 0                                   # an all-zero block
+    w = rnd(N, K, seed=2, scale=0.05).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    aq, sa = H.quantize_rows_mx(a)
+    wq, sw = H.quantize_rows_mx(w)
+    want_q, want_s = mx_quantize_ref(a)
+    assert torch.equal(H.mx_unpermute(sa, M), want_s)
+    assert torch.equal(aq.view(torch.float8_e4m3fn).float(), want_q.float())
+    wq_ref, ws_ref = mx_quantize_ref(w)
+    assert torch.equal(H.mx_unpermute(sw, N), ws_ref) and torch.equal(wq.view(torch.float8_e4m3fn).float(), wq_ref.float())
+
+    def deq(q, s):
+        e = s.float() - 127.0
+        return (q.view(torch.float8_e4m3fn).float().view(q.shape[0], -1, 32) * torch.exp2(e)[..., None]).view(q.shape).double()
+    ad, wd = deq(aq, want_s), deq(wq, ws_ref)
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    H.gemm_mxfp8(aq, sa, wq, sw, bias, 5, X=out)
+    want = ad @ wd.t() + bias.double()
+    # the products and the power-of-two scales are exact; what differs is the fp32 summation inside the matrix core
+    assert rel_l2(out, want.float()) < 2e-6
+    torch.testing.assert_close(out.double(), want, rtol=2e-3, atol=5e-3)
+    full = a.double() @ w.double().t() + bias.double()
+    err_mx = rel_l2(out, full.float())
+    assert err_mx < 4e-2, err_mx
+    aq1, sa1 = H.quantize_rows_fp8(a)
+    wq1, sw1 = H.quantize_rows_fp8(w)
+    out1 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    H.gemm_fp8(aq1, sa1, wq1, sw1, bias, 5, X=out1)
+    assert err_mx < rel_l2(out1, full.float()), (err_mx, rel_l2(out1, full.float()))
+    # bf16 store, GELU and gated-residual epilogues
+    cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    H.gemm_mxfp8(aq, sa, wq, sw, bias, 0, Cb=cb)
+    torch.testing.assert_close(cb.float(), want.float(), rtol=1e-2, atol=1e-2)
+    H.gemm_mxfp8(aq, sa, wq, sw, bias, 1, Cb=cb)
+    torch.testing.assert_close(cb.float(), F.gelu(want.float().bfloat16().float(), approximate="tanh"), rtol=2e-2, atol=2e-2)
+    x0 = rnd(M, N, seed=5)
+    x, gate = x0.clone(), rnd(N, seed=6)
+    H.gemm_mxfp8(aq, sa, wq, sw, bias, 2, X=x, gate=gate)
+    torch.testing.assert_close(x, x0 + gate * want.float().to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)
+
+
+def test_gemm_mxfp8_speed_vs_bf16():
+    """informational: the MX fp8 kernel against the bf16 256x256 kernel and the per-row fp8 kernel on the FFN-1 shape"""
+    M, N, K = 32768, 8960 - 8960 % 256, 1536
+    a = rnd(M, K, seed=1, dtype=torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=0.05, dtype=torch.bfloat16)
+    aq, sa = H.quantize_rows_mx(a)
+    wq, sw = H.quantize_rows_mx(w)
+    aq1, sa1 = H.quantize_rows_fp8(a)
+    wq1, sw1 = H.quantize_rows_fp8(w)
+    cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+
+    def timed(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    tmx = timed(lambda: H.gemm_mxfp8(aq, sa, wq, sw, None, 1, Cb=cb))
+    t8 = timed(lambda: H.gemm_fp8(aq1, sa1, wq1, sw1, None, 1, Cb=cb))
+    t16 = timed(lambda: H.gemm(a, w, None, 1, Cb=cb))
+    tq = timed(lambda: H.quantize_rows_mx(a))
+    fl = 2.0 * M * N * K
+    print(f"\nMX fp8 {tmx:.3f} ms {fl / tmx / 1e9:.0f} TF | per-row fp8 {t8:.3f} ms {fl / t8 / 1e9:.0f} TF | "
+          f"bf16 {t16:.3f} ms {fl / t16 / 1e9:.0f} TF | MX quantise A {tq:.3f} ms")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/mxfp8_speed.log", "w") as fh:
+        fh.write(f"FFN-1 shape M {M} N {N} K {K}, GELU epilogue: MX fp8 {tmx:.4f} ms {fl / tmx / 1e9:.0f} TF | per-row fp8 "
+                 f"{t8:.4f} ms {fl / t8 / 1e9:.0f} TF | bf16 {t16:.4f} ms {fl / t16 / 1e9:.0f} TF | MX quantise A {tq:.4f} ms\n")
+    assert tmx < t16
 
 
 def test_gemm_fp8_speed_vs_bf16():
