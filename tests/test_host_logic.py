@@ -76,6 +76,27 @@ def test_c_rule_rejects_bad_arguments():
     assert not lib.mc_rule_create(0, 4, 0.1, 2, 0.2, arr, 0, 0)    # empty table
 
 
+def test_set_option_validates_keys_and_values():
+    """mc_set_option is host state only (no GPU): every documented key takes its documented values and nothing else."""
+    lib = _lib.load()
+    ok = {b"gemm_kernel": (0, 1, 2), b"attn_kernel": (0, 3, 4), b"mmdit_two_streams": (-1, 0, 1, 2, 6)}
+    bad = {b"gemm_kernel": (-1, 3, 4, 9), b"attn_kernel": (1, 2, 5), b"mmdit_two_streams": (-2, 7)}
+    try:
+        for key, vals in ok.items():
+            for v in vals:
+                assert lib.mc_set_option(key, v) == _lib.MC_OK, (key, v)
+        for key, vals in bad.items():
+            for v in vals:
+                assert lib.mc_set_option(key, v) == _lib.MC_EINVAL, (key, v)
+                assert key.decode() in lib.mc_last_error().decode() or "must be" in lib.mc_last_error().decode()
+        assert lib.mc_set_option(b"no_such_option", 0) == _lib.MC_EINVAL
+        assert lib.mc_set_option(None, 0) == _lib.MC_EINVAL
+    finally:
+        lib.mc_set_option(b"gemm_kernel", 0)
+        lib.mc_set_option(b"attn_kernel", 0)
+        lib.mc_set_option(b"mmdit_two_streams", -1)
+
+
 def test_c_rule_short_eval_schedules_wrap_like_python():
     """eval Wan reads ratio[t - 10] from t >= int(n * 0.2) on; with few steps the index is negative.  The reference
     indexes a Python list, which wraps once (ratios[-3]) and raises IndexError beyond -len: the C rule wraps the same
