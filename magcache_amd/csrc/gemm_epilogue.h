@@ -47,6 +47,8 @@ __device__ __forceinline__ void gemm_epilogue_quad(const GemmParams& p, int m, i
     f32x4 gt = {1.f, 1.f, 1.f, 1.f};
     if (p.gate) gt = *(const f32x4*)(((p.gate_sel && p.gate_sel[m]) ? p.gate2 : p.gate) + n);
     float* xp = p.X + (size_t)m * p.ldx + n;
+    // (non-temporal load / store of the residual row: measured 9 % slower on the O projection, 2 % on FFN-2 -- the
+    // write then waits for HBM instead of L2; profiles/r02/kbench_gemm_epi_nt.log)
     f32x4 xv = *(const f32x4*)xp;
 #pragma unroll
     for (int i = 0; i < 4; ++i) xv[i] = xv[i] + bf16_round(val[i]) * gt[i];
