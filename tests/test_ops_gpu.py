@@ -150,8 +150,9 @@ def mx_quantize_ref(x):
 def test_gemm_mxfp8_vs_dequantised_reference(M, N, K):
     """MX block-scaled fp8 (v_mfma_scale_f32_16x16x128_f8f6f4, one E8M0 scale per row and 32 k): (1) the quantiser
     equals its torch restatement byte for byte (elements and scales); (2) the GEMM equals the product of the
-    DEQUANTISED operands (exact products and power-of-two scales, fp32 accumulation order aside); (3) it is closer to
-    the unquantised product than the per-row-scaled fp8 path when a row mixes magnitudes (the point of block scales)."""
+    DEQUANTISED operands (exact products and power-of-two scales, the matrix core's summation aside); (3) it keeps its
+    accuracy when the blocks of a row differ by 2^20, where the per-row-scaled fp8 path flushes the small blocks to
+    zero (the point of block scales; up to ~2^12 e4m3's own exponent absorbs the range and the two paths are equal)."""
     a = rnd(M, K, seed=1, dtype=torch.bfloat16)
     a[:, 3] *= 30.0                                   # an outlier column: only its own 32-block pays for it
     a[5, 64:96] = 0                                   # an all-zero block
@@ -178,12 +179,24 @@ def test_gemm_mxfp8_vs_dequantised_reference(M, N, K):
     torch.testing.assert_close(out.double(), want, rtol=2e-3, atol=5e-3)
     full = a.double() @ w.double().t() + bias.double()
     err_mx = rel_l2(out, full.float())
-    assert err_mx < 4e-2, err_mx
-    aq1, sa1 = H.quantize_rows_fp8(a)
-    wq1, sw1 = H.quantize_rows_fp8(w)
+    assert err_mx < 4e-2, err_mx                      # power-of-two scales cost up to one bit against amax / 448
+    # (3) where block scales matter: one 32-block of every row 2^20 larger than the rest (e4m3 itself spans 2^17) -- a
+    # per-row scale flushes the other blocks to zero, a block scale does not
+    a2 = a.clone()
+    a2[:, 32:64] *= 2.0 ** 20
+    w2 = w.clone()
+    w2[:, 32:64] *= 2.0 ** -20                        # the product stays balanced, so the small blocks still count
+    full2 = a2.double() @ w2.double().t()
+    aq2, sa2 = H.quantize_rows_mx(a2)
+    wq2, sw2 = H.quantize_rows_mx(w2)
+    out2 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    H.gemm_mxfp8(aq2, sa2, wq2, sw2, None, 5, X=out2)
+    aq1, sa1 = H.quantize_rows_fp8(a2)
+    wq1, sw1 = H.quantize_rows_fp8(w2)
     out1 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
-    H.gemm_fp8(aq1, sa1, wq1, sw1, bias, 5, X=out1)
-    assert err_mx < rel_l2(out1, full.float()), (err_mx, rel_l2(out1, full.float()))
+    H.gemm_fp8(aq1, sa1, wq1, sw1, None, 5, X=out1)
+    e_mx, e_row = rel_l2(out2, full2.float()), rel_l2(out1, full2.float())
+    assert e_mx < 4e-2 and e_row > 5 * e_mx, (e_mx, e_row)
     # bf16 store, GELU and gated-residual epilogues
     cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
     H.gemm_mxfp8(aq, sa, wq, sw, bias, 0, Cb=cb)
