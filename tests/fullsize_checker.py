@@ -145,6 +145,40 @@ def hunyuan_on_gpu(bf16_mode):
         HR.joint_attention, HR.timestep_embedding = saved
 
 
+def _on_cpu_then_back(fn):
+    """oracle helpers that build their tables with device-less torch.arange: evaluate on the CPU (the same arithmetic
+    as in the CPU tests) and move the result to the argument's device"""
+    def wrapped(x, *a, **k):
+        out = fn(x.cpu(), *a, **k)
+        return tuple(o.to(x.device) for o in out) if isinstance(out, tuple) else out.to(x.device)
+    return wrapped
+
+
+@contextmanager
+def flux_on_gpu():
+    """FLUX oracle on the GPU: its timestep embedding and RoPE tables are built on the CPU and moved over."""
+    from oracle import flux_ref as FR
+    saved = FR.get_timestep_embedding, FR.rope_cos_sin
+    FR.get_timestep_embedding, FR.rope_cos_sin = _on_cpu_then_back(saved[0]), _on_cpu_then_back(saved[1])
+    try:
+        yield
+    finally:
+        FR.get_timestep_embedding, FR.rope_cos_sin = saved
+
+
+def init_on_device_(model, seed, std=0.02):
+    """oracle.init_synthetic_'s rules with a device generator (12 B parameters: the CPU generator would take minutes)"""
+    dev = next(model.parameters()).device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if ".norm_" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=dev))
+            else:
+                p.copy_(std * torch.randn(p.shape, generator=g, device=dev))
+    return model
+
+
 def rel_l2(a, b):
     a, b = a.float(), b.float()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))

@@ -10,7 +10,9 @@ modules on the GPU with query-chunked attention (tests/fullsize_checker.py; neve
   (ii)  the 30-layer Wan2.1-T2V-1.3B forward at full L on the bench's weights and again with q x6, reporting rel-L2 per
         layer so the growth of the bf16 rounding error over depth is visible;
   (iii) one block at Wan2.1-14B widths (d = 5120, 40 heads, ffn 13 824) at L = 75 600;
-  (iv)  one double + one single block at HunyuanVideo 720p 129f size (118 800 image + 256 text tokens, d = 3072).
+  (iv)  one double + one single block at HunyuanVideo 720p 129f size (118 800 image + 256 text tokens, d = 3072);
+  (v)   the WHOLE FLUX.1-dev transformer (19 double + 38 single blocks, d = 3072, 12 B parameters) at 512x512
+        (1024 image + 512 text tokens): error growth over 57 blocks of the MM-DiT engine.
 
 Tolerance (floating point, stated here): with e_hip = rel-L2(engine, fp32 checker) and e_ac = rel-L2(the reference's
 bf16-autocast mode run by the same checker, fp32 checker),
@@ -31,6 +33,7 @@ pytestmark = pytest.mark.gpu
 import fullsize_checker as FC  # noqa: E402
 from magcache_amd import mmdit as MM  # noqa: E402
 from magcache_amd.engine import MC_MODE_FULL, WAN_T2V_1_3B, WAN_T2V_14B, Engine, synthetic_weights  # noqa: E402
+from oracle import flux_ref as FR  # noqa: E402
 from oracle import hunyuan_ref as HR  # noqa: E402
 
 DEV = "cuda:0"
@@ -182,6 +185,49 @@ def test_hunyuan_one_double_one_single_block_720p_129f():
                out_psnr_hip_db=FC.psnr(got, ref32), out_psnr_bf16_model_db=FC.psnr(refbf, ref32),
                tokens=118800 + txt_len, n_valid_text=n_valid)
     report("hunyuan_1double_1single_720p129f", res)
+    assert res["out_e_hip"] <= 2 * res["out_e_bf16_model"] + 1e-3, res
+    assert res["out_psnr_hip_db"] >= 40.0, res
+    del m, oracle
+    free()
+
+
+def test_flux_dev_full_depth_512():
+    """(v) FLUX.1-dev at full depth and width, 512x512 (BASELINE.json config 0's model; the double blocks run their text
+    half on the second HIP stream, the engine's default for this shape).  The reference's pipeline runs the transformer
+    entirely in bf16; the bar is the HunyuanVideo one: not further from the fp32 checker than twice the all-bf16 model,
+    and >= 40 dB."""
+    cfg = dict(FR.FLUX_DEV)
+    h2 = w2 = 32
+    txt_len = 512
+    with torch.device(DEV):
+        oracle = FR.FluxTransformer2DModel(**cfg)
+    FC.init_on_device_(oracle, seed=17)
+    with torch.no_grad():
+        for n, p in oracle.named_parameters():      # real dynamic range in the logits
+            if n.endswith("norm_q.weight") or n.endswith("norm_added_q.weight"):
+                p.mul_(3.0)
+    oracle.eval()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(1, h2 * w2, 64, generator=g, device=DEV)
+    kw = dict(encoder_hidden_states=torch.randn(1, txt_len, 4096, generator=g, device=DEV),
+              pooled_projections=torch.randn(1, 768, generator=g, device=DEV),
+              img_ids=FR.prepare_latent_image_ids(h2, w2).to(DEV), txt_ids=torch.zeros(txt_len, 3, device=DEV),
+              guidance=torch.tensor([3.5], device=DEV))
+    t = torch.tensor([0.6], device=DEV)
+    cls = type("FluxHIPFullDepth", (MM.FluxTransformer2DModelHIP,), {})
+    m = cls(cfg, h2 * w2, txt_len=txt_len, device=DEV, calibration=False)
+    m.load_state_dict(oracle.state_dict())
+    got = m(hidden_states=x, timestep=t, return_dict=False, **kw)[0].float()
+    with torch.no_grad(), FC.flux_on_gpu():
+        ref32 = oracle(hidden_states=x, timestep=t, **kw)[0]
+        oracle.bfloat16()
+        kwb = {k: (v.bfloat16() if v.dtype == torch.float32 and k not in ("img_ids", "txt_ids") else v) for k, v in kw.items()}
+        refbf = oracle(hidden_states=x.bfloat16(), timestep=t.bfloat16(), **kwb)[0].float()
+    torch.cuda.synchronize()
+    res = dict(out_e_hip=FC.rel_l2(got, ref32), out_e_bf16_model=FC.rel_l2(refbf, ref32),
+               out_psnr_hip_db=FC.psnr(got, ref32), out_psnr_bf16_model_db=FC.psnr(refbf, ref32),
+               blocks="19 double + 38 single", tokens=h2 * w2 + txt_len)
+    report("flux_dev_full_depth_512", res)
     assert res["out_e_hip"] <= 2 * res["out_e_bf16_model"] + 1e-3, res
     assert res["out_psnr_hip_db"] >= 40.0, res
     del m, oracle
