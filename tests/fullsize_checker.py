@@ -166,14 +166,21 @@ def flux_on_gpu():
         FR.get_timestep_embedding, FR.rope_cos_sin = saved
 
 
-def init_on_device_(model, seed, std=0.02):
-    """oracle.init_synthetic_'s rules with a device generator (12 B parameters: the CPU generator would take minutes)"""
+def init_on_device_(model, seed, std=0.02, family="flux"):
+    """oracle.{flux,hunyuan}_ref.init_synthetic_'s rules with a device generator (12 - 13 B parameters: the CPU generator
+    would take minutes)"""
     dev = next(model.parameters()).device
     g = torch.Generator(device=dev).manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
-            if ".norm_" in name and name.endswith("weight"):
+            if family == "flux":
+                is_norm = ".norm_" in name
+            else:
+                is_norm = "_norm." in name or ".norm1." in name or ".norm2." in name
+            if is_norm and name.endswith("weight"):
                 p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=dev))
+            elif is_norm and name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g, device=dev))
             else:
                 p.copy_(std * torch.randn(p.shape, generator=g, device=dev))
     return model

@@ -11,6 +11,7 @@ modules on the GPU with query-chunked attention (tests/fullsize_checker.py; neve
         layer so the growth of the bf16 rounding error over depth is visible;
   (iii) one block at Wan2.1-14B widths (d = 5120, 40 heads, ffn 13 824) at L = 75 600;
   (iv)  one double + one single block at HunyuanVideo 720p 129f size (118 800 image + 256 text tokens, d = 3072);
+  (iv b) ALL 20 double + 40 single HunyuanVideo blocks at a reduced length (3 456 + 256 tokens): error growth over depth;
   (v)   the WHOLE FLUX.1-dev transformer (19 double + 38 single blocks, d = 3072, 12 B parameters) at 512x512
         (1024 image + 512 text tokens): error growth over 57 blocks of the MM-DiT engine.
 
@@ -145,20 +146,18 @@ def test_wan14_one_block_720p_length():
     check(res)
 
 
-def test_hunyuan_one_double_one_single_block_720p_129f():
-    """(iv) HunyuanVideo 720p 129 frames: 118 800 image + 256 text tokens, one double + one single block.  The
-    reference runs this family entirely in bf16; the engine keeps the residual stream / modulation / final layer in
-    fp32 (DESIGN section 7), so the bar is the same: not further from fp32 than twice the all-bf16 model."""
-    cfg = dict(HR.HUNYUAN_VIDEO, mm_double_blocks_depth=1, mm_single_blocks_depth=1)
-    grid, txt_len, n_valid = (33, 90, 160), 256, 143
+def _hunyuan_case(cfg, grid, txt_len, n_valid, seed, key, q_mul):
     with torch.device(DEV):
         oracle = HR.HYVideoDiffusionTransformer(**cfg)
-    HR.init_synthetic_(oracle, seed=11, std=0.02)
-    # real dynamic range in the logits: scale the per-head q norm of both streams and of the single block
+    if cfg["mm_single_blocks_depth"] > 1:
+        FC.init_on_device_(oracle, seed=seed, family="hunyuan")
+    else:
+        HR.init_synthetic_(oracle, seed=seed, std=0.02)
+    # real dynamic range in the logits: scale the per-head q norm of both streams and of the single blocks
     with torch.no_grad():
         for n, p in oracle.named_parameters():
             if n.endswith("q_norm.weight"):
-                p.mul_(4.0)
+                p.mul_(q_mul)
     oracle.eval()
     g = torch.Generator(device=DEV).manual_seed(7)
     x = torch.randn(1, 16, *grid, generator=g, device=DEV)
@@ -181,14 +180,30 @@ def test_hunyuan_one_double_one_single_block_720p_129f():
             refbf = oracle(x.bfloat16(), t, **dict(kw, text_states=kw["text_states"].bfloat16(),
                                                    text_states_2=kw["text_states_2"].bfloat16()))["x"].float()
     torch.cuda.synchronize()
+    li = grid[0] * (grid[1] // 2) * (grid[2] // 2)
     res = dict(out_e_hip=FC.rel_l2(got, ref32), out_e_bf16_model=FC.rel_l2(refbf, ref32),
                out_psnr_hip_db=FC.psnr(got, ref32), out_psnr_bf16_model_db=FC.psnr(refbf, ref32),
-               tokens=118800 + txt_len, n_valid_text=n_valid)
-    report("hunyuan_1double_1single_720p129f", res)
+               tokens=li + txt_len, n_valid_text=n_valid,
+               blocks=f"{cfg['mm_double_blocks_depth']} double + {cfg['mm_single_blocks_depth']} single")
+    report(key, res)
     assert res["out_e_hip"] <= 2 * res["out_e_bf16_model"] + 1e-3, res
     assert res["out_psnr_hip_db"] >= 40.0, res
     del m, oracle
     free()
+
+
+def test_hunyuan_one_double_one_single_block_720p_129f():
+    """(iv) HunyuanVideo 720p 129 frames: 118 800 image + 256 text tokens, one double + one single block.  The
+    reference runs this family entirely in bf16; the engine keeps the residual stream / modulation / final layer in
+    fp32 (DESIGN section 7), so the bar is the same: not further from fp32 than twice the all-bf16 model."""
+    cfg = dict(HR.HUNYUAN_VIDEO, mm_double_blocks_depth=1, mm_single_blocks_depth=1)
+    _hunyuan_case(cfg, (33, 90, 160), 256, 143, seed=11, key="hunyuan_1double_1single_720p129f", q_mul=4.0)
+
+
+def test_hunyuan_full_depth_reduced_length():
+    """(iv b) all 20 double + 40 single blocks of HunyuanVideo (13 B parameters) on a 9 x 32 x 48 latent (3 456 image + 256
+    text tokens): the error growth over 60 blocks that the one-block case at full length cannot show."""
+    _hunyuan_case(dict(HR.HUNYUAN_VIDEO), (9, 32, 48), 256, 77, seed=13, key="hunyuan_full_depth_L3456", q_mul=3.0)
 
 
 def test_flux_dev_full_depth_512():
