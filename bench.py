@@ -312,6 +312,10 @@ def main():
             if not (rel <= 3e-3):
                 PAR.SP_OVERLAP = False
             extra["sp_overlap"] = bool(PAR.SP_OVERLAP)
+            sp = getattr(models[check_name], "_sp", None)
+            # RCCL only: did the in-place all-gather (send chunk = own slot of the receive buffer) pass its start-up
+            # self-test on every rank (parallel.inplace_gather_selftest)?  false = the run uses the out-of-place form
+            extra["rccl_inplace_gather"] = getattr(sp, "inplace_checked", None)
         # ---- layout ablation: 2 no-cache steps of every candidate after 1 untimed step; the faster one is benchmarked
         if len(names) > 1:
             abl = {}

@@ -189,6 +189,9 @@ class MMDiTSequenceParallel:
         self.P, self.rank = engine.sp_size, engine.sp_rank
         assert dist.is_initialized() and dist.get_world_size(group) == self.P
         self.inplace = dist.get_backend(group) == "nccl"
+        if self.inplace:
+            from .parallel import inplace_gather_selftest
+            self.inplace = inplace_gather_selftest(self.P, self.rank, group, engine.device)
         self.kv = engine.buffer("kv_gather", torch.bfloat16).view(self.P, -1)
         self.Lr = engine.tokens_per_rank
         hy = engine.family == MC_FAMILY_HUNYUAN

@@ -87,6 +87,23 @@ class ParallelLayout:
         return buf[0], buf[1]
 
 
+def inplace_gather_selftest(P, rank, group, device, n=4096):
+    """RCCL's in-place all-gather (send chunk = this rank's slot of the receive buffer) is what the K/V join uses, on a
+    view of the engine workspace; it cannot be exercised without P GPUs, so every rank checks it once at start-up on a
+    small tensor and falls back to the out-of-place form if the result is not what the ranks sent.  Collective: every
+    rank of `group` must call it."""
+    buf = torch.full((P, n), -1.0, dtype=torch.bfloat16, device=device)
+    buf[rank] = float(rank + 1)
+    try:
+        dist.all_gather_into_tensor(buf.view(-1), buf[rank].reshape(-1), group=group)
+        want = torch.arange(1, P + 1, dtype=torch.bfloat16, device=device)[:, None].expand(P, n)
+        ok = torch.tensor([float(torch.equal(buf, want))], device=device)
+    except RuntimeError:
+        ok = torch.zeros(1, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same path
+    return bool(ok.item() > 0.5)
+
+
 class SequenceParallelForward:
     def __init__(self, engine, group=None):
         self.e = engine
@@ -95,6 +112,9 @@ class SequenceParallelForward:
         self.rank = engine.sp_rank
         assert dist.is_initialized() and dist.get_world_size(group) == self.P, (dist.get_world_size(group), self.P)
         self.inplace = dist.get_backend(group) == "nccl"
+        self.inplace_checked = None
+        if self.inplace:
+            self.inplace_checked = self.inplace = inplace_gather_selftest(self.P, self.rank, group, engine.device)
         cfg = engine.cfg
         self.d, self.NL = cfg["dim"], cfg["num_layers"]
         self.L = engine.seq_len
@@ -109,6 +129,9 @@ class SequenceParallelForward:
         if self.inplace:
             # RCCL in-place all-gather: the send chunk is this rank's slot of the receive buffer
             return dist.all_gather_into_tensor(self.kv.view(-1), mine.reshape(-1), group=self.group, async_op=True)
+        if dist.get_backend(self.group) == "nccl":
+            # the in-place form failed its start-up self-test on this stack: gather out of place from a copy of the slot
+            return dist.all_gather_into_tensor(self.kv.view(-1), mine.reshape(-1).clone(), group=self.group, async_op=True)
         dist.all_gather([self.kv[r] for r in range(self.P)], mine.clone(), group=self.group)
         return None
 

@@ -527,3 +527,31 @@ def test_vace_shim_schedule_matches_wan21_rule(golden_dir):
         assert m(["x"], t=0, vace_context=vc, context=["c"], seq_len=4, vace_context_scale=0.5) == ["out"]
     assert [int(mode == _lib.MC_MODE_SKIP) for _, mode in m.trace] == g[key]
     assert all(v[0] is vc and v[1] == 0.5 for v in seen) and m.cnt == 0
+
+
+def test_inplace_gather_selftest_detects_a_wrong_or_failing_collective(monkeypatch):
+    """parallel.inplace_gather_selftest (run by every rank at start-up on the RCCL backend, which this container cannot
+    exercise): true only if the in-place all-gather returns what the ranks sent; wrong data or an exception select the
+    out-of-place fallback."""
+    import torch
+    import torch.distributed as dist
+
+    from magcache_amd import parallel as PAR
+
+    P, rank = 4, 2
+    monkeypatch.setattr(dist, "all_reduce", lambda t, op=None, group=None: t)
+
+    def good(out, inp, group=None):
+        n = inp.numel()
+        assert out.data_ptr() + rank * n * out.element_size() == inp.data_ptr(), "send chunk must be the own slot"
+        for r in range(P):
+            out[r * n:(r + 1) * n] = float(r + 1)
+
+    def stale(out, inp, group=None):       # other ranks' slots never arrive
+        pass
+
+    def boom(out, inp, group=None):
+        raise RuntimeError("NCCL error")
+    for fn, want in ((good, True), (stale, False), (boom, False)):
+        monkeypatch.setattr(dist, "all_gather_into_tensor", fn)
+        assert PAR.inplace_gather_selftest(P, rank, None, torch.device("cpu"), n=64) is want
