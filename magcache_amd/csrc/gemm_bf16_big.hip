@@ -240,6 +240,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   // last MFMA -> epilogue VALU reads (the s_nop block behind the main loop).
   auto mma1 = [&](int i, const FragW& w, const FragA& a, f32x4 (&c)[4][2][2], int nh) {
     const int ks = i >> 3, mb = (i >> 1) & 3, nb = i & 1;
+    // ("+a": the accumulators in AGPRs, as the library kernel has them -- measured 0.3..1.7 % slower, the main loop equal
+    // and the epilogue paying for v_accvgpr_read; profiles/r02/kbench_gemm_agpr.log)
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[mb][nh][nb]) : "v"(w.v[nb][ks]), "v"(a.v[mb][ks]));
   };
 
