@@ -39,7 +39,7 @@ def flops_forward(cfg, L, Lc=512):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/rNN/pmc_traffic.json,
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collected by tools/gpu_round.sh; counters cannot be read from
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collected by tools/gpu_pmc2.sh; counters cannot be read from
     inside this process).  None if no such file."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
