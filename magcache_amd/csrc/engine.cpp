@@ -217,7 +217,7 @@ extern int g_mmdit_two_streams;   // mmdit_engine.cpp: mc_set_option("mmdit_two_
 extern "C" {
 
 const char* mc_last_error(void) { return g_err; }
-const char* mc_version(void) { return "magcache_hip 0.2 (gfx950)"; }
+const char* mc_version(void) { return "magcache_hip 0.3 (gfx950)"; }
 
 mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (!cfg || !out) return fail(MC_EINVAL, "null argument");
