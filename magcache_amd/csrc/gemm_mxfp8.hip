@@ -4,8 +4,8 @@
 // A_q, W_q: OCP e4m3 bytes, K contiguous; sa, sw: E8M0 scale bytes, one per (row, 32 consecutive k) -- the OCP
 // microscaling (MX) format, multiplied by the matrix core itself (HW-fused dequantisation), stored block-major with
 // the rows of every group of 64 interleaved 16 x 4: s[kb * rows_pad + perm(row)], perm(row) = (row & ~63) |
-// ((row & 15) << 2) | ((row >> 4) & 3) -- the four 16-row blocks a lane works on are then the four bytes of ONE dword.  An OPTIONAL speed / quality mode of the engine (mc_config.fp8_linear = 2), never the default
-// and never the headline (BASELINE.json config 4 "fp8 MFMA weight path"; no reference counterpart: the reference runs
+// ((row & 15) << 2) | ((row >> 4) & 3) -- the four 16-row blocks a lane works on are then the four bytes of ONE dword.
+// An OPTIONAL speed / quality mode of the engine (mc_config.fp8_linear = 2), never the default and never the headline (BASELINE.json config 4 "fp8 MFMA weight path"; no reference counterpart: the reference runs
 // bf16 autocast, MagCache4Wan2.1/magcache_generate.py:297-298).  The older per-row-scaled fp8 path (gemm_fp8_big.hip,
 // fp8_linear = 1, 32x32x64 MFMA with unit block scales) stays for comparison.
 //
