@@ -12,6 +12,7 @@ import pytest
 from magcache_amd import _lib
 from magcache_amd import model as M
 from magcache_amd.mag_ratios import TABLES
+from oracle import magcache_ref as MR
 from test_oracle_golden import TWO_SLOT, parse_key, table_for
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -555,3 +556,49 @@ def test_inplace_gather_selftest_detects_a_wrong_or_failing_collective(monkeypat
     for fn, want in ((good, True), (stale, False), (boom, False)):
         monkeypatch.setattr(dist, "all_gather_into_tensor", fn)
         assert PAR.inplace_gather_selftest(P, rank, None, torch.device("cpu"), n=64) is want
+
+
+def test_c_rule_equals_the_oracle_state_machine_on_random_configurations():
+    """Differential test of rule.cpp against oracle.magcache_ref.RuleState (itself pinned by schedules produced by the
+    reference's own source lines, tests/golden/rule_schedules.json): every variant, random tables / thresholds / K /
+    retention / step counts, 2.5 passes over the schedule (the wrap-around resets differ per variant).  Decisions,
+    branch indices, counter and accumulators must agree exactly (the accumulators to the last bit: both sides do the
+    same float64 operations in the same order)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(1234)
+    checked = 0
+    for variant, vid in _lib.RULE_VARIANTS.items():
+        for _ in range(60):
+            n = int(rng.integers(12, 61))
+            if variant == "flux":
+                n = max(n, 12)
+            thresh = float(rng.uniform(0.01, 0.4))
+            K = int(rng.integers(1, 8))
+            R = float(rng.uniform(0.0, 0.45))
+            # the eval variants index table[t - 10] / table[t - 1] from their gate on: keep the index non-negative here
+            # (the wrap-around cases have their own test above)
+            if variant == "eval_wan":
+                n = max(n, 50)
+            if variant == "eval_opensora":
+                R = max(R, 1.0 / n + 1e-9)
+            table = (1.0 + rng.normal(0.0, 0.04, size=n)).tolist()
+            split = int(rng.integers(2, n - 2)) if variant in ("wan22_t2v", "wan22_i2v") else None
+            want = MR.RuleState(variant, n, thresh, K, R, table, split_step=split)
+            arr = (C.c_double * n)(*table)
+            r = lib.mc_rule_create(vid, n, thresh, K, R, arr, n, 0 if split is None else split)
+            assert r, (variant, n, R)
+            b = C.c_int()
+            for call in range(int(2.5 * n)):
+                skip_w, p_w = want.step()
+                skip_g = lib.mc_rule_step(r, C.byref(b))
+                assert (bool(skip_g), b.value) == (bool(skip_w), p_w), (variant, n, thresh, K, R, split, call)
+                assert lib.mc_rule_cnt(r) == want.cnt
+            err, steps, ratio = (C.c_double * 2)(), (C.c_int * 2)(), (C.c_double * 2)()
+            lib.mc_rule_state(r, err, steps, ratio)
+            slots = 2 if want.two else 1
+            assert list(err)[:slots] == [float(x) for x in want.acc_err[:slots]]
+            assert list(steps)[:slots] == [int(x) for x in want.acc_steps[:slots]]
+            assert list(ratio)[:slots] == [float(x) for x in want.acc_ratio[:slots]]
+            lib.mc_rule_destroy(r)
+            checked += 1
+    assert checked == 60 * len(_lib.RULE_VARIANTS)
