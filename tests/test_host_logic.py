@@ -602,3 +602,28 @@ def test_c_rule_equals_the_oracle_state_machine_on_random_configurations():
             lib.mc_rule_destroy(r)
             checked += 1
     assert checked == 60 * len(_lib.RULE_VARIANTS)
+
+
+def test_wan_shim_equals_the_oracle_state_machine_on_random_configurations():
+    """The Python shim a user actually patches in (model.magcache_forward + init_magcache) against the oracle rule on
+    random tables / hyper-parameters, including a table that has to be resampled by nearest_interp (length != 2 steps)."""
+    rng = np.random.default_rng(77)
+    for case in range(120):
+        steps = int(rng.integers(8, 41))
+        # the gate must stay shut for the first cond + uncond call: a skip needs a cached residual (the reference would
+        # add None there; the shim raises, see test_skip_before_any_residual_is_an_error)
+        thresh, K, R = float(rng.uniform(0.02, 0.4)), int(rng.integers(1, 7)), float(rng.uniform(1.01 / steps, 0.4))
+        src_len = 2 * steps if case % 3 else 2 * int(rng.integers(10, 60))          # every third case: interpolated
+        table = np.concatenate(([1.0, 1.0], 1.0 + rng.normal(0.0, 0.05, size=src_len - 2)))
+        m = make_shim()
+        M.init_magcache(m, steps, thresh, K, R, mag_ratios=table)
+        want = MR.RuleState("wan21", 2 * steps, thresh, K, R,
+                            table if len(table) == 2 * steps else MR.interp_cfg_table(table, steps))
+        for call in range(5 * steps):
+            skip_w, p_w = want.step()
+            m(["x"], t=0, context=["c"], seq_len=4)
+            b, mode = m.trace[-1]
+            assert (b, int(mode == _lib.MC_MODE_SKIP)) == (p_w, int(skip_w)), (case, call)
+            assert m.cnt == want.cnt
+        assert [float(x) for x in m.accumulated_err] == [float(x) for x in want.acc_err]
+        assert [float(x) for x in m.accumulated_ratio] == [float(x) for x in want.acc_ratio]
