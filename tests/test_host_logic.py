@@ -627,3 +627,19 @@ def test_wan_shim_equals_the_oracle_state_machine_on_random_configurations():
             assert m.cnt == want.cnt
         assert [float(x) for x in m.accumulated_err] == [float(x) for x in want.acc_err]
         assert [float(x) for x in m.accumulated_ratio] == [float(x) for x in want.acc_ratio]
+
+
+def test_nearest_interp_c_python_and_oracle_agree_on_random_lengths():
+    """nearest_interp (reference :27-34) three ways -- mc_nearest_interp, model.nearest_interp, the oracle (pinned by
+    goldens from the reference function) -- on random source / target lengths, including target 1 and equal lengths."""
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        n_src, n_dst = int(rng.integers(1, 130)), int(rng.integers(1, 130))
+        src = rng.normal(1.0, 0.1, size=n_src)
+        want = MR.nearest_interp(src, n_dst)
+        a = (C.c_double * n_src)(*src.tolist())
+        out = (C.c_double * n_dst)()
+        lib.mc_nearest_interp(a, n_src, out, n_dst)
+        assert list(out) == [float(x) for x in want], (n_src, n_dst)
+        assert [float(x) for x in M.nearest_interp(src, n_dst)] == [float(x) for x in want], (n_src, n_dst)
