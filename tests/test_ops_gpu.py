@@ -209,6 +209,36 @@ def test_gemm_mxfp8_vs_dequantised_reference(M, N, K):
     torch.testing.assert_close(x, x0 + gate * want.float().to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)
 
 
+def test_gemm_mxfp8_full_shape_rows_vs_dequantised_reference():
+    """The MX kernel at the headline QKV shape (32768 x 4608 x 1536, 2304 tiles: every CU runs 9 tiles, the scale DMA
+    walks 12 K tiles of 128 scale rows): 320 rows spread over the first, middle and last tiles against the fp64 product
+    of the dequantised operands, plus exact linearity in the scales (doubling every activation scale byte's exponent by
+    one doubles the output exactly)."""
+    M, N, K = 32768, 4608, 1536
+    a = rnd(M, K, seed=11, dtype=torch.bfloat16)
+    a[:, 700:732] *= 64.0
+    w = rnd(N, K, seed=12, scale=0.05, dtype=torch.bfloat16)
+    aq, sa = H.quantize_rows_mx(a)
+    wq, sw = H.quantize_rows_mx(w)
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    H.gemm_mxfp8(aq, sa, wq, sw, None, 5, X=out)
+    rows = torch.cat([torch.arange(0, 64), torch.arange(255, 319), torch.arange(16320, 16384), torch.arange(20001, 20065),
+                      torch.arange(32704, 32768)]).to(DEV)
+    sa_nat, sw_nat = H.mx_unpermute(sa, M), H.mx_unpermute(sw, N)
+
+    def deq(q, s):
+        e = s.float() - 127.0
+        return (q.view(torch.float8_e4m3fn).float().view(q.shape[0], -1, 32) * torch.exp2(e)[..., None]).view(q.shape).double()
+    want = deq(aq[rows], sa_nat[rows]) @ deq(wq, sw_nat).t()
+    assert rel_l2(out[rows], want.float()) < 1e-4
+    # element-wise: the matrix core's summation error against outputs of rms ~ 10 (the x 64 block)
+    torch.testing.assert_close(out[rows].double(), want, rtol=2e-3, atol=2e-3 * float(want.pow(2).mean().sqrt()) + 5e-3)
+    assert rel_l2(out[rows], (a[rows].double() @ w.double().t()).float()) < 4e-2
+    out2 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    H.gemm_mxfp8(aq, (sa + 1).contiguous(), wq, sw, None, 5, X=out2)          # every activation block scale x 2
+    assert torch.equal(out2, 2.0 * out)
+
+
 def test_gemm_mxfp8_speed_vs_bf16():
     """informational: the MX fp8 kernel against the bf16 256x256 kernel and the per-row fp8 kernel on the FFN-1 shape"""
     M, N, K = 32768, 8960 - 8960 % 256, 1536
