@@ -44,6 +44,12 @@
 //     oldest half must have landed.  The data is read one interval AFTER the wait + barrier that
 //     retires it (every wave waits for its own pieces, the barrier publishes them).
 //   - the last two K tiles use exact smaller counts (8,6,4,2 / 0).
+// Persistent tile loop (round 2, bf16-store and GELU epilogues = QKV, cross-attention Q, FFN-1): the grid is one
+//   workgroup per CU and a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the first two K tiles of its NEXT output
+//   tile are queued (LDS-DMA) after the bias loads have arrived and before the accumulators are converted and stored, so
+//   their latency hides behind the epilogue: +5.3 % (QKV), +2.8 % (FFN-1), +4.6 % (cross-attention Q shape),
+//   profiles/r02/kbench_gemm_persistent.log.  The residual epilogues (loads in every quad, which the compiler makes wait
+//   for everything queued before them) keep one tile per workgroup.
 // the LDS-DMA asm below names m0 in its clobber list on purpose (reserved register: the compiler only warns)
 #pragma clang diagnostic ignored "-Winline-asm"
 #include "common.h"
@@ -122,32 +128,40 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   const int wr = wv >> 2, wc = wv & 3;
 
   // ---- tile mapping: XCD-contiguous, grouped along M so neighbouring tiles share W panels in L2
-  int v = xcd_remap(blockIdx.x, tilesM * tilesN);
-  const int per_group = GROUP_M * tilesN;
-  const int grp = v / per_group;
-  const int first_m = grp * GROUP_M;
-  const int gsz = min(tilesM - first_m, GROUP_M);
-  const int in_grp = v - grp * per_group;
-  const int tm = first_m + in_grp % gsz;
-  const int tn = in_grp / gsz;
-  const int m0 = tm * TB, n0 = tn * TB;
-
+  constexpr bool PERSIST = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16);
+  const int ntiles = tilesM * tilesN;
+  const int tstride = PERSIST ? (int)gridDim.x : ntiles;
+  int m0 = 0, n0 = 0;
   // ---- LDS-DMA sources.  Piece g (0..15) of a half = image rows 8g..8g+7; a wave owns pieces
   // 2wv, 2wv+1; lane -> (image row = 8g + lane/8, slot = lane%8), source chunk = slot ^ ((row>>1)&7).
   // image row r of Am<h>: tile row (r>>6)*128 + h*64 + (r&63);  of Wn<h>: (r>>5)*64 + h*32 + (r&31)
   uint32_t srcA[2][2], srcW[2][2];  // [half][piece] BYTE offsets from p.A / p.W (without k)
+  auto setup_tile = [&](int t) {
+    const int v = xcd_remap(t, ntiles);
+    const int per_group = GROUP_M * tilesN;
+    const int grp = v / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(tilesM - first_m, GROUP_M);
+    const int in_grp = v - grp * per_group;
+    const int tm = first_m + in_grp % gsz;
+    const int tn = in_grp / gsz;
+    m0 = tm * TB;
+    n0 = tn * TB;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = (wv * 2 + j) * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-      const int ra = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
-      const int rw = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-      srcA[h][j] = ((uint32_t)ra * (uint32_t)p.lda) * 2 + chunk * 16;
-      srcW[h][j] = ((uint32_t)rw * (uint32_t)p.ldw) * 2 + chunk * 16;
+      for (int j = 0; j < 2; ++j) {
+        const int r = (wv * 2 + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int ra = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
+        const int rw = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+        srcA[h][j] = ((uint32_t)ra * (uint32_t)p.lda) * 2 + chunk * 16;
+        srcW[h][j] = ((uint32_t)rw * (uint32_t)p.ldw) * 2 + chunk * 16;
+      }
     }
-  }
+  };
+  int tile = blockIdx.x;
+  setup_tile(tile);
   // LDS byte address (M0 value) of this wave's two pieces inside half 0 of stage 0
   const uint32_t dma_lds = (uint32_t)(uintptr_t)MC_LDS_PTR(smem) + wv * 2048;
 
@@ -168,16 +182,18 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   }
 
   f32x4 acc[2][4][2][2];  // [m half][m block][n half][n block]
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+          for (int d = 0; d < 2; ++d)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[a][b][c][d][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[a][b][c][d][r] = 0.f;
+  };
 
   const int nk = p.K / BK;
 
@@ -246,9 +262,14 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   };
 
   // ---- prologue: K tiles 0 and 1 in the steady-state issue order; Wn0(0), Am0(0), Wn1(0) landed
-  dma_w(0, 0, 0); dma_a(0, 0, 0); dma_w(0, 0, 1); dma_a(0, 0, 1);
-  dma_w(1, 1, 0); dma_a(1, 1, 0); dma_w(1, 1, 1); dma_a(1, 1, 1);
-  if (MC_VAR & 32) MC_WAIT_(8); else MC_WAIT(10);   // two-barrier form: q0 + q1 read Wn1(0) AND Am1(0) before the next barrier
+  auto prologue_dma = [&]() {
+    dma_w(0, 0, 0); dma_a(0, 0, 0); dma_w(0, 0, 1); dma_a(0, 0, 1);
+    dma_w(1, 1, 0); dma_a(1, 1, 0); dma_w(1, 1, 1); dma_a(1, 1, 1);
+  };
+  prologue_dma();
+  MC_WAIT(10);
+  for (;;) {   // one output tile per trip (a single trip unless PERSIST)
+  zero_acc();
   MC_BARRIER();
   // A0/A1: this wave's m0/m1 halves; W0/W1: n0/n1 of the current tile, W2: n0 of the next (W0 is
   // still live when it is read, so W0/W2 ping-pong by renaming; A0 is dead by then and is reused)
@@ -338,24 +359,49 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
 
   // ---- epilogue.  acc[mh][mb][nh][nb][r] = C[m][n], m = m0 + wr*128 + mh*64 + mb*16 + l15,
   //      n = n0 + wc*64 + nh*32 + nb*16 + 4*kgrp + r  -> 4 consecutive n per accumulator
+  const int em0 = m0, en0 = n0;
+  f32x4 bq[2][2];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      bq[nh][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bq[nh][nb] = *(const f32x4*)(p.bias + en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp);
+    }
+  const int next_tile = tile + tstride;
+  const bool more = PERSIST && next_tile < ntiles;
+  if (PERSIST) {
+    // the bias values must have ARRIVED before the next tile's LDS-DMA is queued behind them: the compiler's own wait for
+    // them (it cannot see the asm DMAs) would otherwise also wait for those
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(bq[0][0]), "v"(bq[0][1]), "v"(bq[1][0]), "v"(bq[1][1]));
+    if (more) {
+      setup_tile(next_tile);
+      prologue_dma();
+    }
+  }
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-      const int m = m0 + wr * 128 + mh * 64 + mb * 16 + l15;
+      const int m = em0 + wr * 128 + mh * 64 + mb * 16 + l15;
       if (m >= p.M) continue;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-          const int n = n0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp;
-          f32x4 b = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) b = *(const f32x4*)(p.bias + n);
-          gemm_epilogue_quad<EPI>(p, m, n, acc[mh][mb][nh][nb] + b);
+          const int n = en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp;
+          gemm_epilogue_quad<EPI>(p, m, n, acc[mh][mb][nh][nb] + bq[nh][nb]);
         }
       }
     }
   }
+  if (!more) break;
+  tile = next_tile;
+  // the next tile's first two K tiles were queued before the stores above: everything has to have landed (a counted
+  // wait would have to know how many stores are still in flight)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }   // tile loop
 }
 
 template <int EPI>
@@ -364,7 +410,18 @@ hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
   static std::atomic<uint64_t> lds_ready{0};
   if (hipError_t e = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, 2 * STAGE_BYTES, lds_ready); e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(tilesM * tilesN), dim3(512), 2 * STAGE_BYTES, stream, p,
+  int grid = tilesM * tilesN;
+  if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (n_cu <= 0) n_cu = 256;
+    }
+    if (grid > n_cu) grid = n_cu;
+  }
+  hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), 2 * STAGE_BYTES, stream, p,
                      tilesM, tilesN, MC_GROUP_M_OF(tilesN));
   return hipGetLastError();
 }
