@@ -19,7 +19,7 @@ inputs.  What is executed from the reference, verbatim:
   * videosys/models/modules/attentions.py:21-100    OpenSoraAttention.forward (imported, stub `diffusers` and
         videosys.core) with qk_norm=True and a rope callable: qk-norm -> RoPE -> SDPA -> proj, against the same chain
         assembled from the oracle's WanRMSNorm / rope_apply / attention_ref_fp32
-  * videosys/schedulers/scheduling_rflow_open_sora.py:243-251 (CFG combine + Euler update, source lines exec'd)
+  * videosys/schedulers/scheduling_rflow_open_sora.py:245-251 (CFG combine + Euler update, source lines exec'd)
         -> oracle flow_solvers_ref.solve(..., "euler") / the CFG line of the sampler (Open-Sora's velocity points from
         noise to data, Wan's from data to noise: the same update with v -> -v, stated in the test)
 """
@@ -130,8 +130,8 @@ def main():
         for k, v in m.state_dict().items():
             out["att_w_" + k] = v.numpy()
 
-    # ---- CFG combine + Euler update (scheduling_rflow_open_sora.py:243-251), one interior and the last step
-    src = ref_lines("videosys/schedulers/scheduling_rflow_open_sora.py", 243, 251)
+    # ---- CFG combine + Euler update (scheduling_rflow_open_sora.py:245-251), one interior and the last step
+    src = ref_lines("videosys/schedulers/scheduling_rflow_open_sora.py", 245, 251)
     num_timesteps = 1000
     timesteps = [torch.tensor([t_]) for t_ in (1000.0, 730.0, 310.0)]
     z0 = torch.randn(1, 4, 3, 6, 5, generator=g)
