@@ -520,11 +520,12 @@ hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// mc_set_option("attn_kernel", v): 0 / 3 = this kernel (the default); 4 = attention_v4.hip, the same pipeline on the
-// 16x16x32 MFMA shape -- correct (same parity tests), equal in the contiguous-layout micro-benchmark (1246 vs 1250 TF)
-// but 6-11 % slower on the engine's strided q|k|v layout (profiles/r02), so it is not dispatched.  The A/B library
-// (tools/build_ab_lib.py, -DMC_AB_KERNELS) also links tools/kernels_ab/attention{,_v2}.hip as 1 / 2.
+// mc_set_option("attn_kernel", v): 0 = default dispatch; 3 = this kernel everywhere; 5 = attention_v5.hip (4 waves x 64 rows,
+// hand-scheduled) wherever it applies -- one key shard, no log-sum-exp merge, i.e. the single-GPU call -- and this kernel
+// for the sequence-parallel forms.  The A/B library (tools/build_ab_lib.py, -DMC_AB_KERNELS) also links
+// tools/kernels_ab/attention{,_v2,_v4}.hip as 1 / 2 / 4.
 int g_attn_kernel = 0;
+constexpr int kDefaultAttnKernel = 3;
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
   const bool two_phase = p.skip_shard_p1 != 0 || p.lse_out || p.lse_in;
@@ -533,8 +534,10 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
 #ifdef MC_AB_KERNELS
   if (!two_phase && g_attn_kernel == 1) return launch_attention_v1(p, stream);
   if (!two_phase && g_attn_kernel == 2) return launch_attention_v2(p, stream);
+  if (!two_phase && g_attn_kernel == 4) return launch_attention_v4(p, stream);
 #endif
-  if (g_attn_kernel == 4) return launch_attention_v4(p, stream);
+  const int kernel = g_attn_kernel ? g_attn_kernel : kDefaultAttnKernel;
+  if (kernel == 5 && attention_v5_supports(p)) return launch_attention_v5(p, stream);
   return launch_attention_v3(p, stream);
 }
 

@@ -1383,10 +1383,10 @@ mc_status mc_set_option(const char* key, int value) {
     mc::g_gemm_kernel = value;
   } else if (k == "attn_kernel") {
 #ifndef MC_AB_KERNELS
-    if (value != 0 && value != 3 && value != 4)
-      return fail(MC_EINVAL, "attn_kernel must be 0 / 3 (32x32x16 MFMA kernel) or 4 (16x16x32 kernel)");
+    if (value != 0 && value != 3 && value != 5)
+      return fail(MC_EINVAL, "attn_kernel must be 0 (default), 3 (8 waves x 32 rows) or 5 (4 waves x 64 rows, hand-scheduled)");
 #endif
-    if (value < 0 || value > 4) return fail(MC_EINVAL, "attn_kernel must be 0..4");
+    if (value < 0 || value > 5) return fail(MC_EINVAL, "attn_kernel must be 0..5");
     mc::g_attn_kernel = value;
   } else if (k == "mmdit_two_streams") {
     if (value < -1 || value > 6) return fail(MC_EINVAL, "mmdit_two_streams must be -1 (by shape), 0, 1 or a diagnostic mode 2..6");

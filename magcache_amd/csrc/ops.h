@@ -87,11 +87,13 @@ struct AttnParams {
 };
 // K/V rows in [shard_valid, shard_rows) are read (and masked) but must hold finite values.
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);     // picks a kernel
-hipError_t launch_attention_v4(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows, pipelined, 16x16x32 MFMA
-hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream);  // the same pipeline on 32x32x16 (round 1)
+hipError_t launch_attention_v5(const AttnParams& p, hipStream_t stream);  // 4 waves x 64 rows, one wave per SIMD, hand-scheduled (round 3)
+bool attention_v5_supports(const AttnParams& p);                          // one shard, no log-sum-exp merge
+hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows, pipelined, 32x32x16 MFMA (round 1)
+hipError_t launch_attention_v4(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab: the v3 pipeline on 16x16x32 (A/B library only)
 hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)
 hipError_t launch_attention_v2(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)
-extern int g_attn_kernel;  // 0 / 3: attention_v3.hip, 4: attention_v4.hip (1, 2: A/B library only)
+extern int g_attn_kernel;  // 0: by support (see launch_attention), 3: attention_v3.hip, 5: attention_v5.hip where it applies (1, 2, 4: A/B library only)
 
 // ---------------------------------------------------------------- token-wise ops (elementwise.hip)
 // out[m,:] = bf16( LN(x[m,:]) * a + b ),  a = 1+scale (modulate) or weight (affine)

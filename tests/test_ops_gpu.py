@@ -40,10 +40,10 @@ def kernel_variant(request):
     _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
 
 
-@pytest.fixture(params=[3, 4], ids=["attn-32x32x16", "attn-16x16x32"])
+@pytest.fixture(params=[3, 5], ids=["attn-8x32", "attn-4x64"])
 def attn_variant(request):
-    """The attention tests run on the dispatched kernel (attention_v3.hip, v_mfma_f32_32x32x16_bf16) and on
-    attention_v4.hip (the same pipeline on 16x16x32), which stays selectable for the A/B of the MFMA shape."""
+    """The attention tests run on attention_v3.hip (8 waves x 32 rows) and on attention_v5.hip (4 waves x 64 rows, one
+    wave per SIMD, hand-scheduled; it takes the single-shard calls and leaves the others to v3)."""
     lib = _lib.load()
     _lib.check(lib.mc_set_option(b"attn_kernel", request.param))
     yield request.param

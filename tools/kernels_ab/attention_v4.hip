@@ -35,8 +35,8 @@
 //    branch: s_nop) and of the packed P (written >= 2 MFMAs before its first use).
 // the LDS-DMA asm below names m0 in its clobber list on purpose (reserved register: the compiler only warns)
 #pragma clang diagnostic ignored "-Winline-asm"
-#include "common.h"
-#include "ops.h"
+#include "../../magcache_amd/csrc/common.h"
+#include "../../magcache_amd/csrc/ops.h"
 
 namespace mc {
 
