@@ -28,7 +28,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, h) for h in ("common.h", "ops.h", "gemm_epilogue.h", "attention_v5_body.inc",
-                                               "attention_v5_clobbers.inc")]
+                                               "attention_v5_clobbers.inc", "attention_v5_config.h")]
     headers.append(os.path.join(HERE, "..", "include", "magcache_hip.h"))
     headers.append(os.path.join(HERE, "..", "include", "magcache_mmdit.h"))
     objdir = os.path.join(CSRC, "build")

@@ -51,7 +51,7 @@ def run_block(n_keys, n_heads=2, head=1, q_amp=1.0, seed=0, dma_late=False, load
     QB, OB = 0x1000_0000, 0x4000_0000
     scale = 1.0 / np.sqrt(128.0)
     text = _bind_inputs(gen.generate(cfg))
-    m = emu.Machine(text + "  s_endpgm\n", n_waves=4, lds_bytes=gen.LDS_BYTES, dma_late=dma_late, load_late=load_late)
+    m = emu.Machine(text + "  s_endpgm\n", n_waves=4, lds_bytes=gen.lds_bytes(cfg), dma_late=dma_late, load_late=load_late)
     m.add_buffer(QB, qkv_bits)
     m.add_buffer(OB, out_bits)
     q_ptr = QB + head * 256
@@ -60,7 +60,9 @@ def run_block(n_keys, n_heads=2, head=1, q_amp=1.0, seed=0, dma_late=False, load
     o_ptr = OB + head * 256
     tail = n_keys - (n_tiles - 1) * 64
     c = np.float32(scale * 1.4426950408889634)
-    vals = [q_ptr, ldq * 2, k_ptr, ldk * 2, v_ptr, ldv * 2, o_ptr, ldo * 2, n_tiles, tail, int(c.view(np.uint32)), None, 0]
+    nrec = ((rows_k - 1) * ldk + 128) * 2      # bytes reachable from the head's first K / V element
+    vals = [q_ptr, ldq * 2, k_ptr, ldk * 2, v_ptr, ldv * 2, o_ptr, ldo * 2, n_tiles, tail, int(c.view(np.uint32)), None, 0,
+            nrec, nrec]
     for w in m.waves:
         for k, val in enumerate(vals):
             r = IN_BASE + 2 * k
@@ -80,7 +82,7 @@ def run_block(n_keys, n_heads=2, head=1, q_amp=1.0, seed=0, dma_late=False, load
     return rel, got, want, m
 
 
-@pytest.mark.parametrize("n_keys", [64, 37, 128, 130, 320, 300])
+@pytest.mark.parametrize("n_keys", [64, 37, 128, 130, 320, 300, 577])
 def test_v5_stream_matches_fp64_attention(n_keys):
     rel, got, want, _ = run_block(n_keys)
     assert np.isfinite(got).all()
@@ -99,6 +101,12 @@ def test_v5_deferred_rescale_branch_is_exercised_and_right():
     rel, got, want, _ = run_block(448, q_amp=4.0, seed=5, spike=True, dma_late=True, load_late=True)
     assert np.isfinite(got).all()
     assert rel < 8e-3, rel
+
+
+def test_v5_two_deep_ring_variant_is_also_right():
+    rel, got, want, _ = run_block(300, dma_late=True, load_late=True, seed=7, cfg={"nst": 2, "ahead": 1})
+    assert np.isfinite(got).all()
+    assert rel < 5e-3, rel
 
 
 def test_v5_inc_file_is_current():
