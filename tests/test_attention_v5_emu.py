@@ -82,23 +82,26 @@ def run_block(n_keys, n_heads=2, head=1, q_amp=1.0, seed=0, dma_late=False, load
     return rel, got, want, m
 
 
+@pytest.mark.parametrize("mfma", [32, 16])
 @pytest.mark.parametrize("n_keys", [64, 37, 128, 130, 320, 300, 577])
-def test_v5_stream_matches_fp64_attention(n_keys):
-    rel, got, want, _ = run_block(n_keys)
+def test_v5_stream_matches_fp64_attention(n_keys, mfma):
+    rel, got, want, _ = run_block(n_keys, cfg={"mfma": mfma})
     assert np.isfinite(got).all()
     assert rel < 5e-3, rel
 
 
+@pytest.mark.parametrize("mfma", [32, 16])
 @pytest.mark.parametrize("dma_late,load_late", [(True, False), (False, True), (True, True)])
-def test_v5_stream_is_race_free_under_late_completion(dma_late, load_late):
-    rel, got, want, _ = run_block(300, dma_late=dma_late, load_late=load_late, seed=3)
+def test_v5_stream_is_race_free_under_late_completion(dma_late, load_late, mfma):
+    rel, got, want, _ = run_block(300, dma_late=dma_late, load_late=load_late, seed=3, cfg={"mfma": mfma})
     assert np.isfinite(got).all()
     assert rel < 5e-3, rel
 
 
-def test_v5_deferred_rescale_branch_is_exercised_and_right():
+@pytest.mark.parametrize("mfma", [32, 16])
+def test_v5_deferred_rescale_branch_is_exercised_and_right(mfma):
     # large logits + a spiked key: the row maximum jumps by far more than 2^RTHR in a late tile
-    rel, got, want, _ = run_block(448, q_amp=4.0, seed=5, spike=True, dma_late=True, load_late=True)
+    rel, got, want, _ = run_block(448, q_amp=4.0, seed=5, spike=True, dma_late=True, load_late=True, cfg={"mfma": mfma})
     assert np.isfinite(got).all()
     assert rel < 8e-3, rel
 

@@ -534,7 +534,56 @@ class Machine:
             self.wr(w, D, u32(val), r)
         self._haz_write(w, ins, D, "mfma")
 
+    def i_v_mfma_f32_16x16x32_bf16(self, w, ins, o):
+        D, A, B, C = o
+        self._haz_read(w, ins, A, "mfma_ab")
+        self._haz_read(w, ins, B, "mfma_ab")
+        same = C[0] == "reg" and C[1:4] == D[1:4]
+        if C[0] == "reg":
+            self._haz_read(w, ins, C, "mfma_c_same" if same else "mfma_c")
+            if not same and C[1] == D[1] and not (C[2] + C[3] <= D[2] or D[2] + D[3] <= C[2]):
+                raise HazardError(f"line {ins.line}: partially overlapping C / D in '{ins.text}'")
+        a = np.stack([self.rd(w, A, i) for i in range(4)], axis=1)
+        b = np.stack([self.rd(w, B, i) for i in range(4)], axis=1)
+
+        def unpack(x):
+            lo = bf16_to_f32(x & np.uint32(0xFFFF))
+            hi = bf16_to_f32(x >> np.uint32(16))
+            return np.stack([lo, hi], axis=2).reshape(64, 8)
+        af, bfr = unpack(a).astype(np.float64), unpack(b).astype(np.float64)
+        Am = np.zeros((16, 32))
+        Bm = np.zeros((32, 16))
+        for l in range(64):
+            Am[l & 15, 8 * (l >> 4):8 * (l >> 4) + 8] = af[l]
+            Bm[8 * (l >> 4):8 * (l >> 4) + 8, l & 15] = bfr[l]
+        with np.errstate(all="ignore"):
+            Dm = Am @ Bm
+        lanes = np.arange(64)
+        for r in range(4):
+            rows = 4 * (lanes >> 4) + r
+            c = f32(self.rd(w, C, r)).astype(np.float64) if C[0] == "reg" else np.full(64, float(f32(np.array([C[1]], dtype=np.uint32))[0]))
+            with np.errstate(all="ignore"):
+                val = (Dm[rows, lanes & 15] + c).astype(np.float32)
+            self.wr(w, D, u32(val), r)
+        self._haz_write(w, ins, D, "mfma")
+
     # ---- LDS
+    def i_ds_bpermute_b32(self, w, ins, o):
+        """vdst[l] = vdata[(vaddr[l] >> 2) & 63]   (no LDS memory involved; completes with lgkmcnt)"""
+        self._haz_read(w, ins, o[1], "mem")
+        self._haz_read(w, ins, o[2], "mem")
+        idx = ((self.rd(w, o[1]) + np.uint32(ins.mods.get("offset", 0))) >> np.uint32(2)) & np.uint32(63)
+        data = self.rd(w, o[2]).copy()
+        dst = o[0]
+        val = data[idx]
+        if self.load_late:
+            self.wr(w, dst, np.full(64, POISON, dtype=np.uint32))
+            w.lgkm_q.append(lambda: self.wr(w, dst, val))
+        else:
+            self.wr(w, dst, val)
+            w.lgkm_q.append(None)
+        self._haz_write(w, ins, dst, "mem")
+
     def _lds_read(self, addr, n):
         out = np.zeros((64, n), dtype=np.uint8)
         for l in range(64):

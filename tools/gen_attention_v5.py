@@ -2,22 +2,28 @@
 """Generator of the hand-scheduled body of csrc/attention_v5.hip (flash-style attention, head_dim 128, gfx950).
 
 Why a generator: the kernel runs ONE wave per SIMD with the whole 512-register file (O^T, Q and the K fragments in AGPRs,
-the scores and the softmax in arch VGPRs).  One wave hides at most ~5 single-issue instructions behind each
-v_mfma_f32_32x32x16_bf16 (CDNA4 guide, "one wave per SIMD" rows; tools/ubench_issue.cpp), so the instruction stream is
-written in ISSUE ORDER -- one MFMA, then the fillers of its gap, placed by an issue-cost budget -- with explicit
-registers, explicit s_waitcnt counts and explicit hazard padding; hipcc only wraps it (kernel arguments in SGPRs, launch).
-This script emits that stream as csrc/attention_v5_body.inc (a C string for one asm statement); tests/test_attention_v5_emu.py
-executes it on the functional emulator tools/gcn_emu.py.
+the scores and the softmax in arch VGPRs).  One wave hides only a few single-issue instructions behind each MFMA (CDNA4
+guide, "one wave per SIMD" rows; tools/ubench_issue.cpp), so the instruction stream is written in ISSUE ORDER -- one MFMA,
+then the fillers of its gap, placed by an issue-cost budget -- with explicit registers, explicit s_waitcnt counts and
+explicit hazard padding; hipcc only wraps it (kernel arguments in SGPRs, launch).  This script emits that stream as
+csrc/attention_v5_body.inc (a C string for one asm statement); tests/test_attention_v5_emu.py executes it on the
+functional emulator tools/gcn_emu.py.
 
-Shape: workgroup = 4 waves = 256 query rows of one head; wave = 64 rows = two 32-row blocks (qb 0 / 1).  Per 64-key tile t:
-   phase 1  S(t+1)^T = K(t+1) Q^T     32 MFMA  ||  P(t) = exp2(S(t)) (first part), row sums, bf16 pack IN PLACE,
+Shape: workgroup = 4 waves = 256 query rows of one head; wave = 64 rows.  Per 64-key tile t:
+   phase 1  S(t+1)^T = K(t+1) Q^T              ||  P(t) = exp2(S(t)) (first part), row sums, bf16 pack IN PLACE,
                                                     LDS-DMA of K(t+2+A) / V(t+A), first V^T fragments of phase 2
-   phase 2  O^T += V(t)^T P(t)^T      32 MFMA  ||  rest of P(t), V^T fragments (ds_read_b64_tr_b16) just in time,
-                                                    K(t+2) fragments -> AGPRs (ds_read_b128), row maxima of S(t+1)
+   phase 2  O^T += V(t)^T P(t)^T               ||  rest of P(t), V^T fragments (ds_read_b64_tr_b16) just in time,
+                                                    K(t+2) fragments -> AGPRs (ds_read_b128), lane maxima of S(t+1)
    one counted s_waitcnt vmcnt + s_barrier per tile; K / V tiles in NST-deep LDS rings, A tiles ahead.
+Two MFMA shapes (cfg "mfma"):
+   32: v_mfma_f32_32x32x16_bf16, wave = 2 query blocks x 32 rows, 32 MFMAs per phase (the shape of attention_v3.hip);
+   16: v_mfma_f32_16x16x32_bf16, wave = 4 query blocks x 16 rows, 64 MFMAs per phase -- the same fragment reads, VALU
+       work and registers, but the shape that draws less power per FLOP (tools/ubench_mfma_issue2.cpp: 2030 vs 1800
+       TFLOP/s on random operands at the power limit); the kernel is power-limited (profiles/r03), so this is the lever.
 Same math as attention_v3.hip: Q pre-multiplied by scale*log2(e), accumulators of S start from -m (c_init), deferred
-rescale (wave-uniform rare branch when a row maximum exceeds the reference by more than 2^RTHR), S^T accumulators consumed
-directly as the B operand of the PV MFMA, K rows swizzled chunk16 ^= row&15 and V rows chunk64 ^= row&3 on the DMA source.
+rescale (wave-uniform rare branch when a lane maximum exceeds the reference by more than 2^RTHR), S^T accumulators consumed
+directly as the B operand of the PV MFMA (contraction index permuted consistently on both operands), K rows swizzled
+chunk16 ^= row&15; V rows chunk64 ^= row&3 (32) / chunk32 ^= row&7 (16), applied on the DMA source address.
 LDS-DMA = buffer_load_dwordx4 ... lds (profiles/r03/lds_dma_probe.log: LDS address = M0 + imm + lane*16, M0 reaches all
 160 KiB, imm and the SGPR offset are added to the global address and range-checked against num_records -- tiles past the
 end of the key sequence read zeros, so the cursors need no clamp).
@@ -32,31 +38,18 @@ TILE = 16384                 # one 64-key tile image: 64 rows x 256 B
 RTHR = 4.0
 
 DEFAULT_CFG = {
+    "mfma": 32,              # 32: 32x32x16, 16: 16x16x32
     "nst": 4,                # LDS ring depth (K and V)
     "ahead": 2,              # iteration t issues K(t+2+ahead), V(t+ahead)
-    "cap1": 5.4, "cap2": 5.5,        # issue-cost budget of one MFMA gap in phase 1 / 2
+    "cap1": 5.4, "cap2": 5.6,        # issue-cost budget per 32nd of a phase (= one 32x32x16 MFMA, two 16x16x32)
     "w_exp": 1.67, "w_dma": 6.0, "w_wait": 0.5,
-    "dma_gaps": [1, 4, 7, 10, 14, 17, 20, 23],   # phase-1 gaps of the 4 K and 4 V pieces
-    "vlook": 4,              # V^T fragments are read this many MFMA pairs ahead
+    "dma_at": [1, 4, 7, 10, 14, 17, 20, 23],   # positions (32nds of phase 1) of the 4 K and 4 V pieces
+    "vlook": 4,              # V^T fragments are read this many fragments ahead
     "wait_group": 2,         # one s_waitcnt per this many V^T fragments
-    "rowmax_from": 13,       # first phase-2 gap that may read S(t+1)
-    "kread_from": 2,         # first phase-2 gap with a K fragment read
+    "rowmax_from": 13,       # first position of phase 2 that may read S(t+1)
+    "kread_from": 2,         # first position of phase 2 with a K fragment read
 }
 
-# ---------------------------------------------------------------- register map
-V_S = (0, 64)                # two S buffers, [qb][kb] x 16
-V_CI = 128                   # c_init[qb] x 16
-V_VF, NVF = 160, 8           # V^T fragment buffers, 4 registers each
-V_KOFF, V_VOFF, V_SRCK, V_SRCV = 192, 200, 204, 208
-V_L = 212                    # row-sum chains [qb][2]
-V_RM = 216                   # row-max partials [qb][4]
-V_MX = 224                   # [qb]
-V_M = 226                    # running reference m [qb]
-V_T = 228                    # temporaries 228..243
-V_LANE, V_L31, V_HALF, V_L15 = 244, 245, 246, 247
-V_QOFF = 248                 # [qb] byte offset of the lane's query row (Q loads, O stores)
-V_ALPHA, V_D = 250, 252      # [qb]
-V_NINF, V_TAILV = 254, 255
 A_O, A_Q, A_K = 0, 128, 192
 
 # SGPRs owned by the asm block (inputs are copied here first)
@@ -83,13 +76,62 @@ def s(n, cnt=1):
     return f"s{n}" if cnt == 1 else f"s[{n}:{n + cnt - 1}]"
 
 
-def S(buf, qb, kb):
-    return V_S[buf] + (qb * 2 + kb) * 16
+class Mode:
+    """everything that depends on the MFMA shape"""
+
+    def __init__(self, mfma):
+        assert mfma in (16, 32)
+        self.mfma = mfma
+        big = mfma == 32
+        self.NQB = 2 if big else 4          # query blocks per wave
+        self.NKB = 2 if big else 4          # key blocks per tile (rows of one S accumulator tile)
+        self.NDS = 8 if big else 4          # d-steps of the QK product (16 / 32 wide)
+        self.ACC = 16 if big else 4         # registers of one accumulator tile
+        self.NKS = 4 if big else 2          # key steps of the PV product (16 / 32 keys)
+        self.NDB = 4 if big else 8          # d-blocks of O^T (32 / 16 rows)
+        self.NM = self.NQB * self.NKB * self.NDS          # MFMAs per phase: 32 / 64
+        self.mn = "v_mfma_f32_32x32x16_bf16" if big else "v_mfma_f32_16x16x32_bf16"
+        self.QBS = 64 // self.NQB           # S registers per query block per buffer
+        # ---- VGPR map
+        self.V_S = (0, 64)
+        self.V_CI = 128                     # c_init[qb] x ACC
+        r = 128 + self.NQB * self.ACC       # 160 / 144
+        self.V_VF, self.NVF = r, 8
+        r += 32
+        self.V_KOFF = r; r += self.NDS      # K fragment address per d-step
+        self.V_VOFF = r; r += self.NDB      # V^T fragment address per d-block
+        self.V_SRCK = r; r += 4
+        self.V_SRCV = r; r += 4
+        self.V_L = r; r += 2 * self.NQB     # row-sum chains [qb][2]
+        self.V_RM = r; r += 8               # lane-max partials (shared by the query blocks, one after the other)
+        self.V_MX = r; r += self.NQB
+        self.V_M = r; r += self.NQB
+        self.V_ALPHA = r; r += self.NQB
+        self.V_D = r; r += self.NQB
+        self.V_QOFF = r; r += self.NQB
+        self.V_T = r; r += 14
+        self.V_LANE, self.V_L15, self.V_G, self.V_QL = r, r + 1, r + 2, r + 3   # lane, lane&15, lane>>4 | lane>>5, query row in block
+        r += 4
+        self.V_NINF, self.V_TAILV, self.V_X16, self.V_X32 = r, r + 1, r + 2, r + 3
+        r += 4
+        assert r <= 256, r
+
+    def S(self, buf, qb, kb):
+        return self.V_S[buf] + qb * self.QBS + kb * self.ACC
+
+    def P(self, buf, qb, ks):
+        """first of the 8 accumulator registers of key step ks (its 4 packed words end up in the first 4)"""
+        return self.V_S[buf] + qb * self.QBS + 8 * ks
+
+    def key_of(self, kb, r):
+        """key index inside the tile of accumulator register r of key block kb, for the lane group 0 (add 4 * group)"""
+        return 32 * kb + (r & 3) + 8 * (r >> 2) if self.mfma == 32 else 16 * kb + r
 
 
 class Emitter:
     def __init__(self, cfg):
         self.cfg = cfg
+        self.M = Mode(cfg["mfma"])
         self.lines = []
         self.n = 0                # instructions emitted
         self.lds_issued = 0       # LDS reads issued so far (program order)
@@ -140,18 +182,18 @@ class Emitter:
 
 
 # ---------------------------------------------------------------- instruction streams
-def finish_stream(buf, groups):
+def finish_stream(M, buf, groups):
     """softmax finish of S_cur for the given (ks, qb) groups: exp2 in place, row sums, bf16 pack in place (word p of a
     group lands in its register p: the 4 words of a key step are the B operand of its PV MFMAs).  One linear list,
     software-skewed so that nothing uses a result produced less than two instructions earlier."""
     ex, rest = [], []
     for ks, qb in groups:
-        base = S(buf, qb, ks >> 1) + 8 * (ks & 1)
+        base = M.P(buf, qb, ks)
         for p in range(4):        # pair p = elements 2p, 2p+1 -> word p
             r0, r1 = base + 2 * p, base + 2 * p + 1
             ex.append([f"v_exp_f32 {v(r0)}, {v(r0)}", f"v_exp_f32 {v(r1)}, {v(r1)}"])
-            rest.append([f"v_add_f32 {v(V_L + 2 * qb)}, {v(V_L + 2 * qb)}, {v(r0)}",
-                         f"v_add_f32 {v(V_L + 2 * qb + 1)}, {v(V_L + 2 * qb + 1)}, {v(r1)}",
+            rest.append([f"v_add_f32 {v(M.V_L + 2 * qb)}, {v(M.V_L + 2 * qb)}, {v(r0)}",
+                         f"v_add_f32 {v(M.V_L + 2 * qb + 1)}, {v(M.V_L + 2 * qb + 1)}, {v(r1)}",
                          f"v_cvt_pk_bf16_f32 {v(base + p)}, {v(r0)}, {v(r1)}"])
     out = []
     n = len(ex)
@@ -164,34 +206,42 @@ def finish_stream(buf, groups):
     return out
 
 
-def rowmax_stream(buf, qb):
-    """per-LANE maximum over the 32 accumulator registers of S[buf][qb][0..1] -> V_MX+qb (a lane sees half of a row's 64
-    keys; the other half sits in lane +-32 and is folded in only where a row value is needed: combine_halves)"""
-    e = [S(buf, qb, kb) + r for kb in range(2) for r in range(16)]
-    rm = [V_RM + 4 * qb + i for i in range(4)]
+def rowmax_stream(M, buf, qb):
+    """per-LANE maximum over the accumulator registers of S[buf][qb][*] -> V_MX+qb (a lane sees a part of a row's 64
+    keys; the other parts sit in lanes +-16 / +-32 and are folded in only where a row value is needed: combine_lanes)"""
+    e = [M.S(buf, qb, kb) + r for kb in range(M.NKB) for r in range(M.ACC)]
+    nch = 4 if len(e) >= 32 else 2
+    rm = [M.V_RM + 4 * (qb & 1) + i for i in range(nch)]
     out = []
-    for c in range(4):
+    for c in range(nch):
         out.append(f"v_max3_f32 {v(rm[c])}, {v(e[3 * c])}, {v(e[3 * c + 1])}, {v(e[3 * c + 2])}")
-    k = 12
+    k = 3 * nch
     c = 0
-    while k < 32:
+    while k < len(e):
         out.append(f"v_max3_f32 {v(rm[c])}, {v(rm[c])}, {v(e[k])}, {v(e[k + 1])}")
         k += 2
-        c = (c + 1) & 3
-    out.append(f"v_max3_f32 {v(rm[0])}, {v(rm[0])}, {v(rm[1])}, {v(rm[2])}")
-    out.append(f"v_max_f32 {v(V_MX + qb)}, {v(rm[0])}, {v(rm[3])}")
+        c = (c + 1) % nch
+    if nch == 4:
+        out.append(f"v_max3_f32 {v(rm[0])}, {v(rm[0])}, {v(rm[1])}, {v(rm[2])}")
+        out.append(f"v_max_f32 {v(M.V_MX + qb)}, {v(rm[0])}, {v(rm[3])}")
+    else:
+        out.append(f"v_max_f32 {v(M.V_MX + qb)}, {v(rm[0])}, {v(rm[1])}")
     return out
 
 
-def combine_halves(x, op):
-    """x <- op(x, x of lane +-32) on both halves"""
-    t = V_T + 12
-    return [f"v_mov_b32 {v(t)}, {v(x)}", "s_nop 1", f"v_permlane32_swap_b32 {v(t)}, {v(x)}", f"{op} {v(x)}, {v(t)}, {v(x)}"]
+def combine_lanes(M, x, op):
+    """x <- op over the lanes that hold parts of the same query row (lane ^ 32, and lane ^ 16 for the 16x16 shape).
+    ds_bpermute: rare paths only."""
+    t = M.V_T + 12
+    out = []
+    for xr in ([M.V_X32] if M.mfma == 32 else [M.V_X32, M.V_X16]):
+        out += [f"ds_bpermute_b32 {v(t)}, {v(xr)}, {v(x)}", "s_waitcnt lgkmcnt(0)", f"{op} {v(x)}, {v(t)}, {v(x)}"]
+    return out
 
 
-def dma_piece(op, j):
+def dma_piece(M, op, j):
     """1 KiB piece j of this wave's 4 for operand op: rows 16 wv + 4 j .. +3 of the tile; M0 = this wave's 4 KiB of the slot"""
-    src, srd, cur = (V_SRCK, S_KSRD, S_KCUR) if op == "K" else (V_SRCV, S_VSRD, S_VCUR)
+    src, srd, cur = (M.V_SRCK, S_KSRD, S_KCUR) if op == "K" else (M.V_SRCV, S_VSRD, S_VCUR)
     return f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(cur)} offen offset:{1024 * j} lds"
 
 
@@ -201,35 +251,41 @@ def dma_tile_now(E, op, slot):
     E.i(f"s_mov_b32 m0, {s(dst + slot)}")
     E.i("s_nop 0")
     for j in range(4):
-        E.i(dma_piece(op, j))
+        E.i(dma_piece(E.M, op, j))
     E.i(f"s_add_u32 {s(cur)}, {s(cur)}, {s(step)}")
 
 
-def qk_mfma(buf_nxt, ds, qb, kb):
-    d = S(buf_nxt, qb, kb)
-    c = v(V_CI + 16 * qb, 16) if ds == 0 else v(d, 16)
-    return f"v_mfma_f32_32x32x16_bf16 {v(d, 16)}, {a(A_K + (kb * 8 + ds) * 4, 4)}, {a(A_Q + (qb * 8 + ds) * 4, 4)}, {c}"
+def qk_mfma(M, buf_nxt, ds, qb, kb):
+    d = M.S(buf_nxt, qb, kb)
+    c = v(M.V_CI + M.ACC * qb, M.ACC) if ds == 0 else v(d, M.ACC)
+    return f"{M.mn} {v(d, M.ACC)}, {a(A_K + (kb * M.NDS + ds) * 4, 4)}, {a(A_Q + (qb * M.NDS + ds) * 4, 4)}, {c}"
 
 
 def pv_mfma(E, buf_cur, ks, db, qb):
-    f = ks * 4 + db
-    o = a(A_O + (qb * 4 + db) * 16, 16)
-    p = S(buf_cur, qb, ks >> 1) + 8 * (ks & 1)
+    M = E.M
+    f = ks * M.NDB + db
+    o = a(A_O + (qb * M.NDB + db) * M.ACC, M.ACC)
+    p = M.P(buf_cur, qb, ks)
     for w in range(4):            # the P words must have been packed, and not just now (VALU write -> MFMA read)
         assert E.written_at.get(p + w, -1) >= 0 and E.n - E.written_at[p + w] >= 2, f"P word {p + w} not ready for PV ks={ks}"
-    return f"v_mfma_f32_32x32x16_bf16 {o}, {v(V_VF + 4 * (f % NVF), 4)}, {v(p, 4)}, {o}"
+    return f"{M.mn} {o}, {v(M.V_VF + 4 * (f % M.NVF), 4)}, {v(p, 4)}, {o}"
 
 
-def vfrag_reads(E, f, off, addr_base=V_VOFF):
-    """the two transposing reads of V^T fragment f = 4 ks + db; off = byte offset of the tile's ring slot"""
-    ks, db = f >> 2, f & 3
-    b = V_VF + 4 * (f % NVF)
-    E.ds(f"ds_read_b64_tr_b16 {v(b, 2)}, {v(addr_base + db)} offset:{off + ks * 4096}")
-    return E.ds(f"ds_read_b64_tr_b16 {v(b + 2, 2)}, {v(addr_base + db)} offset:{off + ks * 4096 + 2048}")
+def vfrag_reads(E, f, off, addr_base=None):
+    """the two transposing reads of V^T fragment f = NDB ks + db; off = byte offset of the tile's ring slot"""
+    M = E.M
+    addr_base = M.V_VOFF if addr_base is None else addr_base
+    ks, db = f // M.NDB, f % M.NDB
+    b = M.V_VF + 4 * (f % M.NVF)
+    step, second = (4096, 2048) if M.mfma == 32 else (8192, 4096)
+    E.ds(f"ds_read_b64_tr_b16 {v(b, 2)}, {v(addr_base + db)} offset:{off + ks * step}")
+    return E.ds(f"ds_read_b64_tr_b16 {v(b + 2, 2)}, {v(addr_base + db)} offset:{off + ks * step + second}")
 
 
 def kfrag_read(E, kb, ds, slot):
-    return E.ds(f"ds_read_b128 {a(A_K + (kb * 8 + ds) * 4, 4)}, {v(V_KOFF + ds)} offset:{slot * TILE + kb * 8192}")
+    M = E.M
+    kbs = 8192 if M.mfma == 32 else 4096
+    return E.ds(f"ds_read_b128 {a(A_K + (kb * M.NDS + ds) * 4, 4)}, {v(M.V_KOFF + ds)} offset:{slot * TILE + kb * kbs}")
 
 
 class Body:
@@ -244,83 +300,107 @@ class Body:
         self.v_dma_slot = (b + ah) % nst        # V(t+ahead)
 
 
+class Credit:
+    """issue-cost budget of the MFMA gaps: every gap earns `cap`, fillers spend their weight; a debt carries over"""
+
+    def __init__(self, cap):
+        self.cap, self.c = cap, 0.0
+
+    def gap(self):
+        self.c = min(self.c + self.cap, 2.0 * self.cap)
+
+    def spend(self, w):
+        self.c -= w
+
+    def can(self, w):
+        return self.c >= w - 1e-9
+
+
 def emit_phase1(E, B):
-    cfg = E.cfg
+    cfg, M = E.cfg, E.M
     cur, nxt = B.par, 1 - B.par
-    fin = finish_stream(cur, [(ks, qb) for ks in range(4) for qb in range(2)])
-    gaps = cfg["dma_gaps"]
+    sc = M.NM // 32                      # gaps per "position"
+    fin = finish_stream(M, cur, [(ks, qb) for ks in range(M.NKS) for qb in range(M.NQB)])
+    pos = [p * sc for p in cfg["dma_at"]]
     dma_at = {}
     for j in range(4):
-        dma_at[gaps[j]] = ("K", j)
-        dma_at[gaps[4 + j]] = ("V", j)
-    m0_at = {gaps[0] - 1: "K", gaps[4] - 1: "V"}
-    adv_at = {gaps[3] + 1: "K", gaps[7] + 1: "V"}
+        dma_at[pos[j]] = ("K", j)
+        dma_at[pos[4 + j]] = ("V", j)
+    m0_at = {pos[0] - 1: "K", pos[4] - 1: "V"}
+    adv_at = {pos[3] + 1: "K", pos[7] + 1: "V"}
     vlook = cfg["vlook"]
+    first = M.NM - vlook * M.NQB         # the first V^T fragments of phase 2, one per NQB MFMAs
     tickets = {}
+    cr = Credit(cfg["cap1"] / sc)
     g = 0
-    for ds in range(8):
-        for kb in range(2):
-            for qb in range(2):
-                E.i(qk_mfma(nxt, ds, qb, kb))
-                used = 0.0
+    for ds in range(M.NDS):
+        for kb in range(M.NKB):
+            for qb in range(M.NQB):
+                E.i(qk_mfma(M, nxt, ds, qb, kb))
+                cr.gap()
                 if g in m0_at:
                     op = m0_at[g]
                     E.i(f"s_mov_b32 m0, {s((S_DK if op == 'K' else S_DV) + (B.k_dma_slot if op == 'K' else B.v_dma_slot))}")
-                    used += 1
+                    cr.spend(1)
                 if g in dma_at:
-                    t = dma_piece(*dma_at[g])
+                    t = dma_piece(M, *dma_at[g])
                     E.i(t)
-                    used += E.weight(t)
+                    cr.spend(E.weight(t))
                 if g in adv_at:
                     op = adv_at[g]
                     cur_, step = (S_KCUR, S_KSTEP) if op == "K" else (S_VCUR, S_VSTEP)
                     E.i(f"s_add_u32 {s(cur_)}, {s(cur_)}, {s(step)}")
-                    used += 1
-                first = 32 - 2 * vlook          # the first V^T fragments of phase 2, one per MFMA pair
-                if g >= first and (g - first) % 2 == 0:
-                    f = (g - first) // 2
+                    cr.spend(1)
+                if g >= first and (g - first) % M.NQB == 0:
+                    f = (g - first) // M.NQB
                     tickets[f] = vfrag_reads(E, f, B.v_read_slot * TILE)
-                    used += 2
-                while fin and used + E.weight(fin[0]) <= cfg["cap1"] + 1e-9:
-                    used += E.weight(fin[0])
+                    cr.spend(2)
+                while fin and cr.can(E.weight(fin[0])):
+                    cr.spend(E.weight(fin[0]))
                     E.i(fin.pop(0))
                 g += 1
     return tickets, fin
 
 
-def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=V_VOFF):
-    """32 PV MFMAs; `last`: no next tile (no K fragments, no row maxima)"""
-    cfg = E.cfg
+def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=None):
+    """the PV MFMAs; `last`: no next tile (no K fragments, no lane maxima)"""
+    cfg, M = E.cfg, E.M
     cur, nxt = par, 1 - par
-    rmx = [] if last else rowmax_stream(nxt, 0) + rowmax_stream(nxt, 1)
-    kreads = [] if last else [(kb, ds) for ds in range(8) for kb in range(2)]
+    sc = M.NM // 32
+    rmx = []
+    if not last:
+        for qb in range(M.NQB):
+            rmx += rowmax_stream(M, nxt, qb)
+    kreads = [] if last else [(kb, ds) for ds in range(M.NDS) for kb in range(M.NKB)]
     kt = []
     vlook, wg = cfg["vlook"], cfg["wait_group"]
+    nfr = M.NKS * M.NDB
+    cr = Credit(cfg["cap2"] / sc)
     g = 0
-    for ks in range(4):
-        for db in range(4):
-            f = ks * 4 + db
-            for qb in range(2):
-                used = 0.0
+    for ks in range(M.NKS):
+        for db in range(M.NDB):
+            f = ks * M.NDB + db
+            for qb in range(M.NQB):
+                cr.gap()
                 if qb == 0:
                     # wait for this fragment (and, grouped, the next wg-1 whose reads are already issued)
-                    want = max(tickets[x] for x in range(f, min(16, f - f % wg + wg)) if x in tickets)
+                    want = max(tickets[x] for x in range(f, min(nfr, f - f % wg + wg)) if x in tickets)
                     if E.wait_lds(want):
-                        used += cfg["w_wait"]
+                        cr.spend(cfg["w_wait"])
                 E.i(pv_mfma(E, cur, ks, db, qb))
-                if qb == 0 and f + vlook < 16:
+                if qb == 0 and f + vlook < nfr:
                     tickets[f + vlook] = vfrag_reads(E, f + vlook, v_off, v_addr)
-                    used += 2
-                while fin and used + E.weight(fin[0]) <= cfg["cap2"] + 1e-9:
-                    used += E.weight(fin[0])
+                    cr.spend(2)
+                while fin and cr.can(E.weight(fin[0])):
+                    cr.spend(E.weight(fin[0]))
                     E.i(fin.pop(0))
-                if kreads and g >= cfg["kread_from"] and (qb == 1 or not fin) and used + 1 <= cfg["cap2"] + 1e-9:
+                if kreads and g >= cfg["kread_from"] * sc and (qb == M.NQB - 1 or not fin) and cr.can(1):
                     kb_, ds_ = kreads.pop(0)
                     kt.append(kfrag_read(E, kb_, ds_, k_slot))
-                    used += 1
-                if g >= cfg["rowmax_from"]:
-                    while rmx and used + 1 <= cfg["cap2"] + 1e-9:
-                        used += 1
+                    cr.spend(1)
+                if g >= cfg["rowmax_from"] * sc:
+                    while rmx and cr.can(1):
+                        cr.spend(1)
                         E.i(rmx.pop(0))
                 g += 1
     assert not fin, "finish stream does not fit: raise cap1 / cap2"
@@ -335,8 +415,13 @@ def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=V_V
 
 def emit_decide(E, par, ret):
     """does some lane's maximum of S_cur exceed the reference by more than 2^RTHR?  (rare, wave-uniform branch)"""
-    E.i(f"v_max_f32 {v(V_T)}, {v(V_MX)}, {v(V_MX + 1)}")
-    E.i(f"v_cmp_lt_f32 vcc, {s(S_THR)}, {v(V_T)}")
+    M = E.M
+    if M.NQB == 2:
+        E.i(f"v_max_f32 {v(M.V_T)}, {v(M.V_MX)}, {v(M.V_MX + 1)}")
+    else:
+        E.i(f"v_max3_f32 {v(M.V_T)}, {v(M.V_MX)}, {v(M.V_MX + 1)}, {v(M.V_MX + 2)}")
+        E.i(f"v_max_f32 {v(M.V_T)}, {v(M.V_T)}, {v(M.V_MX + 3)}")
+    E.i(f"v_cmp_lt_f32 vcc, {s(S_THR)}, {v(M.V_T)}")
     E.i(f"s_mov_b32 {s(S_RET)}, {ret}")
     E.i(f"s_cbranch_vccnz L_rescale{par}")
     E.label(f"L_back{ret}")
@@ -344,35 +429,36 @@ def emit_decide(E, par, ret):
 
 def emit_rescale_routine(E, par, n_ret):
     """O, l, S_cur and c_init move to a new reference: d = max(row max, floor) (floor = 0, -inf on the first tile)"""
+    M = E.M
     E.label(f"L_rescale{par}")
     E.i("s_nop 15")
-    for qb in range(2):
-        for t in combine_halves(V_MX + qb, "v_max_f32"):
+    for qb in range(M.NQB):
+        for t in combine_lanes(M, M.V_MX + qb, "v_max_f32"):
             E.i(t)
-    for qb in range(2):
-        d, al = V_D + qb, V_ALPHA + qb
-        E.i(f"v_max_f32 {v(d)}, {s(S_FLOOR)}, {v(V_MX + qb)}")
-        E.i(f"v_add_f32 {v(V_M + qb)}, {v(V_M + qb)}, {v(d)}")
+    for qb in range(M.NQB):
+        d, al = M.V_D + qb, M.V_ALPHA + qb
+        E.i(f"v_max_f32 {v(d)}, {s(S_FLOOR)}, {v(M.V_MX + qb)}")
+        E.i(f"v_add_f32 {v(M.V_M + qb)}, {v(M.V_M + qb)}, {v(d)}")
         E.i(f"v_exp_f32 {v(al)}, -{v(d)}")
-        E.i(f"v_sub_f32 {v(V_MX + qb)}, {v(V_MX + qb)}, {v(d)}")
+        E.i(f"v_sub_f32 {v(M.V_MX + qb)}, {v(M.V_MX + qb)}, {v(d)}")
     E.i("s_nop 0")
-    for qb in range(2):
-        d, al = V_D + qb, V_ALPHA + qb
-        E.i(f"v_mul_f32 {v(V_L + 2 * qb)}, {v(V_L + 2 * qb)}, {v(al)}")
-        E.i(f"v_mul_f32 {v(V_L + 2 * qb + 1)}, {v(V_L + 2 * qb + 1)}, {v(al)}")
-        for kb in range(2):
-            for r in range(16):
-                x = S(par, qb, kb) + r
-                E.i(f"v_sub_f32 {v(x)}, {v(x)}, {v(d)}")
-        for r in range(16):
-            E.i(f"v_sub_f32 {v(V_CI + 16 * qb + r)}, {v(V_CI + 16 * qb + r)}, {v(d)}")
-        for r0 in range(0, 64, 4):
+    for qb in range(M.NQB):
+        d, al = M.V_D + qb, M.V_ALPHA + qb
+        E.i(f"v_mul_f32 {v(M.V_L + 2 * qb)}, {v(M.V_L + 2 * qb)}, {v(al)}")
+        E.i(f"v_mul_f32 {v(M.V_L + 2 * qb + 1)}, {v(M.V_L + 2 * qb + 1)}, {v(al)}")
+        for r in range(M.QBS):
+            x = M.S(par, qb, 0) + r
+            E.i(f"v_sub_f32 {v(x)}, {v(x)}, {v(d)}")
+        for r in range(M.ACC):
+            E.i(f"v_sub_f32 {v(M.V_CI + M.ACC * qb + r)}, {v(M.V_CI + M.ACC * qb + r)}, {v(d)}")
+        no = M.NDB * M.ACC                 # O registers of this query block
+        for r0 in range(0, no, 4):
             for k in range(4):
-                E.i(f"v_accvgpr_read_b32 {v(V_T + 4 + k)}, {a(A_O + 64 * qb + r0 + k)}")
+                E.i(f"v_accvgpr_read_b32 {v(M.V_T + 4 + k)}, {a(A_O + no * qb + r0 + k)}")
             for k in range(4):
-                E.i(f"v_mul_f32 {v(V_T + 4 + k)}, {v(V_T + 4 + k)}, {v(al)}")
+                E.i(f"v_mul_f32 {v(M.V_T + 4 + k)}, {v(M.V_T + 4 + k)}, {v(al)}")
             for k in range(4):
-                E.i(f"v_accvgpr_write_b32 {a(A_O + 64 * qb + r0 + k)}, {v(V_T + 4 + k)}")
+                E.i(f"v_accvgpr_write_b32 {a(A_O + no * qb + r0 + k)}, {v(M.V_T + 4 + k)}")
     E.i(f"s_mov_b32 {s(S_FLOOR)}, 0")
     E.i("s_nop 4")
     for r in range(n_ret):
@@ -396,19 +482,21 @@ def emit_body(E, b, ret):
 
 def emit_mask_tail(E, par):
     """the last tile of the key sequence has S_TAIL < 64 valid keys: -inf on the others, lane maxima again"""
-    for qb in range(2):
-        for kb in range(2):
-            for r in range(16):
-                key = 32 * kb + (r & 3) + 8 * (r >> 2)
-                x = S(par, qb, kb) + r
-                E.i(f"v_cmp_ge_i32 vcc, {key}, {v(V_TAILV)}")
-                E.i(f"v_cndmask_b32 {v(x)}, {v(x)}, {v(V_NINF)}, vcc")
-    for t in rowmax_stream(par, 0) + rowmax_stream(par, 1):
-        E.i(t)
+    M = E.M
+    for qb in range(M.NQB):
+        for kb in range(M.NKB):
+            for r in range(M.ACC):
+                x = M.S(par, qb, kb) + r
+                E.i(f"v_cmp_ge_i32 vcc, {M.key_of(kb, r)}, {v(M.V_TAILV)}")
+                E.i(f"v_cndmask_b32 {v(x)}, {v(x)}, {v(M.V_NINF)}, vcc")
+    for qb in range(M.NQB):
+        for t in rowmax_stream(M, par, qb):
+            E.i(t)
 
 
 def emit_last(E, par, ret):
     """last tile: P from S_cur (buffer par), PV with V from the ring slot whose byte offset is in S_VSLOT; no next S"""
+    M = E.M
     E.comment(f"---- last tile, S_cur = buffer {par}")
     E.written_at = {}
     E.i("s_waitcnt vmcnt(0)")
@@ -419,21 +507,33 @@ def emit_last(E, par, ret):
     emit_mask_tail(E, par)
     E.label(f"L_nomask{ret}")
     emit_decide(E, par, ret)
-    for db in range(4):                   # V^T fragment addresses of the (run-time) ring slot
-        E.i(f"v_add_u32 {v(V_T + 8 + db)}, {s(S_VSLOT)}, {v(V_VOFF + db)}")
-    for t in finish_stream(par, [(ks, qb) for ks in range(4) for qb in range(2)]):
+    va = M.V_VF + 4 * (M.NVF - 2)         # the last two fragment buffers hold the run-time V addresses here
+    assert M.NDB <= 8
+    for db in range(M.NDB):               # V^T fragment addresses of the (run-time) ring slot
+        E.i(f"v_add_u32 {v(va + db)}, {s(S_VSLOT)}, {v(M.V_VOFF + db)}")
+    for t in finish_stream(M, par, [(ks, qb) for ks in range(M.NKS) for qb in range(M.NQB)]):
         E.i(t)
     E.i("s_nop 1")
-    tickets = {}
-    for f in range(E.cfg["vlook"]):
-        tickets[f] = vfrag_reads(E, f, 0, V_T + 8)
-    emit_phase2(E, par, tickets, [], 0, last=True, v_addr=V_T + 8)
+    # unpipelined: fragment by fragment through buffer 0 (this code runs once per 256-row block)
+    nfr = M.NKS * M.NDB
+    for f in range(nfr):
+        ks, db = f // M.NDB, f % M.NDB
+        step, second = (4096, 2048) if M.mfma == 32 else (8192, 4096)
+        b = M.V_VF
+        E.ds(f"ds_read_b64_tr_b16 {v(b, 2)}, {v(va + db)} offset:{ks * step}")
+        t = E.ds(f"ds_read_b64_tr_b16 {v(b + 2, 2)}, {v(va + db)} offset:{ks * step + second}")
+        E.wait_lds(t)
+        for qb in range(M.NQB):
+            o = a(A_O + (qb * M.NDB + db) * M.ACC, M.ACC)
+            E.i(f"{M.mn} {o}, {v(b, 4)}, {v(M.P(par, qb, ks), 4)}, {o}")
+        E.i("s_nop 7")                    # the next fragment overwrites the operand registers of these MFMAs
 
 
 def emit_prologue(E):
-    cfg = E.cfg
+    cfg, M = E.cfg, E.M
     nst, ah = cfg["nst"], cfg["ahead"]
     vring = nst * TILE
+    big = M.mfma == 32
     E.comment("---- inputs -> fixed SGPRs")
     E.i(f"s_mov_b64 {s(S_Q, 2)}, %0")
     E.i(f"s_mov_b32 {s(S_LDQ)}, %1")
@@ -457,48 +557,76 @@ def emit_prologue(E):
         E.i(f"s_mov_b32 {s(srd + 2)}, {s(nrec)}")
         E.i(f"s_mov_b32 {s(srd + 3)}, 0x00020000")
     E.comment("---- lane constants")
-    E.i(f"v_mbcnt_lo_u32_b32 {v(V_LANE)}, -1, 0")
-    E.i(f"v_mbcnt_hi_u32_b32 {v(V_LANE)}, -1, {v(V_LANE)}")
-    E.i(f"v_and_b32 {v(V_L31)}, 31, {v(V_LANE)}")
-    E.i(f"v_lshrrev_b32 {v(V_HALF)}, 5, {v(V_LANE)}")
-    E.i(f"v_and_b32 {v(V_L15)}, 15, {v(V_LANE)}")
-    t0, t1, t2, g4 = V_T, V_T + 1, V_T + 2, V_T + 3
-    E.i(f"v_lshrrev_b32 {v(g4)}, 4, {v(V_LANE)}")
-    # K fragment offsets: l31 * 256 + (((2 ds + half) ^ l15) << 4) + lds
-    E.i(f"v_lshlrev_b32 {v(t0)}, 8, {v(V_L31)}")
+    E.i(f"v_mbcnt_lo_u32_b32 {v(M.V_LANE)}, -1, 0")
+    E.i(f"v_mbcnt_hi_u32_b32 {v(M.V_LANE)}, -1, {v(M.V_LANE)}")
+    E.i(f"v_and_b32 {v(M.V_L15)}, 15, {v(M.V_LANE)}")
+    t0, t1, t2, g4 = M.V_T, M.V_T + 1, M.V_T + 2, M.V_T + 3
+    E.i(f"v_lshrrev_b32 {v(g4)}, 4, {v(M.V_LANE)}")
+    if big:
+        E.i(f"v_lshrrev_b32 {v(M.V_G)}, 5, {v(M.V_LANE)}")               # half
+        E.i(f"v_and_b32 {v(M.V_QL)}, 31, {v(M.V_LANE)}")
+    else:
+        E.i(f"v_mov_b32 {v(M.V_G)}, {v(g4)}")                            # lane group 0..3
+        E.i(f"v_mov_b32 {v(M.V_QL)}, {v(M.V_L15)}")
+    E.i(f"v_xor_b32 {v(t0)}, 32, {v(M.V_LANE)}")
+    E.i(f"v_lshlrev_b32 {v(M.V_X32)}, 2, {v(t0)}")
+    E.i(f"v_xor_b32 {v(t0)}, 16, {v(M.V_LANE)}")
+    E.i(f"v_lshlrev_b32 {v(M.V_X16)}, 2, {v(t0)}")
+    # K fragment offsets: row * 256 + ((chunk ^ (row & 15)) << 4) + lds
+    #   32: row = lane & 31, chunk = 2 ds + half        16: row = lane & 15, chunk = 4 ds + group
+    E.i(f"v_lshlrev_b32 {v(t0)}, 8, {v(M.V_QL)}")
     E.i(f"v_add_u32 {v(t0)}, {s(S_LDS)}, {v(t0)}")
-    for ds in range(8):
-        E.i(f"v_or_b32 {v(t1)}, {2 * ds}, {v(V_HALF)}")
-        E.i(f"v_xor_b32 {v(t1)}, {v(t1)}, {v(V_L15)}")
-        E.i(f"v_lshl_add_u32 {v(V_KOFF + ds)}, {v(t1)}, 4, {v(t0)}")
-    # V^T fragment offsets: VRING + (4 half + vr) * 256 + dg * 32 + c * 8 + ((db ^ vr) << 6),  vr = l15 >> 2, dg = (lane >> 4) & 1, c = lane & 3
-    E.i(f"v_lshrrev_b32 {v(t1)}, 2, {v(V_L15)}")                       # vr
-    E.i(f"v_lshl_add_u32 {v(t0)}, {v(V_HALF)}, 2, {v(t1)}")            # 4 half + vr
-    E.i(f"v_lshlrev_b32 {v(t0)}, 8, {v(t0)}")
-    E.i(f"v_and_b32 {v(t2)}, 1, {v(g4)}")
-    E.i(f"v_lshl_add_u32 {v(t0)}, {v(t2)}, 5, {v(t0)}")
-    E.i(f"v_and_b32 {v(t2)}, 3, {v(V_LANE)}")
-    E.i(f"v_lshl_add_u32 {v(t0)}, {v(t2)}, 3, {v(t0)}")
-    E.i(f"v_add_u32 {v(t0)}, {vring}, {v(t0)}")
-    E.i(f"v_add_u32 {v(t0)}, {s(S_LDS)}, {v(t0)}")
-    for db in range(4):
-        E.i(f"v_xor_b32 {v(t2)}, {db}, {v(t1)}")
-        E.i(f"v_lshl_add_u32 {v(V_VOFF + db)}, {v(t2)}, 6, {v(t0)}")
-    # DMA source offsets (bytes from the tile's first row, minus the piece's immediate offset): row = 16 wv + 4 j + g4
+    for ds in range(M.NDS):
+        E.i(f"v_or_b32 {v(t1)}, {(2 if big else 4) * ds}, {v(M.V_G)}")
+        E.i(f"v_xor_b32 {v(t1)}, {v(t1)}, {v(M.V_L15)}")
+        E.i(f"v_lshl_add_u32 {v(M.V_KOFF + ds)}, {v(t1)}, 4, {v(t0)}")
+    if big:
+        # V^T fragment offsets: VRING + (4 half + vr) * 256 + dg * 32 + c * 8 + ((db ^ vr) << 6),  vr = l15 >> 2, dg = (lane >> 4) & 1, c = lane & 3
+        E.i(f"v_lshrrev_b32 {v(t1)}, 2, {v(M.V_L15)}")                   # vr
+        E.i(f"v_lshl_add_u32 {v(t0)}, {v(M.V_G)}, 2, {v(t1)}")           # 4 half + vr
+        E.i(f"v_lshlrev_b32 {v(t0)}, 8, {v(t0)}")
+        E.i(f"v_and_b32 {v(t2)}, 1, {v(g4)}")
+        E.i(f"v_lshl_add_u32 {v(t0)}, {v(t2)}, 5, {v(t0)}")
+        E.i(f"v_and_b32 {v(t2)}, 3, {v(M.V_LANE)}")
+        E.i(f"v_lshl_add_u32 {v(t0)}, {v(t2)}, 3, {v(t0)}")
+        E.i(f"v_add_u32 {v(t0)}, {vring}, {v(t0)}")
+        E.i(f"v_add_u32 {v(t0)}, {s(S_LDS)}, {v(t0)}")
+        for db in range(M.NDB):
+            E.i(f"v_xor_b32 {v(t2)}, {db}, {v(t1)}")
+            E.i(f"v_lshl_add_u32 {v(M.V_VOFF + db)}, {v(t2)}, 6, {v(t0)}")
+    else:
+        # V^T fragment offsets: VRING + vrow * 256 + ((db ^ (vrow & 7)) << 5) + c * 8,  vrow = 4 group + (l15 >> 2), c = l15 & 3
+        E.i(f"v_lshrrev_b32 {v(t1)}, 2, {v(M.V_L15)}")
+        E.i(f"v_lshl_add_u32 {v(t1)}, {v(M.V_G)}, 2, {v(t1)}")           # vrow (0..15)
+        E.i(f"v_lshlrev_b32 {v(t0)}, 8, {v(t1)}")
+        E.i(f"v_and_b32 {v(t2)}, 3, {v(M.V_L15)}")
+        E.i(f"v_lshl_add_u32 {v(t0)}, {v(t2)}, 3, {v(t0)}")
+        E.i(f"v_add_u32 {v(t0)}, {vring}, {v(t0)}")
+        E.i(f"v_add_u32 {v(t0)}, {s(S_LDS)}, {v(t0)}")
+        E.i(f"v_and_b32 {v(t1)}, 7, {v(t1)}")                            # vrow & 7
+        for db in range(M.NDB):
+            E.i(f"v_xor_b32 {v(t2)}, {db}, {v(t1)}")
+            E.i(f"v_lshl_add_u32 {v(M.V_VOFF + db)}, {v(t2)}, 5, {v(t0)}")
+    # DMA source offsets (bytes from the tile's first row, minus the piece's immediate offset): row = 16 wv + 4 j + g4,
+    #   K: 16-byte slot l15 holds chunk l15 ^ (row & 15);  V: l15 ^ ((row & 3) << 2)  (32)  /  l15 ^ ((row & 7) << 1)  (16)
     E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 4")
     for j in range(4):
-        E.i(f"v_add_u32 {v(t0)}, {4 * j}, {v(g4)}")                    # row & 15
-        E.i(f"v_add_u32 {v(t1)}, {s(S_T)}, {v(t0)}")                   # row
+        E.i(f"v_add_u32 {v(t0)}, {4 * j}, {v(g4)}")                      # row & 15
+        E.i(f"v_add_u32 {v(t1)}, {s(S_T)}, {v(t0)}")                     # row
         E.i(f"v_mul_lo_u32 {v(t2)}, {v(t1)}, {s(S_LDK)}")
-        E.i(f"v_xor_b32 {v(t0)}, {v(t0)}, {v(V_L15)}")                 # chunk
-        E.i(f"v_lshl_add_u32 {v(V_SRCK + j)}, {v(t0)}, 4, {v(t2)}")
+        E.i(f"v_xor_b32 {v(t0)}, {v(t0)}, {v(M.V_L15)}")                 # chunk
+        E.i(f"v_lshl_add_u32 {v(M.V_SRCK + j)}, {v(t0)}, 4, {v(t2)}")
         E.i(f"v_mul_lo_u32 {v(t2)}, {v(t1)}, {s(S_LDV)}")
-        E.i(f"v_lshlrev_b32 {v(t0)}, 2, {v(g4)}")                      # (row & 3) << 2
-        E.i(f"v_xor_b32 {v(t0)}, {v(t0)}, {v(V_L15)}")
-        E.i(f"v_lshl_add_u32 {v(V_SRCV + j)}, {v(t0)}, 4, {v(t2)}")
+        if big:
+            E.i(f"v_lshlrev_b32 {v(t0)}, 2, {v(g4)}")                    # (row & 3) << 2
+        else:
+            E.i(f"v_add_u32 {v(t0)}, {4 * (j & 1)}, {v(g4)}")            # row & 7
+            E.i(f"v_lshlrev_b32 {v(t0)}, 1, {v(t0)}")
+        E.i(f"v_xor_b32 {v(t0)}, {v(t0)}, {v(M.V_L15)}")
+        E.i(f"v_lshl_add_u32 {v(M.V_SRCV + j)}, {v(t0)}, 4, {v(t2)}")
         if j:
-            E.i(f"v_subrev_u32 {v(V_SRCK + j)}, {1024 * j}, {v(V_SRCK + j)}")
-            E.i(f"v_subrev_u32 {v(V_SRCV + j)}, {1024 * j}, {v(V_SRCV + j)}")
+            E.i(f"v_subrev_u32 {v(M.V_SRCK + j)}, {1024 * j}, {v(M.V_SRCK + j)}")
+            E.i(f"v_subrev_u32 {v(M.V_SRCV + j)}, {1024 * j}, {v(M.V_SRCV + j)}")
     # LDS destinations of this wave's pieces, tile steps, counters
     E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 12")
     E.i(f"s_add_u32 {s(S_T)}, {s(S_T)}, {s(S_LDS)}")
@@ -512,36 +640,38 @@ def emit_prologue(E):
     E.i(f"s_mov_b32 {s(S_VCUR)}, 0")
     E.i(f"s_mov_b32 {s(S_FLOOR)}, 0xff800000")
     E.i(f"s_mov_b32 {s(S_THR)}, {RTHR}")
-    E.i(f"v_mov_b32 {v(V_NINF)}, 0xff800000")
-    E.i(f"v_lshlrev_b32 {v(t0)}, 2, {v(V_HALF)}")
-    E.i(f"v_sub_u32 {v(V_TAILV)}, {s(S_TAIL)}, {v(t0)}")              # key index bound seen by this half
+    E.i(f"v_mov_b32 {v(M.V_NINF)}, 0xff800000")
+    E.i(f"v_lshlrev_b32 {v(t0)}, 2, {v(M.V_G)}")
+    E.i(f"v_sub_u32 {v(M.V_TAILV)}, {s(S_TAIL)}, {v(t0)}")              # key index bound seen by this lane group
     E.comment("---- K(0), K(1) on their way; Q rows -> registers")
     dma_tile_now(E, "K", 0)
     dma_tile_now(E, "K", 1)
-    # query row of the lane: wv * 64 + 32 qb + l31
+    # query row of the lane: wv * 64 + QROWS * qb + ql;  bytes inside the row: 16 * group (the lane's 8 d of a d-step)
+    qrows = 64 // M.NQB
     E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 6")
-    for qb in range(2):
-        E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(V_L31)}")
+    for qb in range(M.NQB):
+        E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(M.V_QL)}")
         if qb:
-            E.i(f"v_add_u32 {v(t0)}, 32, {v(t0)}")
-        E.i(f"v_mul_lo_u32 {v(V_QOFF + qb)}, {v(t0)}, {s(S_LDQ)}")
-        E.i(f"v_lshl_add_u32 {v(V_QOFF + qb)}, {v(V_HALF)}, 4, {v(V_QOFF + qb)}")
-    for qb in range(2):
-        for ds in range(8):
-            E.i(f"global_load_dwordx4 {v((qb * 8 + ds) * 4, 4)}, {v(V_QOFF + qb)}, {s(S_Q, 2)} offset:{ds * 32}")
+            E.i(f"v_add_u32 {v(t0)}, {qrows * qb}, {v(t0)}")
+        E.i(f"v_mul_lo_u32 {v(M.V_QOFF + qb)}, {v(t0)}, {s(S_LDQ)}")
+        E.i(f"v_lshl_add_u32 {v(M.V_QOFF + qb)}, {v(M.V_G)}, 4, {v(M.V_QOFF + qb)}")
+    dstep = 32 if big else 64               # bytes of one d-step in a row
+    for qb in range(M.NQB):
+        for ds in range(M.NDS):
+            E.i(f"global_load_dwordx4 {v((qb * M.NDS + ds) * 4, 4)}, {v(M.V_QOFF + qb)}, {s(S_Q, 2)} offset:{ds * dstep}")
     E.comment("---- O = 0, l = 0, m = 0, c_init = 0")
     for r in range(128):
         E.i(f"v_accvgpr_write_b32 {a(A_O + r)}, 0")
-    for r in range(32):
-        E.i(f"v_mov_b32 {v(V_CI + r)}, 0")
-    for r in range(4):
-        E.i(f"v_mov_b32 {v(V_L + r)}, 0")
-    E.i(f"v_mov_b32 {v(V_M)}, 0")
-    E.i(f"v_mov_b32 {v(V_M + 1)}, 0")
+    for r in range(M.NQB * M.ACC):
+        E.i(f"v_mov_b32 {v(M.V_CI + r)}, 0")
+    for r in range(2 * M.NQB):
+        E.i(f"v_mov_b32 {v(M.V_L + r)}, 0")
+    for qb in range(M.NQB):
+        E.i(f"v_mov_b32 {v(M.V_M + qb)}, 0")
     E.i("s_waitcnt vmcnt(0)")
     E.comment("---- Q * scale*log2(e), rounded to bf16 again, into AGPRs")
     for r in range(64):
-        lo, hi = V_T + 4, V_T + 5
+        lo, hi = M.V_T + 4, M.V_T + 5
         E.i(f"v_lshlrev_b32 {v(lo)}, 16, {v(r)}")
         E.i(f"v_and_b32 {v(hi)}, 0xffff0000, {v(r)}")
         E.i(f"v_mul_f32 {v(lo)}, {s(S_C)}, {v(lo)}")
@@ -551,18 +681,18 @@ def emit_prologue(E):
     E.i("s_barrier")
     E.comment("---- S(0) = K(0) Q^T into buffer 0, then the fragments of K(1)")
     tk = None
-    for ds in range(8):
-        for kb in range(2):
+    for ds in range(M.NDS):
+        for kb in range(M.NKB):
             tk = kfrag_read(E, kb, ds, 0)
     E.wait_lds(tk)
     E.i("s_nop 1")
-    for ds in range(8):
-        for kb in range(2):
-            for qb in range(2):
-                E.i(qk_mfma(0, ds, qb, kb))
+    for ds in range(M.NDS):
+        for kb in range(M.NKB):
+            for qb in range(M.NQB):
+                E.i(qk_mfma(M, 0, ds, qb, kb))
     E.i("s_nop 7")
-    for ds in range(8):
-        for kb in range(2):
+    for ds in range(M.NDS):
+        for kb in range(M.NKB):
             tk = kfrag_read(E, kb, ds, 1)
     E.wait_lds(tk)
     E.i("s_barrier")                       # every wave has read K(0) and K(1): their slots may be refilled
@@ -578,47 +708,60 @@ def emit_prologue(E):
     emit_mask_tail(E, 0)
     E.i("s_branch L_pro_done")
     E.label("L_pro_rowmax")
-    for t in rowmax_stream(0, 0) + rowmax_stream(0, 1):
-        E.i(t)
+    for qb in range(M.NQB):
+        for t in rowmax_stream(M, 0, qb):
+            E.i(t)
     E.label("L_pro_done")
 
 
 def emit_epilogue(E):
+    M = E.M
+    big = M.mfma == 32
     E.comment("---- O / l -> bf16 -> global")
     E.i("s_nop 15")
-    t0 = V_T
+    t0 = M.V_T
+    qrows = 64 // M.NQB
     E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 6")
-    for qb in range(2):
-        E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(V_L31)}")
+    for qb in range(M.NQB):
+        E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(M.V_QL)}")
         if qb:
-            E.i(f"v_add_u32 {v(t0)}, 32, {v(t0)}")
-        E.i(f"v_mul_lo_u32 {v(V_QOFF + qb)}, {v(t0)}, {s(S_LDO)}")
-        E.i(f"v_lshl_add_u32 {v(V_QOFF + qb)}, {v(V_HALF)}, 3, {v(V_QOFF + qb)}")
-    for qb in range(2):
-        l = V_L + 2 * qb
+            E.i(f"v_add_u32 {v(t0)}, {qrows * qb}, {v(t0)}")
+        E.i(f"v_mul_lo_u32 {v(M.V_QOFF + qb)}, {v(t0)}, {s(S_LDO)}")
+        E.i(f"v_lshl_add_u32 {v(M.V_QOFF + qb)}, {v(M.V_G)}, 3, {v(M.V_QOFF + qb)}")   # 4 d = 8 bytes per lane group
+    for qb in range(M.NQB):
+        l = M.V_L + 2 * qb
         E.i(f"v_add_f32 {v(l)}, {v(l)}, {v(l + 1)}")
-        for t in combine_halves(l, "v_add_f32"):
+        for t in combine_lanes(M, l, "v_add_f32"):
             E.i(t)
-        E.i(f"v_rcp_f32 {v(V_ALPHA + qb)}, {v(l)}")
+        E.i(f"v_rcp_f32 {v(M.V_ALPHA + qb)}, {v(l)}")
     E.i("s_nop 0")
-    for qb in range(2):
-        for db in range(4):
-            for g in range(4):
-                r = A_O + (qb * 4 + db) * 16 + 4 * g
-                x = V_T + 4
+    for qb in range(M.NQB):
+        for db in range(M.NDB):
+            for g in range(M.ACC // 4):
+                r = A_O + (qb * M.NDB + db) * M.ACC + 4 * g
+                x = M.V_T + 4
                 for k in range(4):
                     E.i(f"v_accvgpr_read_b32 {v(x + k)}, {a(r + k)}")
                 for k in range(4):
-                    E.i(f"v_mul_f32 {v(x + k)}, {v(x + k)}, {v(V_ALPHA + qb)}")
+                    E.i(f"v_mul_f32 {v(x + k)}, {v(x + k)}, {v(M.V_ALPHA + qb)}")
                 E.i(f"v_cvt_pk_bf16_f32 {v(x)}, {v(x)}, {v(x + 1)}")
                 E.i(f"v_cvt_pk_bf16_f32 {v(x + 1)}, {v(x + 2)}, {v(x + 3)}")
-                E.i(f"global_store_dwordx2 {v(V_QOFF + qb)}, {v(x, 2)}, {s(S_O, 2)} offset:{db * 64 + g * 16}")
+                off = db * 64 + g * 16 if big else db * 32
+                E.i(f"global_store_dwordx2 {v(M.V_QOFF + qb)}, {v(x, 2)}, {s(S_O, 2)} offset:{off}")
                 E.i("s_nop 1")
     E.i("s_waitcnt vmcnt(0)")
 
 
+MODE_DEFAULTS = {32: {"cap1": 5.4, "cap2": 5.2}, 16: {"cap1": 6.2, "cap2": 5.4}}   # smallest budgets whose P words are ready in time
+
+
+def full_cfg(cfg=None):
+    cfg = dict(cfg or {})
+    return dict(DEFAULT_CFG, **dict(MODE_DEFAULTS[cfg.get("mfma", DEFAULT_CFG["mfma"])], **cfg))
+
+
 def generate(cfg=None):
-    cfg = dict(DEFAULT_CFG, **(cfg or {}))
+    cfg = full_cfg(cfg)
     nst = cfg["nst"]
     U = nst * 2 // math.gcd(nst, 2)
     assert cfg["ahead"] >= 1 and cfg["ahead"] + 2 <= nst + 1, "ring too shallow for this prefetch distance"
@@ -654,7 +797,7 @@ def generate(cfg=None):
 
 
 def lds_bytes(cfg=None):
-    return 2 * dict(DEFAULT_CFG, **(cfg or {}))["nst"] * TILE
+    return 2 * full_cfg(cfg)["nst"] * TILE
 
 
 def to_inc(text):
@@ -691,7 +834,7 @@ def parse_overrides(items):
     cfg = {}
     for it in items or []:
         k, val = it.split("=", 1)
-        cfg[k] = [int(x) for x in val.split(",")] if k == "dma_gaps" else (float(val) if "." in val else int(val))
+        cfg[k] = [int(x) for x in val.split(",")] if k == "dma_at" else (float(val) if "." in val else int(val))
     return cfg
 
 
