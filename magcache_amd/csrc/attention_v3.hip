@@ -525,7 +525,7 @@ hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream) {
 // for the sequence-parallel forms.  The A/B library (tools/build_ab_lib.py, -DMC_AB_KERNELS) also links
 // tools/kernels_ab/attention{,_v2,_v4}.hip as 1 / 2 / 4.
 int g_attn_kernel = 0;
-constexpr int kDefaultAttnKernel = 3;
+constexpr int kDefaultAttnKernel = 5;   // attention_v5 where it applies (profiles/r03: +13 % over v3), v3 otherwise
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
   const bool two_phase = p.skip_shard_p1 != 0 || p.lse_out || p.lse_in;

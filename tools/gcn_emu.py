@@ -452,6 +452,15 @@ class Machine:
     def i_v_log_f32(self, w, ins, o): self._valu(w, ins, o, lambda a: np.log2(a.astype(np.float64)).astype(np.float32), 1, kind="trans", float_=True)
     def i_v_rcp_f32(self, w, ins, o): self._valu(w, ins, o, lambda a: (1.0 / a.astype(np.float64)).astype(np.float32), 1, kind="trans", float_=True)
 
+    def i_v_pk_add_f32(self, w, ins, o):
+        for k in (1, 2):
+            self._haz_read(w, ins, o[k], "valu")
+        with np.errstate(all="ignore"):
+            r = [u32(f32(self.rd(w, o[1], i)) + f32(self.rd(w, o[2], i))) for i in range(2)]
+        self._haz_write(w, ins, o[0], "valu")
+        for i in range(2):
+            self.wr(w, o[0], r[i], i)
+
     def i_v_cvt_pk_bf16_f32(self, w, ins, o):
         self._valu(w, ins, o, lambda a, b: bf16_rne(f32(a)) | (bf16_rne(f32(b)) << np.uint32(16)), 2)
 

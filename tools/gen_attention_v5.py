@@ -38,7 +38,7 @@ TILE = 16384                 # one 64-key tile image: 64 rows x 256 B
 RTHR = 4.0
 
 DEFAULT_CFG = {
-    "mfma": 32,              # 32: 32x32x16, 16: 16x16x32
+    "mfma": 16,              # 32: 32x32x16, 16: 16x16x32 (the default: less power per FLOP, profiles/r03)
     "nst": 4,                # LDS ring depth (K and V)
     "ahead": 2,              # iteration t issues K(t+2+ahead), V(t+ahead)
     "cap1": 5.4, "cap2": 5.6,        # issue-cost budget per 32nd of a phase (= one 32x32x16 MFMA, two 16x16x32)
@@ -47,7 +47,10 @@ DEFAULT_CFG = {
     "vlook": 4,              # V^T fragments are read this many fragments ahead
     "wait_group": 2,         # one s_waitcnt per this many V^T fragments
     "rowmax_from": 13,       # first position of phase 2 that may read S(t+1)
-    "kread_from": 2,         # first position of phase 2 with a K fragment read
+    "kread_from": 2,         # K fragment reads are spread evenly over these positions of phase 2
+    "kread_to": 24,
+    "pad_nop": 0,            # diagnostic: an s_nop of this many states after every MFMA (idle cycles, no work)
+    "pk_add": 0,             # row sums as v_pk_add_f32 (one instruction per pair)
 }
 
 A_O, A_Q, A_K = 0, 128, 192
@@ -102,6 +105,7 @@ class Mode:
         self.V_VOFF = r; r += self.NDB      # V^T fragment address per d-block
         self.V_SRCK = r; r += 4
         self.V_SRCV = r; r += 4
+        r += r & 1                          # even: a chain pair is one v_pk_add_f32 operand
         self.V_L = r; r += 2 * self.NQB     # row-sum chains [qb][2]
         self.V_RM = r; r += 8               # lane-max partials (shared by the query blocks, one after the other)
         self.V_MX = r; r += self.NQB
@@ -182,7 +186,7 @@ class Emitter:
 
 
 # ---------------------------------------------------------------- instruction streams
-def finish_stream(M, buf, groups):
+def finish_stream(M, buf, groups, pk_add=False):
     """softmax finish of S_cur for the given (ks, qb) groups: exp2 in place, row sums, bf16 pack in place (word p of a
     group lands in its register p: the 4 words of a key step are the B operand of its PV MFMAs).  One linear list,
     software-skewed so that nothing uses a result produced less than two instructions earlier."""
@@ -192,17 +196,27 @@ def finish_stream(M, buf, groups):
         for p in range(4):        # pair p = elements 2p, 2p+1 -> word p
             r0, r1 = base + 2 * p, base + 2 * p + 1
             ex.append([f"v_exp_f32 {v(r0)}, {v(r0)}", f"v_exp_f32 {v(r1)}, {v(r1)}"])
-            rest.append([f"v_add_f32 {v(M.V_L + 2 * qb)}, {v(M.V_L + 2 * qb)}, {v(r0)}",
-                         f"v_add_f32 {v(M.V_L + 2 * qb + 1)}, {v(M.V_L + 2 * qb + 1)}, {v(r1)}",
-                         f"v_cvt_pk_bf16_f32 {v(base + p)}, {v(r0)}, {v(r1)}"])
+            if pk_add:
+                rest.append([f"v_pk_add_f32 {v(M.V_L + 2 * qb, 2)}, {v(M.V_L + 2 * qb, 2)}, {v(r0, 2)}",
+                             f"v_cvt_pk_bf16_f32 {v(base + p)}, {v(r0)}, {v(r1)}"])
+            else:
+                rest.append([f"v_add_f32 {v(M.V_L + 2 * qb)}, {v(M.V_L + 2 * qb)}, {v(r0)}",
+                             f"v_add_f32 {v(M.V_L + 2 * qb + 1)}, {v(M.V_L + 2 * qb + 1)}, {v(r1)}",
+                             f"v_cvt_pk_bf16_f32 {v(base + p)}, {v(r0)}, {v(r1)}"])
     out = []
     n = len(ex)
     SK = 2                        # pairs of skew between the exponentials and their consumers
     for k in range(n + SK):
-        if k < n:
-            out += ex[k]
-        if k >= SK:
-            out += rest[k - SK]
+        e_ = list(ex[k]) if k < n else []
+        r_ = list(rest[k - SK]) if k >= SK else []
+        while e_ or r_:           # E R E R R: never two transcendentals back to back
+            if e_:
+                out.append(e_.pop(0))
+            if r_:
+                out.append(r_.pop(0))
+            if not e_:
+                out += r_
+                r_ = []
     return out
 
 
@@ -210,8 +224,8 @@ def rowmax_stream(M, buf, qb):
     """per-LANE maximum over the accumulator registers of S[buf][qb][*] -> V_MX+qb (a lane sees a part of a row's 64
     keys; the other parts sit in lanes +-16 / +-32 and are folded in only where a row value is needed: combine_lanes)"""
     e = [M.S(buf, qb, kb) + r for kb in range(M.NKB) for r in range(M.ACC)]
-    nch = 4 if len(e) >= 32 else 2
-    rm = [M.V_RM + 4 * (qb & 1) + i for i in range(nch)]
+    nch = 8 // M.NQB              # independent chains per query block: 4 (32x32) / 2 (16x16); 8 partial registers in all
+    rm = [M.V_RM + nch * qb + i for i in range(nch)]
     out = []
     for c in range(nch):
         out.append(f"v_max3_f32 {v(rm[c])}, {v(e[3 * c])}, {v(e[3 * c + 1])}, {v(e[3 * c + 2])}")
@@ -226,6 +240,17 @@ def rowmax_stream(M, buf, qb):
         out.append(f"v_max_f32 {v(M.V_MX + qb)}, {v(rm[0])}, {v(rm[3])}")
     else:
         out.append(f"v_max_f32 {v(M.V_MX + qb)}, {v(rm[0])}, {v(rm[1])}")
+    return out
+
+
+def rowmax_all(M, buf):
+    """the lane maxima of all query blocks, their (independent) dependency chains interleaved"""
+    per = [rowmax_stream(M, buf, qb) for qb in range(M.NQB)]
+    out = []
+    for k in range(max(len(x) for x in per)):
+        for x in per:
+            if k < len(x):
+                out.append(x[k])
     return out
 
 
@@ -320,7 +345,7 @@ def emit_phase1(E, B):
     cfg, M = E.cfg, E.M
     cur, nxt = B.par, 1 - B.par
     sc = M.NM // 32                      # gaps per "position"
-    fin = finish_stream(M, cur, [(ks, qb) for ks in range(M.NKS) for qb in range(M.NQB)])
+    fin = finish_stream(M, cur, [(ks, qb) for ks in range(M.NKS) for qb in range(M.NQB)], cfg["pk_add"])
     pos = [p * sc for p in cfg["dma_at"]]
     dma_at = {}
     for j in range(4):
@@ -337,6 +362,8 @@ def emit_phase1(E, B):
         for kb in range(M.NKB):
             for qb in range(M.NQB):
                 E.i(qk_mfma(M, nxt, ds, qb, kb))
+                if cfg["pad_nop"]:
+                    E.i(f"s_nop {cfg['pad_nop'] - 1}")
                 cr.gap()
                 if g in m0_at:
                     op = m0_at[g]
@@ -367,12 +394,11 @@ def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=Non
     cfg, M = E.cfg, E.M
     cur, nxt = par, 1 - par
     sc = M.NM // 32
-    rmx = []
-    if not last:
-        for qb in range(M.NQB):
-            rmx += rowmax_stream(M, nxt, qb)
+    rmx = [] if last else rowmax_all(M, nxt)
     kreads = [] if last else [(kb, ds) for ds in range(M.NDS) for kb in range(M.NKB)]
     kt = []
+    k0, k1 = cfg["kread_from"] * sc, cfg["kread_to"] * sc
+    kdue = [k0 + (k1 - k0) * i // 16 for i in range(16)]      # gap in which the i-th K fragment read is issued
     vlook, wg = cfg["vlook"], cfg["wait_group"]
     nfr = M.NKS * M.NDB
     cr = Credit(cfg["cap2"] / sc)
@@ -388,13 +414,15 @@ def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=Non
                     if E.wait_lds(want):
                         cr.spend(cfg["w_wait"])
                 E.i(pv_mfma(E, cur, ks, db, qb))
+                if cfg["pad_nop"]:
+                    E.i(f"s_nop {cfg['pad_nop'] - 1}")
                 if qb == 0 and f + vlook < nfr:
                     tickets[f + vlook] = vfrag_reads(E, f + vlook, v_off, v_addr)
                     cr.spend(2)
                 while fin and cr.can(E.weight(fin[0])):
                     cr.spend(E.weight(fin[0]))
                     E.i(fin.pop(0))
-                if kreads and g >= cfg["kread_from"] * sc and (qb == M.NQB - 1 or not fin) and cr.can(1):
+                if kreads and g >= kdue[len(kt)]:
                     kb_, ds_ = kreads.pop(0)
                     kt.append(kfrag_read(E, kb_, ds_, k_slot))
                     cr.spend(1)
@@ -489,9 +517,8 @@ def emit_mask_tail(E, par):
                 x = M.S(par, qb, kb) + r
                 E.i(f"v_cmp_ge_i32 vcc, {M.key_of(kb, r)}, {v(M.V_TAILV)}")
                 E.i(f"v_cndmask_b32 {v(x)}, {v(x)}, {v(M.V_NINF)}, vcc")
-    for qb in range(M.NQB):
-        for t in rowmax_stream(M, par, qb):
-            E.i(t)
+    for t in rowmax_all(M, par):
+        E.i(t)
 
 
 def emit_last(E, par, ret):
@@ -708,9 +735,8 @@ def emit_prologue(E):
     emit_mask_tail(E, 0)
     E.i("s_branch L_pro_done")
     E.label("L_pro_rowmax")
-    for qb in range(M.NQB):
-        for t in rowmax_stream(M, 0, qb):
-            E.i(t)
+    for t in rowmax_all(M, 0):
+        E.i(t)
     E.label("L_pro_done")
 
 
@@ -752,7 +778,7 @@ def emit_epilogue(E):
     E.i("s_waitcnt vmcnt(0)")
 
 
-MODE_DEFAULTS = {32: {"cap1": 5.4, "cap2": 5.2}, 16: {"cap1": 6.2, "cap2": 5.4}}   # smallest budgets whose P words are ready in time
+MODE_DEFAULTS = {32: {"cap1": 5.6, "cap2": 5.4}, 16: {"cap1": 6.2, "cap2": 5.8}}   # smallest budgets whose P words are ready in time
 
 
 def full_cfg(cfg=None):
