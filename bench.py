@@ -31,23 +31,26 @@ GRID = (21, 60, 104)
 SEQ = 21 * 30 * 52
 
 
-def flops_forward(cfg, L, Lc=512):
+def flops_forward(cfg, L, Lc=512, ctx_cached=False):
+    """model FLOPs of one forward; ctx_cached: the text K / V projections (4 Lc d^2 per layer) are NOT counted -- the
+    engine computes them once per prompt (mc_set_context), not per forward"""
     d, f, n = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
-    per_layer = 8 * L * d * d + 4 * L * L * d + 4 * L * d * d + 4 * Lc * d * d + 4 * L * Lc * d + 4 * L * d * f
+    per_layer = 8 * L * d * d + 4 * L * L * d + 4 * L * d * d + (0 if ctx_cached else 4 * Lc * d * d) + 4 * L * Lc * d \
+        + 4 * L * d * f
     return n * per_layer + 2 * L * 64 * d * 2
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/rNN/pmc_traffic.json,
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE collected by tools/gpu_pmc2.sh; counters cannot be read from
-    inside this process).  None if no such file."""
+    """(HBM bytes per launch of `kernel`, file it comes from) from the newest committed PMC pass
+    (profiles/rNN/pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; counters cannot be read from inside this
+    process, so this is a COMMITTED constant, labelled as such in the line).  (None, None) if no such file."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         try:
-            return json.load(open(f))[kernel]["bytes_per_launch"]
+            return json.load(open(f))[kernel]["bytes_per_launch"], os.path.relpath(f, ROOT)
         except (KeyError, ValueError, OSError):
             continue
-    return None
+    return None, None
 
 
 def timed(fn, sync, barrier):
@@ -84,9 +87,18 @@ def kernel_rooflines(cfg, device):
     o = torch.empty(Lp, d, dtype=torch.bfloat16, device=device)
     t = ev_time(lambda: H.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, heads, Lp, SEQ, 1, 128 ** -0.5), 5)
     fl = 4.0 * SEQ * SEQ * d
+    traffic, traffic_src = pmc_traffic("attn_fwd_v5_kernel")
     res["attention"] = dict(bound="mfma", achieved=fl / t / 1e12, peak=2500.0, unit="TFLOP/s",
-                            frac=fl / t / 2.5e15, traffic=pmc_traffic("attn_fwd_v3_kernel"), ms=t * 1e3,
-                            shape=f"L={SEQ} heads={heads} hd=128")
+                            frac=fl / t / 2.5e15, traffic=traffic, traffic_source=f"committed PMC pass, not this run: {traffic_src}",
+                            ms=t * 1e3, shape=f"L={SEQ} heads={heads} hd=128")
+    # cross-attention: the same kernel family on 512 text keys (q = the projected tokens, k|v = the cached context rows)
+    Lc = 512
+    kv = torch.randn(Lc, 2 * d, generator=g, device=device).bfloat16()
+    t = ev_time(lambda: H.attention(qkv[:, :d], kv[:, :d], kv[:, d:], o, heads, Lc, Lc, 1, 128 ** -0.5), 20)
+    fl = 4.0 * SEQ * Lc * d
+    by = (2 * Lp * d + 2 * Lc * d) * 2.0            # q in, o out, k and v in
+    res["attention_cross"] = dict(bound="hbm", achieved=by / t / 1e9, peak=8000.0, unit="GB/s", frac=by / t / 8e12,
+                                  mfma_frac=fl / t / 2.5e15, ms=t * 1e3, shape=f"Lq={SEQ} keys={Lc} heads={heads}")
     for name, (N, K, epi) in dict(gemm_qkv=(3 * d, d, 0), gemm_ffn1=(ffn, d, 1), gemm_ffn2=(d, ffn, 2),
                                   gemm_o=(d, d, 2)).items():
         A = torch.randn(Lp, K, generator=g, device=device).bfloat16()
@@ -100,6 +112,21 @@ def kernel_rooflines(cfg, device):
         res[name] = dict(bound="mfma", achieved=fl / t / 1e12, peak=2500.0, unit="TFLOP/s", frac=fl / t / 2.5e15,
                          ms=t * 1e3, shape=f"M={Lp} N={N} K={K}")
         del A, Wt, Cb, X
+    # token-wise kernels of a block (HBM bound): LayerNorm + modulate (fp32 in, bf16 out), RMSNorm + RoPE (bf16 in place)
+    xs = torch.randn(Lp, d, generator=g, device=device)
+    sc, sh = torch.zeros(d, device=device), torch.zeros(d, device=device)
+    xn = torch.empty(Lp, d, dtype=torch.bfloat16, device=device)
+    t = ev_time(lambda: H.ln_modulate(xs, sc, sh, 0, 1e-6, out_bf16=xn), 20)
+    by = Lp * d * 6.0
+    res["ln_modulate"] = dict(bound="hbm", achieved=by / t / 1e9, peak=8000.0, unit="GB/s", frac=by / t / 8e12,
+                              ms=t * 1e3, shape=f"[{Lp},{d}] fp32 -> bf16")
+    cs = H.rope_table(*[gdim // p for gdim, p in zip(GRID, (1, 2, 2))], 0, SEQ).to(device)
+    wq = torch.ones(d, device=device)
+    t = ev_time(lambda: H.rmsnorm_rope(qkv[:SEQ, :d], wq, 1e-6, cs), 20)
+    by = SEQ * d * 4.0 + SEQ * 128 * 4.0
+    res["rmsnorm_rope"] = dict(bound="hbm", achieved=by / t / 1e9, peak=8000.0, unit="GB/s", frac=by / t / 8e12,
+                               ms=t * 1e3, shape=f"[{SEQ},{d}] bf16 in place + RoPE table")
+    del xs, xn
     x0 = torch.randn(SEQ, d, generator=g, device=device).bfloat16()
     r = torch.randn(SEQ, d, generator=g, device=device)
     out = torch.empty(SEQ, d, device=device)
@@ -256,7 +283,10 @@ def main():
     ctx = torch.randn(512, cfg["text_dim"], generator=g, device=device)
     ctx_null = torch.randn(512, cfg["text_dim"], generator=g, device=device)
     sync = torch.cuda.synchronize
-    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+    # MC_BENCH_FORCE_DIST=1 (tests/test_rccl_gpu.py): create the communicator at world size 1 too, so that the N > 1
+    # code around the timed regions (init on the device, all-reduce, barrier, teardown) runs on RCCL on a one-GPU box
+    force_dist = world == 1 and os.environ.get("MC_BENCH_FORCE_DIST") == "1"
+    barrier = (lambda: dist.barrier()) if (world > 1 or force_dist) else (lambda: None)
 
     def make_model(layout, tag):
         cls = type("WanModelHIP_" + tag, (M.WanModelHIP,), {})     # MagCache state lives on the class: one per layout
@@ -277,6 +307,12 @@ def main():
         return float(tt[0])
 
     layout, extra = None, {}
+    if force_dist:
+        dist.init_process_group(backend, device_id=torch.device(device)) if backend == "nccl" else dist.init_process_group(backend)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        extra["rccl_world"] = int(ones[0])
+        extra["comm_backend"] = dist.get_backend()
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(device))
@@ -378,7 +414,8 @@ def main():
         t_nc = max_over_ranks(t_nc) if t_nc is not None else None
 
     if rank == 0:
-        fl = flops_forward(cfg, SEQ)
+        # the shim caches the text context per prompt (mc_set_context): its K / V projections are not in the forwards
+        fl = flops_forward(cfg, SEQ, ctx_cached=True)
         ran = 2 * args.steps - skipped
         line = {
             "metric": "denoising steps/sec (MagCache on), Wan2.1-T2V-1.3B 480p 81f",
@@ -403,11 +440,13 @@ def main():
                                 "here; it raises rather than invent a number)",
             "model_tflops_per_s_nocache": (2 * args.steps * fl / t_nc / 1e12 / world) if t_nc else None,
             "model_tflops_per_s_magcache_ran": ran * fl / t_mc / 1e12 / world,
+            "model_flops_note": "per forward, text K/V projections excluded (cached per prompt by mc_set_context)",
         }
         line.update(extra)
         if world == 1 and not args.no_kernels:
             k = kernel_rooflines(cfg, device)
-            line["roofline"] = {kk: k["attention"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+            line["roofline"] = {kk: k["attention"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                  "traffic_source")}
             if attn_live and attn_live[1] > 0:
                 # the dominant kernel's average launch duration inside the timed (no-cache) region: algorithmic
                 # FLOPs per launch = 4 L^2 d (attention core, no padding, no recompute)
@@ -417,7 +456,7 @@ def main():
                                         avg_launch_ms=ms, launches=attn_live[1],
                                         measured="hipEvent pairs around every self-attention launch of the timed "
                                                  "no-cache region (mc_profile_read)")
-            line["roofline"]["kernel"] = "attn_fwd_v3_kernel (self-attention, 71% of forward FLOPs, 64% of forward time)"
+            line["roofline"]["kernel"] = "attn_fwd_v5_kernel (self-attention, 71% of forward FLOPs)"
             line["kernels"] = k
         if world > 1 and attn_live and attn_live[1] > 0:
             # N > 1: rank 0's self-attention launches of the timed no-cache region (cfg2: one full-sequence launch per
@@ -431,11 +470,12 @@ def main():
                                 "avg_launch_ms": attn_live[0] / attn_live[1],
                                 "measured": "rank 0, hipEvent pairs around every self-attention launch of the timed "
                                             "no-cache region; per-GPU rate",
-                                "kernel": "attn_fwd_v3_kernel (self-attention)"}
+                                "kernel": "self-attention (attn_fwd_v5_kernel for one key shard, attn_fwd_v3_kernel for the "
+                                          "sequence-parallel two-phase form)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -75,13 +75,16 @@ const char* mc_last_error(void);
 const char* mc_version(void);
 /* Process-wide tuning knobs (no reference counterpart; results are identical for every setting up
  * to fp32 summation order): "gemm_kernel" 0 = chosen by shape, 1 = 128x128-tile kernel, 2 = 256x256
- * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 (= 3) = the attention kernel (32x32x16 MFMA), 4 = the same
- * pipeline on 16x16x32 (attention_v4.hip, kept for A/B: not faster on this workload); "mmdit_two_streams": the
+ * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 = default dispatch (attention_v5.hip: 4 waves x 64 query
+ * rows, one wave per SIMD, hand-scheduled 16x16x32 MFMA stream, for single-shard calls; attention_v3.hip: 8 waves x 32
+ * rows, for the sequence-parallel forms), 3 = attention_v3 everywhere, 5 = as 0; "mmdit_two_streams": the
  * text stream of an MM-DiT double block (FLUX / HunyuanVideo) runs on a second HIP stream next to the image stream
- * between a fork and a join event (bit-identical to the one-stream order: 300-replay determinism test, 4000-forward
- * soak; FLUX.1-dev 512x512: +11 %); -1 (default) = by shape: on when the text half is at least 1/16 of the image half
- * and the engine is not sequence parallel; 0 off; 1 on; values 2..6 are the diagnostic splits of
- * tests/two_stream_bisect.py (which pair of kernels overlaps).  Used by the
+ * between a fork and a join event.  OPT-IN (default 0 = off): round 2 traced a run-to-run difference of this overlap to
+ * packed-fp32 VALU instructions executing beside another stream's MFMA waves on one CU and removed them from the
+ * kernels involved (bit-identical since: 300-replay determinism test, 4000-forward soak; FLUX.1-dev 512x512: +11 %),
+ * but the root cause is not understood, so a caller has to ask for it: 1 = on, -1 = by shape (on when the text half
+ * is at least 1/16 of the image half and the engine is not sequence parallel); values 2..6 are the diagnostic splits
+ * of tests/two_stream_bisect.py (which pair of kernels overlaps).  Used by the
  * parity tests and the A/B micro-benchmarks (tools/build_ab_lib.py builds a library that also answers to the
  * retired kernel generations under tools/kernels_ab/). */
 mc_status mc_set_option(const char* key, int value);

@@ -210,8 +210,11 @@ hipError_t launch_residual_sub(const float* x, long ldx, const bf16_t* x0, long 
 hipError_t launch_calib_stats(const float* r, long ldr, const float* rp, long ldrp, int M, int D, double* partial,
                               int n_blocks, double* sums, float* stats, hipStream_t stream) {
   if ((D % 4) || n_blocks <= 0 || M < 2) return hipErrorInvalidValue;
-  // the arrival ticket sits behind the 4*n_blocks partial sums (scratch of 4*n_blocks + 1 doubles, zeroed once)
+  // the arrival ticket sits behind the 4*n_blocks partial sums (scratch of 4*n_blocks + 1 doubles).  It is zeroed on
+  // the stream before EVERY launch (a memset node under capture): a launch that was aborted, or a caller's buffer
+  // that was never cleared, can then not leave a stale count that silently disables the last-block reduction.
   unsigned int* ticket = (unsigned int*)(partial + 4 * (size_t)n_blocks);
+  if (hipError_t e = hipMemsetAsync(ticket, 0, sizeof(double), stream); e != hipSuccess) return e;
   hipLaunchKernelGGL(calib_stats_kernel, dim3(n_blocks), dim3(256), 0, stream, r, ldr, rp, ldrp, M, D, partial, ticket,
                      sums, stats);
   return hipGetLastError();

@@ -40,9 +40,11 @@ namespace mc {
 mc_status set_error_v(mc_status s, const char* fmt, va_list ap);  // engine.cpp
 }
 
-// mc_set_option("mmdit_two_streams", v): -1 = by shape (default: on when the text half is at least 1/16 of the image
-// half -- FLUX; off for HunyuanVideo's 256 text tokens beside 118 800 image tokens), 0 off, 1 on, 2..6 diagnostic
-int g_mmdit_two_streams = -1;
+// mc_set_option("mmdit_two_streams", v): 0 = off (the DEFAULT since round 3: the packed-fp32 co-execution fault behind
+// round 2's nondeterminism has a measured workaround but no root cause -- ADVICE r02 -- so the overlap is opt-in),
+// -1 = by shape (on when the text half is at least 1/16 of the image half and the engine is not sequence parallel: FLUX),
+// 1 on, 2..6 diagnostic splits (tests/two_stream_bisect.py)
+int g_mmdit_two_streams = 0;
 
 namespace {
 
@@ -383,6 +385,14 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
   add_buf(e, cur, "calib_sums", 64);
   add_buf(e, cur, "calib_stats", 64);
   e->ws_need = cur;
+  // side stream and fork / join events of the (optional) two-stream double block: created here, never inside a forward
+  // (a forward may run under stream capture)
+  if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) return cleanup(fail(MC_EHIP, "side stream"));
+  for (int i = 0; i < 8; ++i) {
+    if (hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) != hipSuccess)
+      return cleanup(fail(MC_EHIP, "fork / join events"));
+  }
   *out = e;
   return MC_OK;
 #undef TRY_C
@@ -627,22 +637,15 @@ mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod,
 // Image stream and text stream of a double block touch disjoint rows of every buffer: with "mmdit_two_streams" the text
 // half runs on the engine's side stream between a fork and a join event (capturable: the side stream joins back).
 template <class FI, class FT>
-mc_status run_two(mc_mmdit* e, hipStream_t s, FI&& img_part, FT&& txt_part) {
-  const bool by_shape = g_mmdit_two_streams < 0 && (long)e->Lt * 16 >= (long)e->Li && e->P == 1;
-  if (!(by_shape || g_mmdit_two_streams == 1 || g_mmdit_two_streams == 2)) {   // > 2: diagnostic modes split block_pre only
+mc_status run_two(mc_mmdit* e, hipStream_t s, int mode, FI&& img_part, FT&& txt_part) {
+  const bool by_shape = mode < 0 && (long)e->Lt * 16 >= (long)e->Li && e->P == 1;
+  if (!(by_shape || mode == 1 || mode == 2) || !e->side) {   // > 2: diagnostic modes split block_pre only
     MC_TRY(img_part(s));
     return txt_part(s);
   }
-  if (!e->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    for (int i = 0; i < 8; ++i) {
-      HIP_TRY(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
-    }
-  }
   const int i = e->ev_i;
   e->ev_i = (e->ev_i + 1) & 7;
-  if (g_mmdit_two_streams == 2) {   // diagnostic: same streams and events, but the text half starts after the image half
+  if (mode == 2) {   // diagnostic: same streams and events, but the text half starts after the image half
     MC_TRY(img_part(s));
     HIP_TRY(hipEventRecord(e->ev_fork[i], s));
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork[i], 0));
@@ -752,25 +755,23 @@ mc_status mc_mmdit_block_pre(mc_mmdit* e, int blk, mc_stream stream_) {
     auto txt = [&](hipStream_t q, int ph) { return stream_pre_attn(e, e->dtxt[blk], mt, e->txt0, Lt, q, ph); };
     const int mode = g_mmdit_two_streams;
     if (mode <= 2) {
-      MC_TRY(run_two(e, s, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 3); }));
+      MC_TRY(run_two(e, s, mode, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 3); }));
     } else {   // diagnostic splits: which pair of kernels must overlap for the results to change
-      g_mmdit_two_streams = 1;
       mc_status st = MC_OK;
       if (mode == 3) {          // text LN + GEMM beside the image half; text head norm afterwards, serial
-        st = run_two(e, s, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 1); });
+        st = run_two(e, s, 1, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 1); });
         if (st == MC_OK) st = txt(s, 2);
       } else if (mode == 4) {   // text LN + GEMM first, serial; text head norm beside the whole image half
         st = txt(s, 1);
-        if (st == MC_OK) st = run_two(e, s, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 2); });
+        if (st == MC_OK) st = run_two(e, s, 1, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 2); });
       } else if (mode == 5) {   // image LN + GEMM beside the whole text half; image head norm afterwards, serial
-        st = run_two(e, s, [&](hipStream_t q) { return img(q, 1); }, [&](hipStream_t q) { return txt(q, 3); });
+        st = run_two(e, s, 1, [&](hipStream_t q) { return img(q, 1); }, [&](hipStream_t q) { return txt(q, 3); });
         if (st == MC_OK) st = img(s, 2);
       } else {                  // 6: LN + GEMM of both halves serial; the two head norm kernels beside each other
         st = img(s, 1);
         if (st == MC_OK) st = txt(s, 1);
-        if (st == MC_OK) st = run_two(e, s, [&](hipStream_t q) { return img(q, 2); }, [&](hipStream_t q) { return txt(q, 2); });
+        if (st == MC_OK) st = run_two(e, s, 1, [&](hipStream_t q) { return img(q, 2); }, [&](hipStream_t q) { return txt(q, 2); });
       }
-      g_mmdit_two_streams = mode;
       MC_TRY(st);
     }
   } else {
@@ -875,7 +876,7 @@ mc_status mc_mmdit_block_post(mc_mmdit* e, int blk, mc_stream stream_) {
   const bool last = (blk == nb - 1);
   if (blk < c.n_double) {
     MC_TRY(run_two(
-        e, s,
+        e, s, g_mmdit_two_streams > 2 ? 0 : g_mmdit_two_streams,
         [&](hipStream_t q) {
           return stream_post_attn(e, e->dimg[blk], emod + e->mod_double(blk, 0), e->img0, Li, q,
                                   last ? e->residual_joint(e->dst) : nullptr);

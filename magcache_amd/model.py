@@ -15,6 +15,7 @@ engine.  The skip decision is pure host arithmetic on those attributes, as in th
 (:277-292): no device sync on the launch path.
 """
 import json
+import os
 
 import numpy as np
 import torch
@@ -55,18 +56,35 @@ def select_table(ckpt_dir, task="t2v"):
     raise ValueError(f"no mag_ratios table for ckpt_dir={ckpt_dir!r}; run --magcache_calibration first")
 
 
+def _version_of(t):
+    """autograd's in-place counter, or None where it cannot be read (inference tensors raise)"""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def _tensor_key(t):
     """Identity of a conditioning tensor WITHOUT reading it (a content compare is a device-to-host sync on every
     forward): the tensor object is kept alive, so its storage cannot be recycled for different data, and an in-place
-    write bumps `_version`.  A caller that rebuilds the tensor every step only pays the re-upload."""
-    return (t, t._version)
+    write bumps `_version`.  A caller that rebuilds the tensor every step only pays the re-upload.
+    Limits: writes that bypass the version counter (`.data.copy_()`, `set_()`, a numpy view of a
+    `from_numpy` tensor) are not seen -- conditioning tensors must not be mutated through such paths, or
+    MAGCACHE_COMPARE_CONDITIONING=1 restores the content compare.  Tensors created under `torch.inference_mode()` have
+    no readable counter: they are re-uploaded on every call (correct, just not cached)."""
+    return (t, _version_of(t))
 
 
 def _same_tensor(key, t):
     k, ver = key
-    return k is t and ver == t._version or (k.data_ptr() == t.data_ptr() and k.shape == t.shape and
-                                            k.dtype == t.dtype and k.device == t.device and
-                                            ver == k._version == t._version)
+    now = _version_of(t)
+    if ver is None or now is None:          # no counter to trust: treat as changed
+        return False
+    same = k is t and ver == now or (k.data_ptr() == t.data_ptr() and k.shape == t.shape and k.dtype == t.dtype and
+                                     k.device == t.device and ver == _version_of(k) == now)
+    if same and os.environ.get("MAGCACHE_COMPARE_CONDITIONING") == "1" and k is not t:
+        same = bool(torch.equal(k, t))
+    return same
 
 
 class WanModelHIP:
@@ -153,9 +171,23 @@ class WanModelHIP:
         if torch.is_tensor(t) and t.numel() > 1:
             # Wan2.2: t [B, seq_len] = per-token timesteps (MagCache4Wan2.2/magcache_generate.py:259-270; TI2V passes
             # t * mask).  The engine takes them as a device vector and selects between two modulation sets per token.
+            # Limits, checked here because the engine would silently modulate with min / max otherwise: one
+            # sample, at least seq_len entries, AT MOST TWO distinct values (what TI2V uses: 0 on the conditioning
+            # frame, the step's t elsewhere).  The value check reads the tensor (one small device sync) and runs only
+            # when the tensor object or its version changes.
             assert t.shape[0] == 1 or t.dim() == 1, "one sample per call"
-            self.engine.set_token_timesteps(t.reshape(-1)[:self.engine.seq_len])
-            t = t.reshape(-1)[-1:]
+            tv = t.reshape(-1)
+            assert tv.numel() >= self.engine.seq_len, f"t has {tv.numel()} entries, the sequence {self.engine.seq_len}"
+            tv = tv[:self.engine.seq_len]
+            k = getattr(self, "_tok_t_key", None)
+            if k is None or not _same_tensor(k, t):
+                n = int(torch.unique(tv).numel())
+                if n > 2:
+                    raise ValueError(f"per-token timesteps with {n} distinct values: the engine supports at most two "
+                                     "per forward (Wan2.2 TI2V: conditioning frame + the step's t)")
+                self._tok_t_key = _tensor_key(t)
+            self.engine.set_token_timesteps(tv)
+            t = tv[-1:]
         elif hasattr(self.engine, "set_token_timesteps"):
             self.engine.set_token_timesteps(None)
         t = t if not torch.is_tensor(t) else t.to(self.device)

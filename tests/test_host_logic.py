@@ -95,7 +95,7 @@ def test_set_option_validates_keys_and_values():
     finally:
         lib.mc_set_option(b"gemm_kernel", 0)
         lib.mc_set_option(b"attn_kernel", 0)
-        lib.mc_set_option(b"mmdit_two_streams", -1)
+        lib.mc_set_option(b"mmdit_two_streams", 0)
 
 
 def test_c_rule_short_eval_schedules_wrap_like_python():

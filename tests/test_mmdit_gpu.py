@@ -286,7 +286,7 @@ def test_mmdit_two_streams_is_bit_identical_and_deterministic():
     kwd = {k: dev(v) for k, v in kw.items()}
     xd, td = dev(x), dev(t)
     try:
-        _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))        # the default (-1, by shape) would already fork here
+        _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))        # the default: one stream
         ref = m(hidden_states=xd, timestep=td, return_dict=False, **kwd)[0].clone()
         assert bool(torch.isfinite(ref).all())
         _lib.check(lib.mc_set_option(b"mmdit_two_streams", 1))
@@ -294,4 +294,4 @@ def test_mmdit_two_streams_is_bit_identical_and_deterministic():
             got = m(hidden_states=xd, timestep=td, return_dict=False, **kwd)[0]
             assert torch.equal(got, ref), f"replay {rep}: two-stream forward differs from the one-stream forward"
     finally:
-        _lib.check(lib.mc_set_option(b"mmdit_two_streams", -1))
+        _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))
