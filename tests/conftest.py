@@ -11,6 +11,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-depth x full-length parity runs (minutes each); MC_SKIP_SLOW=1 skips them")
 
 
 @pytest.fixture(scope="session")

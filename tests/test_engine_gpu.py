@@ -278,26 +278,40 @@ def test_magcache_loop_vs_reference_golden(golden, hip_model):
     sig, ts = flow_timesteps(steps, meta["shift"])
     assert np.array_equal(ts, g["timesteps"])
     L = hip_model.engine.seq_len
-    modes = []
+    modes, rels = [], []
     orig = hip_model.engine.forward
     hip_model.engine.forward = lambda *a, **k: (modes.append(k["mode"]), orig(*a, **k))[1]
     try:
         for i in range(steps):
             t = torch.tensor([float(ts[i])], device=DEV)
             outs = [hip_model([x], t=t, context=[c], seq_len=L)[0] for c in (ctx, ctxn)]
-            assert rel_l2(outs[0], g["outs"][2 * i]) < 3e-2, i
-            assert rel_l2(outs[1], g["outs"][2 * i + 1]) < 3e-2, i
+            rels += [rel_l2(outs[0], g["outs"][2 * i]), rel_l2(outs[1], g["outs"][2 * i + 1])]
+            assert max(rels[-2:]) < 3e-2, (i, rels[-2:])
             cfg_euler_(x, outs[0].contiguous(), outs[1].contiguous(), meta["guide"], float(sig[i + 1] - sig[i]))
     finally:
         hip_model.engine.forward = orig
     skipped = [int(m == MC_MODE_SKIP) for m in modes]
     assert skipped == g["skipped"].tolist()
     final = x.cpu().numpy()
-    assert MR.psnr(final, g["final_latent"], data_range=float(np.abs(g["final_latent"]).max())) > 35.0
+    ps = MR.psnr(final, g["final_latent"], data_range=float(np.abs(g["final_latent"]).max()))
+    _probe("magcache_loop_vs_golden", dict(max_rel_l2_per_call=max(rels), final_psnr_db=ps))
+    assert ps > 35.0
     assert hip_model.cnt == 0
     # residual_cache entries are live views of the engine's HBM slots
     r = hip_model.residual_cache[0]
     assert r.dtype == torch.float32 and tuple(r.shape) == (L, meta["cfg"]["dim"]) and bool(torch.isfinite(r).all())
+
+
+def _probe(key, value):
+    """measured margins of the tolerance bars, for the record (gpurun_out/tolerance_probe.json)"""
+    try:
+        path = os.path.join(ROOT, "gpurun_out", "tolerance_probe.json")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = value
+        json.dump(data, open(path, "w"), indent=1)
+    except OSError:
+        pass
 
 
 def test_skip_is_exactly_cached_residual_add(golden, hip_model):
@@ -327,6 +341,8 @@ def test_calibration_vs_reference_golden(golden, hip_model, golden_dir, tmp_path
            sampling_steps=steps, shift=meta["shift"], guide_scale=meta["guide"])
     assert len(hip_model.norm_ratio) == 2 * steps - 2
     # tolerance: the statistics are means over 360 tokens of bf16-noisy residuals
+    _probe("calibration_vs_golden", {k: float(np.abs(np.array(getattr(hip_model, k)) - np.array(want[k])).max())
+                                     for k in ("norm_ratio", "norm_std", "cos_dis")})
     np.testing.assert_allclose(hip_model.norm_ratio, want["norm_ratio"], atol=1e-2)
     np.testing.assert_allclose(hip_model.norm_std, want["norm_std"], atol=1e-2)
     np.testing.assert_allclose(hip_model.cos_dis, want["cos_dis"], atol=1e-2)

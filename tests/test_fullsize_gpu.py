@@ -139,10 +139,60 @@ def test_wan13_thirty_layers_full_length_error_growth(q_scale):
     assert e[-1] < 30 * max(e[0], 2e-4), e
 
 
+def test_wan13_calibration_statistics_full_length_vs_fp32():
+    """The three MagCache calibration statistics (MagCache4Wan2.1/magcache_generate.py:167-169) of two consecutive CALIB
+    forwards at L = 32 760 against the same statistics of the fp32 checker's residuals.  Averages over 32 760 tokens: the
+    engine's bf16 operand rounding (4e-3 per residual) averages out, so the bar is the table's own resolution -- the
+    shipped tables are round(., 5) and the skip rule compares accumulated |1 - ratio| with 0.12: atol 2e-4."""
+    from magcache_amd.engine import MC_MODE_CALIB
+    from oracle.magcache_ref import calibration_stats as calibration_statistics
+    cfg = dict(WAN_T2V_1_3B, num_layers=10)
+    grid = (21, 60, 104)
+    sd = dict(synthetic_weights(cfg, seed=0, device=DEV))
+    g = torch.Generator(device=DEV).manual_seed(42)
+    lat = torch.randn(16, *grid, generator=g, device=DEV)
+    lat2 = lat + 0.25 * torch.randn(16, *grid, generator=g, device=DEV)          # the next step's latent
+    ctx = torch.randn(512, cfg["text_dim"], generator=g, device=DEV)
+    oracle = FC.build_wan_oracle(cfg, sd, DEV)
+    eng = Engine(cfg, grid, device=DEV, n_branches=2, calibration=True)
+    eng.load_weights(sd)
+    del sd
+    L, d = eng.seq_len, cfg["dim"]
+    eng.forward(lat, 700.0, ctx, branch=0, mode=MC_MODE_CALIB)
+    eng.forward(lat2, 650.0, ctx, branch=0, mode=MC_MODE_CALIB)
+    got = eng.calib_stats(0)
+    res = []
+    with FC.wan_on_gpu():
+        for x_in, t in ((lat, 700.0), (lat2, 650.0)):
+            it = FC.wan_layers(oracle, x_in, torch.tensor([t], device=DEV), ctx, L, "fp32")
+            _, x0 = next(it)
+            x0 = x0.clone()
+            for _ in range(cfg["num_layers"]):
+                _, _, x = next(it)
+            res.append((x[0] - x0[0]).float())
+            del it
+    want = calibration_statistics(res[1], res[0])
+    report("wan1.3B_10layers_L32760_calibration", dict(engine=list(got), fp32=list(want)))
+    for a, b, name in zip(got, want, ("norm_ratio", "norm_std", "cos_dis")):
+        assert abs(a - b) <= 2e-4, (name, a, b)
+    del oracle, eng
+    free()
+
+
 def test_wan14_one_block_720p_length():
     """(iii) one block at 14B widths, L = 75 600"""
     cfg = dict(WAN_T2V_14B, num_layers=1)
     res = run_wan_layers(cfg, (21, 90, 160), seed=5, q_scale=4.0, ctx_valid=512, tag="wan14B_1block_L75600_qx4")
+    check(res)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("MC_SKIP_SLOW") == "1", reason="MC_SKIP_SLOW=1")
+def test_wan14_forty_layers_720p_full_length_error_growth():
+    """BASELINE.json config 3's model at full depth AND full length on one GPU: Wan2.1-T2V-14B, 40 layers, 720p 81 frames
+    = 75 600 tokens (reference call path MagCache4Wan2.1/magcache_generate.py:297-305), per-layer error growth against
+    the fp32 checker; same bars as the 1.3B case."""
+    res = run_wan_layers(WAN_T2V_14B, (21, 90, 160), seed=5, q_scale=4.0, ctx_valid=512, tag="wan14B_40layers_L75600_qx4")
     check(res)
 
 
@@ -204,6 +254,14 @@ def test_hunyuan_full_depth_reduced_length():
     """(iv b) all 20 double + 40 single blocks of HunyuanVideo (13 B parameters) on a 9 x 32 x 48 latent (3 456 image + 256
     text tokens): the error growth over 60 blocks that the one-block case at full length cannot show."""
     _hunyuan_case(dict(HR.HUNYUAN_VIDEO), (9, 32, 48), 256, 77, seed=13, key="hunyuan_full_depth_L3456", q_mul=3.0)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("MC_SKIP_SLOW") == "1", reason="MC_SKIP_SLOW=1")
+def test_hunyuan_full_depth_720p_129f():
+    """BASELINE.json config 2 at full depth AND full length: HunyuanVideo 720p 129 frames, 118 800 image + 256 text
+    tokens, all 20 double + 40 single blocks (reference forward MagCache4HunyuanVideo/magcache_sample_video.py:105-140)."""
+    _hunyuan_case(dict(HR.HUNYUAN_VIDEO), (33, 90, 160), 256, 143, seed=17, key="hunyuan_full_depth_720p129f", q_mul=3.0)
 
 
 def test_flux_dev_full_depth_512():
