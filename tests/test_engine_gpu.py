@@ -269,7 +269,7 @@ def test_host_scalar_t_equals_device_t(golden, hip_model):
 def test_magcache_loop_vs_reference_golden(golden, hip_model):
     """The sampler loop with MagCache on, against the tensors the reference's magcache_forward
     produced around the oracle model (oracle/gen_golden.py): identical skip schedule, per-call
-    outputs within 3e-2 relative L2, final latent PSNR > 35 dB."""
+    outputs within 1e-2 relative L2, final latent PSNR > 50 dB."""
     g, meta, _ = golden
     steps = meta["steps"]
     M.init_magcache(hip_model, steps, meta["thresh"], meta["K"], meta["R"], mag_ratios=TABLES[meta["table"]])
@@ -286,7 +286,9 @@ def test_magcache_loop_vs_reference_golden(golden, hip_model):
             t = torch.tensor([float(ts[i])], device=DEV)
             outs = [hip_model([x], t=t, context=[c], seq_len=L)[0] for c in (ctx, ctxn)]
             rels += [rel_l2(outs[0], g["outs"][2 * i]), rel_l2(outs[1], g["outs"][2 * i + 1])]
-            assert max(rels[-2:]) < 3e-2, (i, rels[-2:])
+            # measured 4.0e-3 (profiles/r03/tolerance_probe.json): the golden is the reference's own bf16-autocast run, the
+            # engine differs from it by bf16 rounding of operands in a different order; bar = 2.5 x measured
+            assert max(rels[-2:]) < 1e-2, (i, rels[-2:])
             cfg_euler_(x, outs[0].contiguous(), outs[1].contiguous(), meta["guide"], float(sig[i + 1] - sig[i]))
     finally:
         hip_model.engine.forward = orig
@@ -295,7 +297,7 @@ def test_magcache_loop_vs_reference_golden(golden, hip_model):
     final = x.cpu().numpy()
     ps = MR.psnr(final, g["final_latent"], data_range=float(np.abs(g["final_latent"]).max()))
     _probe("magcache_loop_vs_golden", dict(max_rel_l2_per_call=max(rels), final_psnr_db=ps))
-    assert ps > 35.0
+    assert ps > 50.0          # measured 62.7 dB
     assert hip_model.cnt == 0
     # residual_cache entries are live views of the engine's HBM slots
     r = hip_model.residual_cache[0]

@@ -38,19 +38,24 @@ TILE = 16384                 # one 64-key tile image: 64 rows x 256 B
 RTHR = 4.0
 
 DEFAULT_CFG = {
-    "mfma": 16,              # 32: 32x32x16, 16: 16x16x32 (the default: less power per FLOP, profiles/r03)
+    "mfma": 32,              # 32: 32x32x16 (default: fewest cycles, what counts between the engine's other kernels),
+                             # 16: 16x16x32 (less power per FLOP: equal in a sustained back-to-back run, profiles/r03)
     "nst": 4,                # LDS ring depth (K and V)
     "ahead": 2,              # iteration t issues K(t+2+ahead), V(t+ahead)
     "cap1": 5.4, "cap2": 5.6,        # issue-cost budget per 32nd of a phase (= one 32x32x16 MFMA, two 16x16x32)
     "w_exp": 1.67, "w_dma": 6.0, "w_wait": 0.5,
     "dma_at": [1, 4, 7, 10, 14, 17, 20, 23],   # positions (32nds of phase 1) of the 4 K and 4 V pieces
     "vlook": 4,              # V^T fragments are read this many fragments ahead
-    "wait_group": 2,         # one s_waitcnt per this many V^T fragments
+    "wait_group": 4,         # one s_waitcnt per this many V^T fragments (a satisfied wait still costs ~13 cycles)
     "rowmax_from": 13,       # first position of phase 2 that may read S(t+1)
     "kread_from": 2,         # K fragment reads are spread evenly over these positions of phase 2
     "kread_to": 24,
+    "kread_p1": 0,           # this many of the 16 K fragment reads are issued in phase 1 (a fragment's register is free
+                             # once the MFMAs of its d-step have been issued)
+    "exp_rate1": 9.0, "exp_rate2": 9.0,   # v_exp_f32 per position at most (transcendentals take two issue slots)
     "pad_nop": 0,            # diagnostic: an s_nop of this many states after every MFMA (idle cycles, no work)
     "pk_add": 0,             # row sums as v_pk_add_f32 (one instruction per pair)
+    "abl": "",               # TIMING ABLATIONS (wrong results): comma list of exp add cvt max lds dma bar -- drops those
 }
 
 A_O, A_Q, A_K = 0, 128, 192
@@ -141,8 +146,24 @@ class Emitter:
         self.lds_issued = 0       # LDS reads issued so far (program order)
         self.lds_done = 0         # ... known complete after the last emitted wait
         self.written_at = {}      # VGPR -> instruction index of its last v_cvt_pk write (P-word readiness check)
+        self.in_body = False      # ablations apply to the pipelined loop bodies only
+
+    ABL = {"exp": ("v_exp_f32",), "add": ("v_add_f32", "v_pk_add_f32"), "cvt": ("v_cvt_pk_bf16_f32",),
+           "max": ("v_max3_f32",), "lds": ("ds_read_b128", "ds_read_b64_tr_b16"), "dma": ("buffer_load_dwordx4",),
+           "bar": ("s_barrier",)}
 
     def i(self, text):
+        if self.in_body and self.cfg["abl"]:
+            mn = text.split()[0]
+            for key in str(self.cfg["abl"]).split("+"):
+                if mn in self.ABL.get(key, ()):
+                    self.n += 1      # keeps the readiness bookkeeping of the generator unchanged
+                    m = re.match(r"v_cvt_pk_bf16_f32 v(\d+),", text)
+                    if m:
+                        self.written_at[int(m.group(1))] = self.n
+                    return
+            if "lds" in str(self.cfg["abl"]).split("+") and mn == "s_waitcnt" and "lgkmcnt" in text:
+                return
         self.lines.append("  " + text)
         self.n += 1
         m = re.match(r"v_cvt_pk_bf16_f32 v(\d+),", text)
@@ -329,7 +350,7 @@ class Credit:
     """issue-cost budget of the MFMA gaps: every gap earns `cap`, fillers spend their weight; a debt carries over"""
 
     def __init__(self, cap):
-        self.cap, self.c = cap, 0.0
+        self.cap, self.c = cap, cap
 
     def gap(self):
         self.c = min(self.c + self.cap, 2.0 * self.cap)
@@ -357,6 +378,11 @@ def emit_phase1(E, B):
     first = M.NM - vlook * M.NQB         # the first V^T fragments of phase 2, one per NQB MFMAs
     tickets = {}
     cr = Credit(cfg["cap1"] / sc)
+    ecr = Credit(cfg["exp_rate1"] / sc)
+    kreads = [(kb_, ds_) for ds_ in range(M.NDS) for kb_ in range(M.NKB)]
+    per_step = M.NKB * M.NQB
+    k_p1 = 0
+    E.kt = []
     g = 0
     for ds in range(M.NDS):
         for kb in range(M.NKB):
@@ -365,6 +391,7 @@ def emit_phase1(E, B):
                 if cfg["pad_nop"]:
                     E.i(f"s_nop {cfg['pad_nop'] - 1}")
                 cr.gap()
+                ecr.gap()
                 if g in m0_at:
                     op = m0_at[g]
                     E.i(f"s_mov_b32 m0, {s((S_DK if op == 'K' else S_DV) + (B.k_dma_slot if op == 'K' else B.v_dma_slot))}")
@@ -383,9 +410,20 @@ def emit_phase1(E, B):
                     tickets[f] = vfrag_reads(E, f, B.v_read_slot * TILE)
                     cr.spend(2)
                 while fin and cr.can(E.weight(fin[0])):
+                    if fin[0].startswith("v_exp_f32"):
+                        if not ecr.can(1):
+                            break
+                        ecr.spend(1)
                     cr.spend(E.weight(fin[0]))
                     E.i(fin.pop(0))
+                # K(t+2) fragments whose registers are free (their d-step of this phase has been issued)
+                if k_p1 < cfg["kread_p1"] and kreads and g >= per_step * (kreads[0][1] + 1) + 1 and cr.can(1):
+                    kb_, ds_ = kreads.pop(0)
+                    E.kt.append(kfrag_read(E, kb_, ds_, B.k_read_slot))
+                    cr.spend(1)
+                    k_p1 += 1
                 g += 1
+    E.kreads_left = kreads
     return tickets, fin
 
 
@@ -395,19 +433,22 @@ def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=Non
     cur, nxt = par, 1 - par
     sc = M.NM // 32
     rmx = [] if last else rowmax_all(M, nxt)
-    kreads = [] if last else [(kb, ds) for ds in range(M.NDS) for kb in range(M.NKB)]
-    kt = []
+    kreads = [] if last else list(E.kreads_left)
+    kt = [] if last else list(E.kt)
     k0, k1 = cfg["kread_from"] * sc, cfg["kread_to"] * sc
-    kdue = [k0 + (k1 - k0) * i // 16 for i in range(16)]      # gap in which the i-th K fragment read is issued
+    nk0 = len(kt)
+    kdue = [0] * nk0 + [k0 + (k1 - k0) * i // max(1, 16 - nk0) for i in range(16 - nk0)]   # gap of the i-th K fragment read
     vlook, wg = cfg["vlook"], cfg["wait_group"]
     nfr = M.NKS * M.NDB
     cr = Credit(cfg["cap2"] / sc)
+    ecr = Credit(cfg["exp_rate2"] / sc)
     g = 0
     for ks in range(M.NKS):
         for db in range(M.NDB):
             f = ks * M.NDB + db
             for qb in range(M.NQB):
                 cr.gap()
+                ecr.gap()
                 if qb == 0:
                     # wait for this fragment (and, grouped, the next wg-1 whose reads are already issued)
                     want = max(tickets[x] for x in range(f, min(nfr, f - f % wg + wg)) if x in tickets)
@@ -420,6 +461,10 @@ def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=Non
                     tickets[f + vlook] = vfrag_reads(E, f + vlook, v_off, v_addr)
                     cr.spend(2)
                 while fin and cr.can(E.weight(fin[0])):
+                    if fin[0].startswith("v_exp_f32"):
+                        if not ecr.can(1):
+                            break
+                        ecr.spend(1)
                     cr.spend(E.weight(fin[0]))
                     E.i(fin.pop(0))
                 if kreads and g >= kdue[len(kt)]:
@@ -501,11 +546,13 @@ def emit_body(E, b, ret):
     E.written_at = {}
     E.comment(f"---- iteration body {b}: S_cur = buffer {B.par}, reads K slot {B.k_read_slot} / V slot {B.v_read_slot}, "
               f"refills K slot {B.k_dma_slot} / V slot {B.v_dma_slot}")
+    E.in_body = True
     E.i(f"s_waitcnt vmcnt({8 * (cfg['ahead'] - 1)})")
     E.i("s_barrier")
     emit_decide(E, B.par, ret)
     tickets, fin = emit_phase1(E, B)
     emit_phase2(E, B.par, tickets, fin, B.v_read_slot * TILE, k_slot=B.k_read_slot)
+    E.in_body = False
 
 
 def emit_mask_tail(E, par):
@@ -860,6 +907,9 @@ def parse_overrides(items):
     cfg = {}
     for it in items or []:
         k, val = it.split("=", 1)
+        if k == "abl":
+            cfg[k] = val
+            continue
         cfg[k] = [int(x) for x in val.split(",")] if k == "dma_at" else (float(val) if "." in val else int(val))
     return cfg
 

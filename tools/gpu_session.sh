@@ -79,7 +79,7 @@ for step in "$@"; do
       if [ -n "${a[1]:-}" ]; then
         timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -p no:cacheprovider -k "${a[1]}" 2>&1 | tail -40 > "$out/pytest_k.log"; echo "pytest exit: ${PIPESTATUS[0]}" >> "$out/pytest_k.log"; cat "$out/pytest_k.log"
       else
-        timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider 2>&1 | tail -60 > "$out/pytest_gpu.log"; echo "pytest exit: ${PIPESTATUS[0]}" >> "$out/pytest_gpu.log"; tail -30 "$out/pytest_gpu.log"
+        timeout 2400 python -m pytest tests -m gpu -q --timeout 1500 --durations=25 -p no:cacheprovider 2>&1 | tail -90 > "$out/pytest_gpu.log"; echo "pytest exit: ${PIPESTATUS[0]}" >> "$out/pytest_gpu.log"; tail -30 "$out/pytest_gpu.log"
       fi
       ;;
     pytest_slow)
