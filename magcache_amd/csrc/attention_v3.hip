@@ -520,9 +520,9 @@ hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// mc_set_option("attn_kernel", v): 0 = default dispatch; 3 = this kernel everywhere; 5 = attention_v5.hip (4 waves x 64 rows,
-// hand-scheduled) wherever it applies -- one key shard, no log-sum-exp merge, i.e. the single-GPU call -- and this kernel
-// for the sequence-parallel forms.  The A/B library (tools/build_ab_lib.py, -DMC_AB_KERNELS) also links
+// mc_set_option("attn_kernel", v): 0 = default dispatch = 5; 3 = this kernel everywhere; 5 = attention_v5.hip (4 waves x 64
+// rows, hand-scheduled) wherever it applies -- every form of the call whose K / V span fits 32-bit byte offsets -- and
+// this kernel otherwise.  The A/B library (tools/build_ab_lib.py, -DMC_AB_KERNELS) also links
 // tools/kernels_ab/attention{,_v2,_v4}.hip as 1 / 2 / 4.
 int g_attn_kernel = 0;
 constexpr int kDefaultAttnKernel = 5;   // attention_v5 where it applies (profiles/r03: +13 % over v3), v3 otherwise

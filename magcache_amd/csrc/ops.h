@@ -88,7 +88,7 @@ struct AttnParams {
 // K/V rows in [shard_valid, shard_rows) are read (and masked) but must hold finite values.
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);     // picks a kernel
 hipError_t launch_attention_v5(const AttnParams& p, hipStream_t stream);  // 4 waves x 64 rows, one wave per SIMD, hand-scheduled (round 3)
-bool attention_v5_supports(const AttnParams& p);                          // one shard, no log-sum-exp merge
+bool attention_v5_supports(const AttnParams& p);                          // K / V span within 32-bit byte offsets
 hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows, pipelined, 32x32x16 MFMA (round 1)
 hipError_t launch_attention_v4(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab: the v3 pipeline on 16x16x32 (A/B library only)
 hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)

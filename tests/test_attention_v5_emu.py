@@ -20,8 +20,8 @@ IN_BASE = 64   # SGPRs the "compiler" hands the inputs over in
 
 
 def _bind_inputs(text):
-    # %0 %2 %4 %6 are 64-bit (register pairs), the others 32-bit
-    pairs = {0, 2, 4, 6}
+    # %0 %2 %4 %6 %19 %20 are 64-bit (register pairs), the others 32-bit
+    pairs = {0, 2, 4, 6, 19, 20}
     for k in range(gen.N_INPUTS - 1, -1, -1):
         r = IN_BASE + 2 * k
         text = text.replace(f"%{k}", f"s[{r}:{r + 1}]" if k in pairs else f"s{r}")
@@ -32,37 +32,69 @@ def bf16_round(x):
     return emu.bf16_to_f32(emu.bf16_rne(x.astype(np.float32)))
 
 
-def run_block(n_keys, n_heads=2, head=1, q_amp=1.0, seed=0, dma_late=False, load_late=False, spike=False, cfg=None):
-    rng = np.random.default_rng(seed)
-    n_tiles = (n_keys + 63) // 64
-    rows_k = n_tiles * 64
-    ldq = ldk = ldv = 3 * n_heads * 128           # the engine's fused q|k|v row layout
-    ldo = n_heads * 128
-    qkv = np.zeros((max(256, rows_k), ldq), dtype=np.float32)
-    qkv[:, :] = bf16_round(rng.standard_normal(qkv.shape).astype(np.float32))
-    qkv[:, : n_heads * 128] *= q_amp
-    qkv[:, : n_heads * 128] = bf16_round(qkv[:, : n_heads * 128])
-    qkv[n_keys:rows_k, n_heads * 128:] = 0.0      # padded K/V rows hold finite values (zeros)
-    if spike:                                      # one key far above the others late in the sequence: forces a rescale
-        qkv[n_keys - 70, n_heads * 128 + head * 128:n_heads * 128 + (head + 1) * 128] = \
-            bf16_round(6.0 * qkv[5, head * 128:(head + 1) * 128])
-    qkv_bits = emu.bf16_rne(qkv).astype(np.uint16)
-    out_bits = np.zeros((256, ldo), dtype=np.uint16)
-    QB, OB = 0x1000_0000, 0x4000_0000
-    scale = 1.0 / np.sqrt(128.0)
+class Problem:
+    """q|k|v rows in the engine's fused layout; the keys are n_shards shards of shard_rows rows, valid rows first"""
+
+    def __init__(self, valid, n_shards=1, n_heads=2, head=1, q_amp=1.0, seed=0, spike=False, pad_value=0.0):
+        rng = np.random.default_rng(seed)
+        self.valid, self.n_shards, self.n_heads, self.head = valid, n_shards, n_heads, head
+        self.tps = (valid + 63) // 64
+        self.shard_rows = self.tps * 64
+        rows = max(256, n_shards * self.shard_rows)
+        self.ld = 3 * n_heads * 128
+        qkv = bf16_round(rng.standard_normal((rows, self.ld)).astype(np.float32))
+        qkv[:, : n_heads * 128] = bf16_round(qkv[:, : n_heads * 128] * q_amp)
+        for sh in range(n_shards):                      # padded K/V rows hold finite values
+            qkv[sh * self.shard_rows + valid:(sh + 1) * self.shard_rows, n_heads * 128:] = pad_value
+        if spike:                                       # one key far above the others late in the sequence: forces a rescale
+            r = (n_shards - 1) * self.shard_rows + max(0, valid - 70)
+            qkv[r, n_heads * 128 + head * 128:n_heads * 128 + (head + 1) * 128] = bf16_round(6.0 * qkv[5, head * 128:(head + 1) * 128])
+        self.qkv = qkv
+        self.qkv_bits = emu.bf16_rne(qkv).astype(np.uint16)
+
+    def reference(self, shards):
+        h, nh = self.head, self.n_heads
+        q = self.qkv[:256, h * 128:(h + 1) * 128].astype(np.float64)
+        idx = np.concatenate([np.arange(sh * self.shard_rows, sh * self.shard_rows + self.valid) for sh in shards])
+        k = self.qkv[idx, nh * 128 + h * 128:nh * 128 + (h + 1) * 128].astype(np.float64)
+        vv = self.qkv[idx, 2 * nh * 128 + h * 128:2 * nh * 128 + (h + 1) * 128].astype(np.float64)
+        sc = (q @ k.T) / np.sqrt(128.0)
+        mx = sc.max(axis=1, keepdims=True)
+        p = np.exp(sc - mx)
+        lse2 = (mx[:, 0] + np.log(p.sum(axis=1))) * 1.4426950408889634      # log2-sum-exp of the scaled scores
+        return (p / p.sum(axis=1, keepdims=True)) @ vv, lse2
+
+
+def launch(pb, first_shard=0, n_visit=None, skip=-1, lse_out=False, lse_in=None, o_init=None, dma_late=False,
+           load_late=False, cfg=None, k_base_shard=0):
+    """one workgroup of the generated kernel on the emulator.  k_base_shard: the K / V pointers start at this shard
+    (a one-shard launch over a shard in the middle of the buffer)."""
+    n_visit = pb.n_shards - (1 if skip >= 0 else 0) if n_visit is None else n_visit
+    nh, head, ld = pb.n_heads, pb.head, pb.ld
+    ldo = nh * 128
+    out_bits = np.zeros((256, ldo), dtype=np.uint16) if o_init is None else o_init.copy()
+    lse_o = np.zeros(256, dtype=np.float32)
+    lse_i = np.zeros(256, dtype=np.float32) if lse_in is None else lse_in.astype(np.float32)
+    QB, OB, LO, LI = 0x1000_0000, 0x4000_0000, 0x5000_0000, 0x6000_0000
     text = _bind_inputs(gen.generate(cfg))
     m = emu.Machine(text + "  s_endpgm\n", n_waves=4, lds_bytes=gen.lds_bytes(cfg), dma_late=dma_late, load_late=load_late)
-    m.add_buffer(QB, qkv_bits)
+    m.add_buffer(QB, pb.qkv_bits)
     m.add_buffer(OB, out_bits)
+    m.add_buffer(LO, lse_o)
+    m.add_buffer(LI, lse_i)
+    shard_bytes = pb.shard_rows * ld * 2
     q_ptr = QB + head * 256
-    k_ptr = QB + (n_heads * 128 + head * 128) * 2
-    v_ptr = QB + (2 * n_heads * 128 + head * 128) * 2
+    k_ptr = QB + (nh * 128 + head * 128) * 2 + k_base_shard * shard_bytes
+    v_ptr = QB + (2 * nh * 128 + head * 128) * 2 + k_base_shard * shard_bytes
     o_ptr = OB + head * 256
-    tail = n_keys - (n_tiles - 1) * 64
-    c = np.float32(scale * 1.4426950408889634)
-    nrec = ((rows_k - 1) * ldk + 128) * 2      # bytes reachable from the head's first K / V element
-    vals = [q_ptr, ldq * 2, k_ptr, ldk * 2, v_ptr, ldv * 2, o_ptr, ldo * 2, n_tiles, tail, int(c.view(np.uint32)), None, 0,
-            nrec, nrec]
+    tail = pb.valid - (pb.tps - 1) * 64
+    c = np.float32(1.4426950408889634 / np.sqrt(128.0))
+    rows_reach = (pb.n_shards - k_base_shard) * pb.shard_rows
+    nrec = ((rows_reach - 1) * ld + 128) * 2          # bytes reachable from the head's first K / V element
+    vals = [q_ptr, ld * 2, k_ptr, ld * 2, v_ptr, ld * 2, o_ptr, ldo * 2, n_visit * pb.tps, tail, int(c.view(np.uint32)),
+            None, 0, nrec, nrec, shard_bytes, shard_bytes, pb.tps, skip & 0xFFFFFFFF, LO if lse_out else 0,
+            LI if lse_in is not None else 0, first_shard]
+    assert len(vals) == gen.N_INPUTS
     for w in m.waves:
         for k, val in enumerate(vals):
             r = IN_BASE + 2 * k
@@ -71,13 +103,14 @@ def run_block(n_keys, n_heads=2, head=1, q_amp=1.0, seed=0, dma_late=False, load
             w.s[r] = np.uint32(val & 0xFFFFFFFF)
             w.s[r + 1] = np.uint32((val >> 32) & 0xFFFFFFFF)
     m.run()
+    return out_bits, lse_o, m
+
+
+def run_block(n_keys, n_heads=2, head=1, q_amp=1.0, seed=0, dma_late=False, load_late=False, spike=False, cfg=None):
+    pb = Problem(n_keys, 1, n_heads, head, q_amp, seed, spike)
+    out_bits, _, m = launch(pb, dma_late=dma_late, load_late=load_late, cfg=cfg)
     got = emu.bf16_to_f32(out_bits[:, head * 128:(head + 1) * 128].astype(np.uint32))
-    q = qkv[:256, head * 128:(head + 1) * 128].astype(np.float64)
-    k = qkv[:n_keys, n_heads * 128 + head * 128:n_heads * 128 + (head + 1) * 128].astype(np.float64)
-    vv = qkv[:n_keys, 2 * n_heads * 128 + head * 128:2 * n_heads * 128 + (head + 1) * 128].astype(np.float64)
-    sc = (q @ k.T) * scale
-    p = np.exp(sc - sc.max(axis=1, keepdims=True))
-    want = (p / p.sum(axis=1, keepdims=True)) @ vv
+    want, _ = pb.reference([0])
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     return rel, got, want, m
 
@@ -104,6 +137,38 @@ def test_v5_deferred_rescale_branch_is_exercised_and_right(mfma):
     rel, got, want, _ = run_block(448, q_amp=4.0, seed=5, spike=True, dma_late=True, load_late=True, cfg={"mfma": mfma})
     assert np.isfinite(got).all()
     assert rel < 8e-3, rel
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("valid,n_shards,skip", [(100, 3, -1), (128, 2, -1), (37, 4, -1), (130, 3, 1), (64, 4, 0), (70, 3, 2)])
+def test_v5_key_shards_with_padding_and_a_skipped_shard(valid, n_shards, skip, mfma):
+    """sequence-parallel key layout: n_shards x shard_rows rows, `valid` keys at the start of every shard (the padding rows
+    hold LARGE finite garbage: it must be masked, not merely down-weighted), optionally one shard left out"""
+    pb = Problem(valid, n_shards, seed=valid + n_shards, pad_value=40.0)
+    first = 1 if skip == 0 else 0
+    out_bits, _, _ = launch(pb, first_shard=first, skip=skip, dma_late=True, load_late=True, cfg={"mfma": mfma})
+    got = emu.bf16_to_f32(out_bits[:, pb.head * 128:(pb.head + 1) * 128].astype(np.uint32))
+    want, _ = pb.reference([sh for sh in range(n_shards) if sh != skip])
+    assert np.isfinite(got).all()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 5e-3
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+def test_v5_two_phase_local_then_remote_merge(mfma):
+    """the overlapped sequence-parallel schedule: launch 1 attends the local shard (one-shard call on a shard in the
+    middle of the buffer) and writes O + log2-sum-exp; launch 2 attends the other shards and merges by the log-sum-exp"""
+    pb = Problem(150, 3, seed=21, pad_value=25.0)
+    loc = 1
+    o1, lse1, _ = launch(pb, n_visit=1, lse_out=True, k_base_shard=loc, cfg={"mfma": mfma})
+    want1, lse_want1 = pb.reference([loc])
+    got1 = emu.bf16_to_f32(o1[:, pb.head * 128:(pb.head + 1) * 128].astype(np.uint32))
+    assert np.linalg.norm(got1 - want1) / np.linalg.norm(want1) < 5e-3
+    assert np.abs(lse1 - lse_want1).max() < 2e-2
+    o2, lse2, _ = launch(pb, skip=loc, lse_in=lse1, lse_out=True, o_init=o1, dma_late=True, load_late=True, cfg={"mfma": mfma})
+    want, lse_want = pb.reference([0, 1, 2])
+    got = emu.bf16_to_f32(o2[:, pb.head * 128:(pb.head + 1) * 128].astype(np.uint32))
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 6e-3     # the partial O passes through bf16 once more
+    assert np.abs(lse2 - lse_want).max() < 2e-2
 
 
 def test_v5_two_deep_ring_variant_is_also_right():

@@ -715,6 +715,34 @@ class Machine:
             w.vm_q.append(None)
         self._haz_write(w, ins, dst, "mem")
 
+    def _gload_n(self, w, ins, o, ndw):
+        self._haz_read(w, ins, o[1], "mem")
+        addr = self._gaddr(w, o[1], o[2], ins)
+        dst = o[0]
+
+        def fin():
+            val = self.gload(addr, 4 * ndw).view(np.uint32).reshape(64, ndw)
+            for i in range(ndw):
+                self.wr(w, dst, val[:, i], i)
+        if self.load_late:
+            for i in range(ndw):
+                self.wr(w, dst, np.full(64, POISON, dtype=np.uint32), i)
+            w.vm_q.append(fin)
+        else:
+            fin()
+            w.vm_q.append(None)
+        self._haz_write(w, ins, dst, "mem")
+
+    def i_global_load_dword(self, w, ins, o): self._gload_n(w, ins, o, 1)
+    def i_global_load_dwordx2(self, w, ins, o): self._gload_n(w, ins, o, 2)
+
+    def i_global_store_dword(self, w, ins, o):
+        self._haz_read(w, ins, o[0], "mem")
+        self._haz_read(w, ins, o[1], "mem")
+        addr = self._gaddr(w, o[0], o[2], ins)
+        self.gstore(addr, self.rd(w, o[1], 0).copy().view(np.uint8).reshape(64, 4))
+        w.vm_q.append(None)
+
     def i_global_store_dwordx2(self, w, ins, o):
         self._haz_read(w, ins, o[0], "mem")
         self._haz_read(w, ins, o[1], "mem")

@@ -68,8 +68,12 @@ S_T = 47                     # temporaries 47..51
 S_FLOOR, S_RET, S_THR, S_VSLOT = 52, 53, 54, 55
 S_DK, S_DV = 56, 60          # [slot] LDS destination of this wave's pieces (up to 4 slots each)
 S_KSRD, S_VSRD = 64, 68      # buffer descriptors
-S_LAST = 79
-N_INPUTS = 15
+S_KSHS, S_VSHS, S_TPS, S_SKIP = 72, 73, 74, 75       # shard strides (bytes), tiles per shard, shard to leave out (-1: none)
+S_KTIN, S_KSH, S_VTIN, S_VSH = 76, 77, 78, 79        # DMA cursors: tile in shard / shard index of the NEXT tile to issue
+S_MASKCNT, S_KWRAP, S_VWRAP, S_FIRST = 80, 81, 82, 83             # iterations until S_cur is a shard's last tile; shard-wrap jumps
+S_LSEO, S_LSEI = 84, 86                              # log-sum-exp out / in row pointers (0: none)
+S_LAST = 91
+N_INPUTS = 22
 
 
 def v(n, cnt=1):
@@ -147,6 +151,9 @@ class Emitter:
         self.lds_done = 0         # ... known complete after the last emitted wait
         self.written_at = {}      # VGPR -> instruction index of its last v_cvt_pk write (P-word readiness check)
         self.in_body = False      # ablations apply to the pipelined loop bodies only
+        self.uid = 0
+        self.masktops = []        # (ret id, S buffer) of the loop-top mask paths
+        self.ool = []             # out-of-line blocks (shard wraps) to emit behind the main code
 
     ABL = {"exp": ("v_exp_f32",), "add": ("v_add_f32", "v_pk_add_f32"), "cvt": ("v_cvt_pk_bf16_f32",),
            "max": ("v_max3_f32",), "lds": ("ds_read_b128", "ds_read_b64_tr_b16"), "dma": ("buffer_load_dwordx4",),
@@ -291,14 +298,51 @@ def dma_piece(M, op, j):
     return f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(cur)} offen offset:{1024 * j} lds"
 
 
+def cursor_advance(E, op):
+    """move the DMA cursor of K / V to the next tile of the key sequence: + one tile, and at the end of a shard a jump to
+    the next shard (out of line, rare), past the shard the call leaves out.  4 SALU instructions on the hot path."""
+    cur, step, tin = (S_KCUR, S_KSTEP, S_KTIN) if op == "K" else (S_VCUR, S_VSTEP, S_VTIN)
+    E.uid += 1
+    lab = f"L_wrap{op}{E.uid}"
+    E.ool.append((lab, op))
+    return [f"s_add_u32 {s(cur)}, {s(cur)}, {s(step)}",
+            f"s_add_u32 {s(tin)}, {s(tin)}, 1",
+            f"s_cmp_eq_u32 {s(tin)}, {s(S_TPS)}",
+            f"s_cbranch_scc1 {lab}",
+            f"{lab}_back:"]
+
+
+def emit_wrap_blocks(E):
+    for lab, op in E.ool:
+        cur, tin, sh, wrap, shs = (S_KCUR, S_KTIN, S_KSH, S_KWRAP, S_KSHS) if op == "K" else \
+                                  (S_VCUR, S_VTIN, S_VSH, S_VWRAP, S_VSHS)
+        E.label(lab)
+        E.i(f"s_add_u32 {s(cur)}, {s(cur)}, {s(wrap)}")          # shard stride - tiles_per_shard * tile step
+        E.i(f"s_mov_b32 {s(tin)}, 0")
+        E.i(f"s_add_u32 {s(sh)}, {s(sh)}, 1")
+        E.i(f"s_cmp_eq_u32 {s(sh)}, {s(S_SKIP)}")
+        E.i(f"s_cbranch_scc0 {lab}_back")
+        E.i(f"s_add_u32 {s(cur)}, {s(cur)}, {s(shs)}")
+        E.i(f"s_add_u32 {s(sh)}, {s(sh)}, 1")
+        E.i(f"s_branch {lab}_back")
+
+
+def emit_seq(E, seq):
+    for t in seq:
+        if t.endswith(":"):
+            E.label(t[:-1])
+        else:
+            E.i(t)
+
+
 def dma_tile_now(E, op, slot):
     """a whole operand tile back to back (prologue), cursor moves on"""
-    dst, cur, step = (S_DK, S_KCUR, S_KSTEP) if op == "K" else (S_DV, S_VCUR, S_VSTEP)
+    dst = S_DK if op == "K" else S_DV
     E.i(f"s_mov_b32 m0, {s(dst + slot)}")
     E.i("s_nop 0")
     for j in range(4):
         E.i(dma_piece(E.M, op, j))
-    E.i(f"s_add_u32 {s(cur)}, {s(cur)}, {s(step)}")
+    emit_seq(E, cursor_advance(E, op))
 
 
 def qk_mfma(M, buf_nxt, ds, qb, kb):
@@ -401,10 +445,8 @@ def emit_phase1(E, B):
                     E.i(t)
                     cr.spend(E.weight(t))
                 if g in adv_at:
-                    op = adv_at[g]
-                    cur_, step = (S_KCUR, S_KSTEP) if op == "K" else (S_VCUR, S_VSTEP)
-                    E.i(f"s_add_u32 {s(cur_)}, {s(cur_)}, {s(step)}")
-                    cr.spend(1)
+                    emit_seq(E, cursor_advance(E, adv_at[g]))
+                    cr.spend(4)
                 if g >= first and (g - first) % M.NQB == 0:
                     f = (g - first) // M.NQB
                     tickets[f] = vfrag_reads(E, f, B.v_read_slot * TILE)
@@ -549,6 +591,11 @@ def emit_body(E, b, ret):
     E.in_body = True
     E.i(f"s_waitcnt vmcnt({8 * (cfg['ahead'] - 1)})")
     E.i("s_barrier")
+    # S_cur is the last tile of a key shard with padding keys (counter runs out): mask them, lane maxima again (rare)
+    E.i(f"s_sub_u32 {s(S_MASKCNT)}, {s(S_MASKCNT)}, 1")
+    E.i(f"s_cbranch_scc1 L_masktop{ret}")
+    E.label(f"L_maskback{ret}")
+    E.masktops.append((ret, B.par))
     emit_decide(E, B.par, ret)
     tickets, fin = emit_phase1(E, B)
     emit_phase2(E, B.par, tickets, fin, B.v_read_slot * TILE, k_slot=B.k_read_slot)
@@ -624,6 +671,13 @@ def emit_prologue(E):
     E.i(f"s_mov_b32 {s(S_LDS)}, %12")
     E.i(f"s_mov_b32 {s(S_KNREC)}, %13")
     E.i(f"s_mov_b32 {s(S_VNREC)}, %14")
+    E.i(f"s_mov_b32 {s(S_KSHS)}, %15")
+    E.i(f"s_mov_b32 {s(S_VSHS)}, %16")
+    E.i(f"s_mov_b32 {s(S_TPS)}, %17")
+    E.i(f"s_mov_b32 {s(S_SKIP)}, %18")
+    E.i(f"s_mov_b64 {s(S_LSEO, 2)}, %19")
+    E.i(f"s_mov_b64 {s(S_LSEI, 2)}, %20")
+    E.i(f"s_mov_b32 {s(S_FIRST)}, %21")               # first shard of the walk (1 if shard 0 is the one left out)
     E.comment("---- buffer descriptors of K and V (raw buffer, stride 0, num_records bytes)")
     for srd, base, nrec in ((S_KSRD, S_K, S_KNREC), (S_VSRD, S_V, S_VNREC)):
         E.i(f"s_mov_b32 {s(srd)}, {s(base)}")
@@ -710,8 +764,21 @@ def emit_prologue(E):
     E.i(f"s_lshl_b32 {s(S_KSTEP)}, {s(S_LDK)}, 6")
     E.i(f"s_lshl_b32 {s(S_VSTEP)}, {s(S_LDV)}, 6")
     E.i(f"s_sub_u32 {s(S_IT)}, {s(S_NT)}, 1")
-    E.i(f"s_mov_b32 {s(S_KCUR)}, 0")
-    E.i(f"s_mov_b32 {s(S_VCUR)}, 0")
+    # cursors start at the first shard of the walk; wrap = shard stride - tiles_per_shard * tile step
+    E.i(f"s_mul_i32 {s(S_KCUR)}, {s(S_FIRST)}, {s(S_KSHS)}")
+    E.i(f"s_mul_i32 {s(S_VCUR)}, {s(S_FIRST)}, {s(S_VSHS)}")
+    E.i(f"s_mov_b32 {s(S_KSH)}, {s(S_FIRST)}")
+    E.i(f"s_mov_b32 {s(S_VSH)}, {s(S_FIRST)}")
+    E.i(f"s_mov_b32 {s(S_KTIN)}, 0")
+    E.i(f"s_mov_b32 {s(S_VTIN)}, 0")
+    E.i(f"s_mul_i32 {s(S_T + 1)}, {s(S_TPS)}, {s(S_KSTEP)}")
+    E.i(f"s_sub_u32 {s(S_KWRAP)}, {s(S_KSHS)}, {s(S_T + 1)}")
+    E.i(f"s_mul_i32 {s(S_T + 1)}, {s(S_TPS)}, {s(S_VSTEP)}")
+    E.i(f"s_sub_u32 {s(S_VWRAP)}, {s(S_VSHS)}, {s(S_T + 1)}")
+    # iterations until S_cur is a shard's last tile (tile t: t = tps - 1 mod tps); never, if those tiles are full
+    E.i(f"s_sub_u32 {s(S_MASKCNT)}, {s(S_TPS)}, 1")
+    E.i(f"s_cmp_ge_u32 {s(S_TAIL)}, 64")
+    E.i(f"s_cselect_b32 {s(S_MASKCNT)}, -1, {s(S_MASKCNT)}")
     E.i(f"s_mov_b32 {s(S_FLOOR)}, 0xff800000")
     E.i(f"s_mov_b32 {s(S_THR)}, {RTHR}")
     E.i(f"v_mov_b32 {v(M.V_NINF)}, 0xff800000")
@@ -774,8 +841,8 @@ def emit_prologue(E):
         dma_tile_now(E, "K", (2 + i) % nst)
         dma_tile_now(E, "V", i % nst)
     E.i("s_nop 7")
-    # a one-tile key sequence with padding keys: mask them before the first reference is taken
-    E.i(f"s_cmp_gt_u32 {s(S_NT)}, 1")
+    # one-tile shards with padding keys: mask tile 0 before the first reference is taken
+    E.i(f"s_cmp_gt_u32 {s(S_TPS)}, 1")
     E.i("s_cbranch_scc1 L_pro_rowmax")
     E.i(f"s_cmp_ge_u32 {s(S_TAIL)}, 64")
     E.i("s_cbranch_scc1 L_pro_rowmax")
@@ -788,17 +855,23 @@ def emit_prologue(E):
 
 
 def emit_epilogue(E):
+    """O / l -> bf16 -> global; optional log-sum-exp out (two-phase attention, first launch) and merge with the result of
+    an earlier launch over other keys (lse_in: O holds that launch's normalised result) -- the epilogue of attention_v3.hip"""
     M = E.M
     big = M.mfma == 32
     E.comment("---- O / l -> bf16 -> global")
     E.i("s_nop 15")
     t0 = M.V_T
     qrows = 64 // M.NQB
+    lrow = [M.V_D + qb for qb in range(M.NQB)]           # byte offset of the lane's row in the lse arrays
+    lse = [M.V_MX + qb for qb in range(M.NQB)]
+    ca = [M.V_M + qb for qb in range(M.NQB)]             # weight of the earlier launch's result (merge)
     E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 6")
     for qb in range(M.NQB):
         E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(M.V_QL)}")
         if qb:
             E.i(f"v_add_u32 {v(t0)}, {qrows * qb}, {v(t0)}")
+        E.i(f"v_lshlrev_b32 {v(lrow[qb])}, 2, {v(t0)}")
         E.i(f"v_mul_lo_u32 {v(M.V_QOFF + qb)}, {v(t0)}, {s(S_LDO)}")
         E.i(f"v_lshl_add_u32 {v(M.V_QOFF + qb)}, {v(M.V_G)}, 3, {v(M.V_QOFF + qb)}")   # 4 d = 8 bytes per lane group
     for qb in range(M.NQB):
@@ -807,22 +880,85 @@ def emit_epilogue(E):
         for t in combine_lanes(M, l, "v_add_f32"):
             E.i(t)
         E.i(f"v_rcp_f32 {v(M.V_ALPHA + qb)}, {v(l)}")
-    E.i("s_nop 0")
+        E.i(f"v_log_f32 {v(t0 + 1)}, {v(l)}")            # scores are in log2 units: lse = m + log2(l)
+        E.i("s_nop 0")
+        E.i(f"v_add_f32 {v(lse[qb])}, {v(M.V_M + qb)}, {v(t0 + 1)}")
+    # ---- merge with an earlier launch?
+    E.i(f"s_or_b32 {s(S_T)}, {s(S_LSEI)}, {s(S_LSEI + 1)}")
+    E.i(f"s_cmp_eq_u32 {s(S_T)}, 0")
+    E.i("s_cbranch_scc1 L_epi_plain")
+    for qb in range(M.NQB):
+        E.i(f"global_load_dword {v(t0 + 2 + qb)}, {v(lrow[qb])}, {s(S_LSEI, 2)}")
+    # the earlier launch's O rows of this lane: 8 bytes per (qb, db, g) -> v0.. (the S buffers are dead)
+    nq = M.NDB * (M.ACC // 4)
     for qb in range(M.NQB):
         for db in range(M.NDB):
             for g in range(M.ACC // 4):
-                r = A_O + (qb * M.NDB + db) * M.ACC + 4 * g
-                x = M.V_T + 4
-                for k in range(4):
-                    E.i(f"v_accvgpr_read_b32 {v(x + k)}, {a(r + k)}")
-                for k in range(4):
-                    E.i(f"v_mul_f32 {v(x + k)}, {v(x + k)}, {v(M.V_ALPHA + qb)}")
-                E.i(f"v_cvt_pk_bf16_f32 {v(x)}, {v(x)}, {v(x + 1)}")
-                E.i(f"v_cvt_pk_bf16_f32 {v(x + 1)}, {v(x + 2)}, {v(x + 3)}")
                 off = db * 64 + g * 16 if big else db * 32
-                E.i(f"global_store_dwordx2 {v(M.V_QOFF + qb)}, {v(x, 2)}, {s(S_O, 2)} offset:{off}")
-                E.i("s_nop 1")
+                q = (qb * nq + db * (M.ACC // 4) + g) * 2
+                E.i(f"global_load_dwordx2 {v(q, 2)}, {v(M.V_QOFF + qb)}, {s(S_O, 2)} offset:{off}")
     E.i("s_waitcnt vmcnt(0)")
+    for qb in range(M.NQB):
+        prev, mm, wa, wb = t0 + 2 + qb, t0 + 6, t0 + 7, t0 + 8
+        E.i(f"v_max_f32 {v(mm)}, {v(lse[qb])}, {v(prev)}")
+        E.i(f"v_sub_f32 {v(wa)}, {v(prev)}, {v(mm)}")
+        E.i(f"v_sub_f32 {v(wb)}, {v(lse[qb])}, {v(mm)}")
+        E.i(f"v_exp_f32 {v(wa)}, {v(wa)}")
+        E.i(f"v_exp_f32 {v(wb)}, {v(wb)}")
+        E.i("s_nop 0")
+        E.i(f"v_add_f32 {v(t0 + 9)}, {v(wa)}, {v(wb)}")
+        E.i(f"v_rcp_f32 {v(t0 + 10)}, {v(t0 + 9)}")
+        E.i(f"v_log_f32 {v(t0 + 11)}, {v(t0 + 9)}")
+        E.i("s_nop 0")
+        E.i(f"v_mul_f32 {v(ca[qb])}, {v(wa)}, {v(t0 + 10)}")
+        E.i(f"v_mul_f32 {v(wb)}, {v(wb)}, {v(t0 + 10)}")
+        E.i(f"v_mul_f32 {v(M.V_ALPHA + qb)}, {v(wb)}, {v(M.V_ALPHA + qb)}")      # cb = wb * rden / l
+        E.i(f"v_add_f32 {v(lse[qb])}, {v(mm)}, {v(t0 + 11)}")
+    for merge in (True, False):
+        if not merge:
+            E.label("L_epi_plain")
+        for qb in range(M.NQB):
+            for db in range(M.NDB):
+                for g in range(M.ACC // 4):
+                    r = A_O + (qb * M.NDB + db) * M.ACC + 4 * g
+                    x = M.V_T + 4
+                    for k in range(4):
+                        E.i(f"v_accvgpr_read_b32 {v(x + k)}, {a(r + k)}")
+                    for k in range(4):
+                        E.i(f"v_mul_f32 {v(x + k)}, {v(x + k)}, {v(M.V_ALPHA + qb)}")
+                    if merge:
+                        q = (qb * nq + db * (M.ACC // 4) + g) * 2
+                        y = M.V_T + 8
+                        E.i(f"v_lshlrev_b32 {v(y)}, 16, {v(q)}")
+                        E.i(f"v_and_b32 {v(y + 1)}, 0xffff0000, {v(q)}")
+                        E.i(f"v_lshlrev_b32 {v(y + 2)}, 16, {v(q + 1)}")
+                        E.i(f"v_and_b32 {v(y + 3)}, 0xffff0000, {v(q + 1)}")
+                        for k in range(4):
+                            E.i(f"v_fma_f32 {v(x + k)}, {v(y + k)}, {v(ca[qb])}, {v(x + k)}")
+                    E.i(f"v_cvt_pk_bf16_f32 {v(x)}, {v(x)}, {v(x + 1)}")
+                    E.i(f"v_cvt_pk_bf16_f32 {v(x + 1)}, {v(x + 2)}, {v(x + 3)}")
+                    off = db * 64 + g * 16 if big else db * 32
+                    E.i(f"global_store_dwordx2 {v(M.V_QOFF + qb)}, {v(x, 2)}, {s(S_O, 2)} offset:{off}")
+                    E.i("s_nop 1")
+        if merge:
+            E.i("s_branch L_epi_lse")
+    E.label("L_epi_lse")
+    E.i(f"s_or_b32 {s(S_T)}, {s(S_LSEO)}, {s(S_LSEO + 1)}")
+    E.i(f"s_cmp_eq_u32 {s(S_T)}, 0")
+    E.i("s_cbranch_scc1 L_epi_done")
+    for qb in range(M.NQB):                              # every lane that holds a part of the row writes the same value
+        E.i(f"global_store_dword {v(lrow[qb])}, {v(lse[qb])}, {s(S_LSEO, 2)}")
+    E.label("L_epi_done")
+    E.i("s_waitcnt vmcnt(0)")
+
+
+def emit_masktops(E):
+    """loop-top rare path: S_cur is the last tile of a key shard and has padding keys"""
+    for ret, par in E.masktops:
+        E.label(f"L_masktop{ret}")
+        emit_mask_tail(E, par)
+        E.i(f"s_sub_u32 {s(S_MASKCNT)}, {s(S_TPS)}, 1")
+        E.i(f"s_branch L_maskback{ret}")
 
 
 MODE_DEFAULTS = {32: {"cap1": 5.6, "cap2": 5.4}, 16: {"cap1": 6.2, "cap2": 5.8}}   # smallest budgets whose P words are ready in time
@@ -865,6 +1001,8 @@ def generate(cfg=None):
     E.i("s_branch L_end")
     emit_rescale_routine(E, 0, n_ret)
     emit_rescale_routine(E, 1, n_ret)
+    emit_masktops(E)
+    emit_wrap_blocks(E)
     E.label("L_end")
     return E.text()
 
