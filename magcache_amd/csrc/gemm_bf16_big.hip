@@ -53,6 +53,8 @@
 // the LDS-DMA asm below names m0 in its clobber list on purpose (reserved register: the compiler only warns)
 #pragma clang diagnostic ignored "-Winline-asm"
 #include "common.h"
+#include <type_traits>
+
 #include "gemm_epilogue.h"
 #include "ops.h"
 
@@ -380,18 +382,64 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
       prologue_dma();
     }
   }
+  if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
+    // two-phase residual epilogue (gemm_epilogue.h): a batch of quads is loaded together, then added and stored
+    constexpr int MBB = 2;      // m blocks per batch: 8 quads = 32 (+ 16 for the capture's x0) registers, no spills
+    auto resid = [&](auto with_sel) {
+      constexpr bool SEL = decltype(with_sel)::value;          // per-row choice between two gate vectors (Wan2.2 TI2V)
+      f32x4 g1[2][2], g2[2][2];
 #pragma unroll
-  for (int mh = 0; mh < 2; ++mh) {
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const int m = em0 + wr * 128 + mh * 64 + mb * 16 + l15;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
+      for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           const int n = en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp;
-          gemm_epilogue_quad<EPI>(p, m, n, acc[mh][mb][nh][nb] + bq[nh][nb]);
+          g1[nh][nb] = p.gate ? *(const f32x4*)(p.gate + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+          g2[nh][nb] = SEL ? *(const f32x4*)(p.gate2 + n) : g1[nh][nb];
+        }
+#pragma unroll
+      for (int b0 = 0; b0 < 8; b0 += MBB) {                    // m block index 4 mh + mb
+        ResidIn in[MBB][2][2];
+        uint8_t sel[MBB];
+#pragma unroll
+        for (int j = 0; j < MBB; ++j) {
+          const int m = min(em0 + wr * 128 + (b0 + j) * 16 + l15, p.M - 1);   // rows past M: loaded (clamped), not stored
+          sel[j] = SEL ? p.gate_sel[m] : (uint8_t)0;
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              in[j][nh][nb] = resid_load<EPI>(p, m, en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp);
+        }
+#pragma unroll
+        for (int j = 0; j < MBB; ++j) {
+          const int m = em0 + wr * 128 + (b0 + j) * 16 + l15;
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              resid_apply<EPI>(p, m, en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp,
+                               acc[(b0 + j) >> 2][(b0 + j) & 3][nh][nb] + bq[nh][nb],
+                               (SEL && sel[j]) ? g2[nh][nb] : g1[nh][nb], in[j][nh][nb]);
+        }
+      }
+    };
+    if (p.gate_sel) resid(std::true_type{});
+    else resid(std::false_type{});
+  } else {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int m = em0 + wr * 128 + mh * 64 + mb * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int n = en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp;
+            gemm_epilogue_quad<EPI>(p, m, n, acc[mh][mb][nh][nb] + bq[nh][nb]);
+          }
         }
       }
     }
@@ -411,14 +459,14 @@ hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
   if (hipError_t e = ensure_dynamic_lds((const void*)gemm_big_kernel<EPI>, 2 * STAGE_BYTES, lds_ready); e != hipSuccess)
     return e;
   int grid = tilesM * tilesN;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+  }
   if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-      if (n_cu <= 0) n_cu = 256;
-    }
     if (grid > n_cu) grid = n_cu;
   }
   hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), 2 * STAGE_BYTES, stream, p,

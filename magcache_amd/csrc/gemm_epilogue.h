@@ -82,4 +82,40 @@ __device__ __forceinline__ void gemm_epilogue_quad(const GemmParams& p, int m, i
   }
 }
 
+// The residual epilogues in two phases.  gemm_epilogue_quad<EPI_RESID_*> is load - add - store per quad, and because the
+// stores may alias the next quad's loads the compiler cannot hoist a load above the previous store: the ISA was one load
+// per s_waitcnt vmcnt(0), 64 serial memory round trips per wave (~17 us per 256x256 tile, round 2's "epilogue wall").
+// resid_load for a whole batch of quads FIRST, then resid_apply for the batch: one round trip per batch.
+struct ResidIn {
+  f32x4 x;
+  u32x2 x0;   // EPI_RESID_CAPTURE only
+};
+
+template <int EPI>
+__device__ __forceinline__ ResidIn resid_load(const GemmParams& p, int m, int n) {
+  ResidIn r;
+  r.x = *(const f32x4*)(p.X + (size_t)m * p.ldx + n);
+  r.x0 = u32x2{0u, 0u};
+  if constexpr (EPI == EPI_RESID_CAPTURE) r.x0 = *(const u32x2*)(p.X0 + (size_t)m * p.ldx0 + n);
+  return r;
+}
+
+// val = acc + bias; gt = the gate values of columns n..n+3 for this row
+template <int EPI>
+__device__ __forceinline__ void resid_apply(const GemmParams& p, int m, int n, f32x4 val, f32x4 gt, ResidIn in) {
+  f32x4 xv = in.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xv[i] = xv[i] + bf16_round(val[i]) * gt[i];
+  *(f32x4*)(p.X + (size_t)m * p.ldx + n) = xv;
+  if constexpr (EPI == EPI_RESID_CAPTURE) {
+    // MagCache residual capture (reference magcache_generate.py:299): R = x_out - ori_x
+    f32x4 r;
+    r[0] = xv[0] - __uint_as_float(in.x0[0] << 16);
+    r[1] = xv[1] - __uint_as_float(in.x0[0] & 0xffff0000u);
+    r[2] = xv[2] - __uint_as_float(in.x0[1] << 16);
+    r[3] = xv[3] - __uint_as_float(in.x0[1] & 0xffff0000u);
+    *(f32x4*)(p.R + (size_t)m * p.ldr + n) = r;
+  }
+}
+
 }  // namespace mc

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gcn_emu as emu  # noqa: E402
 import gen_attention_v5 as gen  # noqa: E402
 
-IN_BASE = 64   # SGPRs the "compiler" hands the inputs over in
+IN_BASE = 128  # SGPRs the "compiler" hands the inputs over in (outside the block's own s20..s91: a restart reads them again)
 
 
 def _bind_inputs(text):
@@ -171,8 +171,47 @@ def test_v5_two_phase_local_then_remote_merge(mfma):
     assert np.abs(lse2 - lse_want).max() < 2e-2
 
 
+S_SAFE = gen.S_SAFE
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+def test_v5_lazy_reference_moves_by_row_sum_and_restarts_on_overflow(mfma):
+    """the pipelined loop takes no lane maxima (cfg lazy): a key ~2^98 above the rest moves the reference through the
+    row-sum check (no restart); one ~2^390 above overflows the exponentials, the workgroup votes and starts over in the
+    exact-maximum loop.  Both must match the fp64 softmax."""
+    rel, got, want, m = run_block(448, q_amp=1.0, seed=5, spike=True, dma_late=True, load_late=True, cfg={"mfma": mfma})
+    assert np.isfinite(got).all() and rel < 8e-3, rel
+    assert all(int(w.s[S_SAFE]) == 0 for w in m.waves)
+    rel, got, want, m = run_block(448, q_amp=4.0, seed=5, spike=True, cfg={"mfma": mfma})
+    assert np.isfinite(got).all() and rel < 8e-3, rel
+    assert all(int(w.s[S_SAFE]) == 1 for w in m.waves)
+    rel, got, want, m = run_block(300, seed=2, cfg={"mfma": mfma})
+    assert all(int(w.s[S_SAFE]) == 0 for w in m.waves)
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("n_keys", [320, 577])
+def test_v5_lazy_rescale_routine_with_a_low_threshold(n_keys, mfma):
+    # lthr = 3: ordinary data crosses the row-sum threshold every few tiles
+    rel, got, want, m = run_block(n_keys, q_amp=3.0, seed=11, dma_late=True, load_late=True, cfg={"mfma": mfma, "lthr": 3})
+    assert np.isfinite(got).all() and rel < 8e-3, rel
+    assert all(int(w.s[S_SAFE]) == 0 for w in m.waves)
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+def test_v5_exact_maximum_stream_alone(mfma):
+    # cfg lazy = 0: only the exact loop is generated (what round 3 shipped first)
+    rel, got, want, _ = run_block(448, q_amp=4.0, seed=5, spike=True, dma_late=True, load_late=True, cfg={"mfma": mfma, "lazy": 0})
+    assert np.isfinite(got).all() and rel < 8e-3, rel
+    pb = Problem(130, 3, seed=4, pad_value=40.0)
+    out_bits, _, _ = launch(pb, skip=1, cfg={"mfma": mfma, "lazy": 0})
+    got = emu.bf16_to_f32(out_bits[:, pb.head * 128:(pb.head + 1) * 128].astype(np.uint32))
+    want, _ = pb.reference([0, 2])
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 5e-3
+
+
 def test_v5_two_deep_ring_variant_is_also_right():
-    rel, got, want, _ = run_block(300, dma_late=True, load_late=True, seed=7, cfg={"nst": 2, "ahead": 1})
+    rel, got, want, _ = run_block(300, dma_late=True, load_late=True, seed=7, cfg={"nst": 2, "ahead": 1, "barrier_every": 1})
     assert np.isfinite(got).all()
     assert rel < 5e-3, rel
 

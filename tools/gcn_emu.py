@@ -112,7 +112,7 @@ class Wave:
         self.wid = wid
         self.v = np.zeros((256, 64), dtype=np.uint32)
         self.a = np.zeros((256, 64), dtype=np.uint32)
-        self.s = np.zeros(128, dtype=np.uint32)
+        self.s = np.zeros(256, dtype=np.uint32)    # (the harness parks kernel inputs above the architectural 104)
         self.vcc = np.zeros(64, dtype=bool)
         self.scc = False
         self.m0 = np.uint32(0)
@@ -207,6 +207,11 @@ class Machine:
         if op[0] == "special" and op[1] == "m0":
             w.m0 = np.uint32(val)
             w.m0_written = w.issued
+            return
+        if op[0] == "special" and op[1] == "vcc":
+            bits = np.array([(int(val) >> i) & 1 for i in range(32)], dtype=bool)
+            w.vcc = w.vcc.copy()
+            w.vcc[32 * idx:32 * idx + 32] = bits
             return
         w.s[op[2] + idx] = np.uint32(val & 0xFFFFFFFF)
 
@@ -447,6 +452,8 @@ class Machine:
     def i_v_max_f32(self, w, ins, o): self._valu(w, ins, o, np.fmax, 2, float_=True)
     def i_v_min_f32(self, w, ins, o): self._valu(w, ins, o, np.fmin, 2, float_=True)
     def i_v_max3_f32(self, w, ins, o): self._valu(w, ins, o, lambda a, b, c: np.fmax(np.fmax(a, b), c), 3, float_=True)
+    def i_v_floor_f32(self, w, ins, o): self._valu(w, ins, o, np.floor, 1, float_=True)
+    def i_v_or3_b32(self, w, ins, o): self._valu(w, ins, o, lambda a, b, c: a | b | c, 3)
     def i_v_fma_f32(self, w, ins, o): self._valu(w, ins, o, lambda a, b, c: (a.astype(np.float64) * b + c).astype(np.float32), 3, float_=True)
     def i_v_exp_f32(self, w, ins, o): self._valu(w, ins, o, lambda a: np.exp2(a.astype(np.float64)).astype(np.float32), 1, kind="trans", float_=True)
     def i_v_log_f32(self, w, ins, o): self._valu(w, ins, o, lambda a: np.log2(a.astype(np.float64)).astype(np.float32), 1, kind="trans", float_=True)
@@ -460,6 +467,14 @@ class Machine:
         self._haz_write(w, ins, o[0], "valu")
         for i in range(2):
             self.wr(w, o[0], r[i], i)
+
+    def i_v_dot2c_f32_bf16(self, w, ins, o):
+        """VOP2: D.f32 += A.bf16[0] * B.bf16[0] + A.bf16[1] * B.bf16[1]"""
+        def dot(acc, x, y):
+            lo = bf16_to_f32(x & np.uint32(0xFFFF)).astype(np.float64) * bf16_to_f32(y & np.uint32(0xFFFF))
+            hi = bf16_to_f32(x >> np.uint32(16)).astype(np.float64) * bf16_to_f32(y >> np.uint32(16))
+            return u32((f32(acc).astype(np.float64) + lo + hi).astype(np.float32))
+        self._valu(w, ins, [o[0], o[0], o[1], o[2]], dot, 3)
 
     def i_v_cvt_pk_bf16_f32(self, w, ins, o):
         self._valu(w, ins, o, lambda a, b: bf16_rne(f32(a)) | (bf16_rne(f32(b)) << np.uint32(16)), 2)
@@ -483,6 +498,8 @@ class Machine:
         with np.errstate(all="ignore"):
             w.vcc = np.asarray(fn(a, b), dtype=bool)
 
+    def i_v_cmp_nlt_f32(self, w, ins, o): self._vcmp(w, ins, o, lambda a, b: ~(a < b), True)
+    def i_v_cmp_ne_u32(self, w, ins, o): self._vcmp(w, ins, o, lambda a, b: a != b, False)
     def i_v_cmp_lt_f32(self, w, ins, o): self._vcmp(w, ins, o, lambda a, b: a < b, True)
     def i_v_cmp_gt_f32(self, w, ins, o): self._vcmp(w, ins, o, lambda a, b: a > b, True)
     def i_v_cmp_ge_i32(self, w, ins, o): self._vcmp(w, ins, o, lambda a, b: a >= b, False, True)
@@ -627,6 +644,28 @@ class Machine:
         if (addr % 16).any():
             raise RuntimeError(f"line {ins.line}: misaligned ds_read_b128")
         self._ds_finish(w, ins, o[0], lambda: self._lds_read(addr, 16).view(np.uint32).reshape(64, 4))
+
+    def i_ds_read_b32(self, w, ins, o):
+        self._haz_read(w, ins, o[1], "mem")
+        addr = self.rd(w, o[1]).astype(np.int64) + ins.mods.get("offset", 0)
+        self._ds_finish(w, ins, o[0], lambda: self._lds_read(addr, 4).view(np.uint32).reshape(64, 1))
+
+    def i_ds_write_b32(self, w, ins, o):
+        """ds_write_b32 vaddr, vdata [offset]: written at issue or, adversarially, only at the covering wait"""
+        self._haz_read(w, ins, o[0], "mem")
+        self._haz_read(w, ins, o[1], "mem")
+        addr = self.rd(w, o[0]).astype(np.int64) + ins.mods.get("offset", 0)
+        data = self.rd(w, o[1]).copy()
+
+        def put():
+            for l in range(64):
+                a = int(addr[l])
+                self.lds[a:a + 4] = np.frombuffer(np.uint32(data[l]).tobytes(), dtype=np.uint8)
+        if self.load_late:
+            w.lgkm_q.append(put)
+        else:
+            put()
+            w.lgkm_q.append(None)
 
     def i_ds_read_b64_tr_b16(self, w, ins, o):
         self._haz_read(w, ins, o[1], "mem")

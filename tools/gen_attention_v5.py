@@ -29,6 +29,7 @@ LDS-DMA = buffer_load_dwordx4 ... lds (profiles/r03/lds_dma_probe.log: LDS addre
 end of the key sequence read zeros, so the cursors need no clamp).
 Reference contract: upstream wan/modules/attention.py flash_attention (call site MagCache4Wan2.1/magcache_generate.py:297-298)."""
 import argparse
+import copy
 import math
 import os
 import re
@@ -53,8 +54,20 @@ DEFAULT_CFG = {
     "kread_p1": 0,           # this many of the 16 K fragment reads are issued in phase 1 (a fragment's register is free
                              # once the MFMAs of its d-step have been issued)
     "exp_rate1": 9.0, "exp_rate2": 9.0,   # v_exp_f32 per position at most (transcendentals take two issue slots)
+    "barrier_every": 2,      # 2: one s_barrier per TWO tiles (-1.4 % cycles, profiles/r03/NOTES.md) (needs nst >= ahead + 2 and, for nst == ahead + 2, vmcnt(0))
     "pad_nop": 0,            # diagnostic: an s_nop of this many states after every MFMA (idle cycles, no work)
     "pk_add": 0,             # row sums as v_pk_add_f32 (one instruction per pair)
+    "dot2": 0,               # row sums of the ROUNDED probabilities: v_dot2c_f32_bf16 l, ones, P word (one per pair,
+                             # the same bf16 values the PV product sums)
+    "lazy": 1,               # LAZY REFERENCE: the pipelined loop takes no lane maxima; the reference moves when a row sum
+                             # passes 2^lthr (after the tile, by an exact power of two); a workgroup whose sums end
+                             # non-finite or >= 2^120 (a score more than ~2^67 above everything before it) starts
+                             # over in the exact-maximum loop ("safe" mode, the lazy=0 stream)
+    "lthr": 60,
+    "hoist": 1,              # the rescale decision's VALU part rides behind the lane maxima of the previous iteration
+    "exp_gap": 3,            # instructions (MFMAs included) between two v_exp_f32 at least
+    "exp_lat": 3,            # ... between an exponential and the first instruction that reads it
+    "skew": 2,               # pairs between an exponential and the instructions that consume it
     "abl": "",               # TIMING ABLATIONS (wrong results): comma list of exp add cvt max lds dma bar -- drops those
 }
 
@@ -66,12 +79,15 @@ S_NT, S_TAIL, S_C, S_WV, S_LDS, S_KNREC, S_VNREC = 35, 36, 37, 38, 39, 40, 41
 S_KSTEP, S_VSTEP, S_IT, S_KCUR, S_VCUR = 42, 43, 44, 45, 46
 S_T = 47                     # temporaries 47..51
 S_FLOOR, S_RET, S_THR, S_VSLOT = 52, 53, 54, 55
-S_DK, S_DV = 56, 60          # [slot] LDS destination of this wave's pieces (up to 4 slots each)
+S_LDSW = 56                  # LDS byte address of this wave's 4 KiB inside slot 0 of the K ring
 S_KSRD, S_VSRD = 64, 68      # buffer descriptors
 S_KSHS, S_VSHS, S_TPS, S_SKIP = 72, 73, 74, 75       # shard strides (bytes), tiles per shard, shard to leave out (-1: none)
 S_KTIN, S_KSH, S_VTIN, S_VSH = 76, 77, 78, 79        # DMA cursors: tile in shard / shard index of the NEXT tile to issue
 S_MASKCNT, S_KWRAP, S_VWRAP, S_FIRST = 80, 81, 82, 83             # iterations until S_cur is a shard's last tile; shard-wrap jumps
 S_LSEO, S_LSEI = 84, 86                              # log-sum-exp out / in row pointers (0: none)
+S_ONES = 57                  # bf16 1.0 | 1.0
+S_SAFE, S_LTHR, S_BIG = 58, 59, 60   # lazy reference: 1 = second pass in the exact loop; 2^lthr; 2^120
+VOTE_OFF_BYTES = 256         # LDS behind the rings: one flag word per wave
 S_LAST = 91
 N_INPUTS = 22
 
@@ -154,8 +170,9 @@ class Emitter:
         self.uid = 0
         self.masktops = []        # (ret id, S buffer) of the loop-top mask paths
         self.ool = []             # out-of-line blocks (shard wraps) to emit behind the main code
+        self.lazy = False         # this region's loop runs on the lazy reference
 
-    ABL = {"exp": ("v_exp_f32",), "add": ("v_add_f32", "v_pk_add_f32"), "cvt": ("v_cvt_pk_bf16_f32",),
+    ABL = {"exp": ("v_exp_f32",), "add": ("v_add_f32", "v_pk_add_f32", "v_dot2c_f32_bf16"), "cvt": ("v_cvt_pk_bf16_f32",),
            "max": ("v_max3_f32",), "lds": ("ds_read_b128", "ds_read_b64_tr_b16"), "dma": ("buffer_load_dwordx4",),
            "bar": ("s_barrier",)}
 
@@ -169,8 +186,13 @@ class Emitter:
                     if m:
                         self.written_at[int(m.group(1))] = self.n
                     return
-            if "lds" in str(self.cfg["abl"]).split("+") and mn == "s_waitcnt" and "lgkmcnt" in text:
-                return
+            keys = str(self.cfg["abl"]).split("+")
+            if ("lds" in keys or "wl" in keys) and mn == "s_waitcnt" and "lgkmcnt" in text:
+                self.n += 1
+                return           # wl: the LDS reads stay, only their waits go
+            if "wv" in keys and mn == "s_waitcnt" and "vmcnt" in text:
+                self.n += 1
+                return           # wv: the barrier stays, the wait for the LDS-DMA in front of it goes
         self.lines.append("  " + text)
         self.n += 1
         m = re.match(r"v_cvt_pk_bf16_f32 v(\d+),", text)
@@ -214,7 +236,7 @@ class Emitter:
 
 
 # ---------------------------------------------------------------- instruction streams
-def finish_stream(M, buf, groups, pk_add=False):
+def finish_stream(M, buf, groups, pk_add=False, SK=2, dot2=False):
     """softmax finish of S_cur for the given (ks, qb) groups: exp2 in place, row sums, bf16 pack in place (word p of a
     group lands in its register p: the 4 words of a key step are the B operand of its PV MFMAs).  One linear list,
     software-skewed so that nothing uses a result produced less than two instructions earlier."""
@@ -224,7 +246,10 @@ def finish_stream(M, buf, groups, pk_add=False):
         for p in range(4):        # pair p = elements 2p, 2p+1 -> word p
             r0, r1 = base + 2 * p, base + 2 * p + 1
             ex.append([f"v_exp_f32 {v(r0)}, {v(r0)}", f"v_exp_f32 {v(r1)}, {v(r1)}"])
-            if pk_add:
+            if dot2:
+                rest.append([f"v_cvt_pk_bf16_f32 {v(base + p)}, {v(r0)}, {v(r1)}",
+                             f"v_dot2c_f32_bf16 {v(M.V_L + 2 * qb + (p & 1))}, {s(S_ONES)}, {v(base + p)}"])
+            elif pk_add:
                 rest.append([f"v_pk_add_f32 {v(M.V_L + 2 * qb, 2)}, {v(M.V_L + 2 * qb, 2)}, {v(r0, 2)}",
                              f"v_cvt_pk_bf16_f32 {v(base + p)}, {v(r0)}, {v(r1)}"])
             else:
@@ -233,8 +258,7 @@ def finish_stream(M, buf, groups, pk_add=False):
                              f"v_cvt_pk_bf16_f32 {v(base + p)}, {v(r0)}, {v(r1)}"])
     out = []
     n = len(ex)
-    SK = 2                        # pairs of skew between the exponentials and their consumers
-    for k in range(n + SK):
+    for k in range(n + SK):       # SK pairs of skew between the exponentials and their consumers
         e_ = list(ex[k]) if k < n else []
         r_ = list(rest[k - SK]) if k >= SK else []
         while e_ or r_:           # E R E R R: never two transcendentals back to back
@@ -246,6 +270,54 @@ def finish_stream(M, buf, groups, pk_add=False):
                 out += r_
                 r_ = []
     return out
+
+
+class Finish:
+    """the softmax finish of one tile as two queues (exponentials / their consumers) that the gap filler draws from:
+    an exponential occupies the transcendental unit for ~16 cycles and the NEXT one stalls the (in-order) wave until it is
+    free (tools/ubench_gap2: E v E v behind one MFMA 47 cycles, E v v v v 36), so exponentials are kept exp_gap
+    instructions apart; a consumer needs its pair's exponentials issued exp_lat instructions earlier."""
+
+    def __init__(self, E, buf, groups):
+        M, cfg = E.M, E.cfg
+        self.E, self.gap, self.lat = E, cfg["exp_gap"], cfg["exp_lat"]
+        self.exq, self.restq = [], []          # restq: (instruction, index of the last exponential it needs)
+        for ks, qb in groups:
+            base = M.P(buf, qb, ks)
+            for p in range(4):
+                r0, r1 = base + 2 * p, base + 2 * p + 1
+                self.exq += [f"v_exp_f32 {v(r0)}, {v(r0)}", f"v_exp_f32 {v(r1)}, {v(r1)}"]
+                need = len(self.exq) - 1
+                self.restq += [(f"v_add_f32 {v(M.V_L + 2 * qb)}, {v(M.V_L + 2 * qb)}, {v(r0)}", need - 1),
+                               (f"v_add_f32 {v(M.V_L + 2 * qb + 1)}, {v(M.V_L + 2 * qb + 1)}, {v(r1)}", need),
+                               (f"v_cvt_pk_bf16_f32 {v(base + p)}, {v(r0)}, {v(r1)}", need)]
+        self.n_exp = 0
+        self.issued_at = []                    # E.n at the issue of exponential i
+        self.last_exp = -10 ** 9
+
+    def __bool__(self):
+        return bool(self.exq or self.restq)
+
+    def peek(self):
+        E = self.E
+        if self.exq and E.n - self.last_exp >= self.gap:
+            return self.exq[0]
+        if self.restq:
+            t, need = self.restq[0]
+            if need < self.n_exp and E.n - self.issued_at[need] >= self.lat:
+                return t
+        return None
+
+    def pop(self):
+        t = self.peek()
+        if t.startswith("v_exp_f32"):
+            self.exq.pop(0)
+            self.issued_at.append(self.E.n)
+            self.last_exp = self.E.n
+            self.n_exp += 1
+        else:
+            self.restq.pop(0)
+        return t
 
 
 def rowmax_stream(M, buf, qb):
@@ -337,8 +409,7 @@ def emit_seq(E, seq):
 
 def dma_tile_now(E, op, slot):
     """a whole operand tile back to back (prologue), cursor moves on"""
-    dst = S_DK if op == "K" else S_DV
-    E.i(f"s_mov_b32 m0, {s(dst + slot)}")
+    E.i(f"s_add_u32 m0, {s(S_LDSW)}, {slot * TILE + (0 if op == 'K' else E.cfg['nst'] * TILE)}")
     E.i("s_nop 0")
     for j in range(4):
         E.i(dma_piece(E.M, op, j))
@@ -410,7 +481,7 @@ def emit_phase1(E, B):
     cfg, M = E.cfg, E.M
     cur, nxt = B.par, 1 - B.par
     sc = M.NM // 32                      # gaps per "position"
-    fin = finish_stream(M, cur, [(ks, qb) for ks in range(M.NKS) for qb in range(M.NQB)], cfg["pk_add"])
+    fin = Finish(E, cur, [(ks, qb) for ks in range(M.NKS) for qb in range(M.NQB)])
     pos = [p * sc for p in cfg["dma_at"]]
     dma_at = {}
     for j in range(4):
@@ -438,7 +509,8 @@ def emit_phase1(E, B):
                 ecr.gap()
                 if g in m0_at:
                     op = m0_at[g]
-                    E.i(f"s_mov_b32 m0, {s((S_DK if op == 'K' else S_DV) + (B.k_dma_slot if op == 'K' else B.v_dma_slot))}")
+                    dst = B.k_dma_slot * TILE if op == "K" else cfg["nst"] * TILE + B.v_dma_slot * TILE
+                    E.i(f"s_add_u32 m0, {s(S_LDSW)}, {dst}")
                     cr.spend(1)
                 if g in dma_at:
                     t = dma_piece(M, *dma_at[g])
@@ -451,13 +523,9 @@ def emit_phase1(E, B):
                     f = (g - first) // M.NQB
                     tickets[f] = vfrag_reads(E, f, B.v_read_slot * TILE)
                     cr.spend(2)
-                while fin and cr.can(E.weight(fin[0])):
-                    if fin[0].startswith("v_exp_f32"):
-                        if not ecr.can(1):
-                            break
-                        ecr.spend(1)
-                    cr.spend(E.weight(fin[0]))
-                    E.i(fin.pop(0))
+                while fin.peek() and cr.can(E.weight(fin.peek())):
+                    cr.spend(E.weight(fin.peek()))
+                    E.i(fin.pop())
                 # K(t+2) fragments whose registers are free (their d-step of this phase has been issued)
                 if k_p1 < cfg["kread_p1"] and kreads and g >= per_step * (kreads[0][1] + 1) + 1 and cr.can(1):
                     kb_, ds_ = kreads.pop(0)
@@ -474,7 +542,13 @@ def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=Non
     cfg, M = E.cfg, E.M
     cur, nxt = par, 1 - par
     sc = M.NM // 32
-    rmx = [] if last else rowmax_all(M, nxt)
+    lazy = bool(E.lazy)
+    if last:
+        rmx = []
+    elif lazy:
+        rmx = []                 # no lane maxima; the row-sum check needs ALL of this tile's sums: behind the loop
+    else:
+        rmx = rowmax_all(M, nxt) + (decide_valu(M) if cfg["hoist"] else [])
     kreads = [] if last else list(E.kreads_left)
     kt = [] if last else list(E.kt)
     k0, k1 = cfg["kread_from"] * sc, cfg["kread_to"] * sc
@@ -502,13 +576,9 @@ def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=Non
                 if qb == 0 and f + vlook < nfr:
                     tickets[f + vlook] = vfrag_reads(E, f + vlook, v_off, v_addr)
                     cr.spend(2)
-                while fin and cr.can(E.weight(fin[0])):
-                    if fin[0].startswith("v_exp_f32"):
-                        if not ecr.can(1):
-                            break
-                        ecr.spend(1)
-                    cr.spend(E.weight(fin[0]))
-                    E.i(fin.pop(0))
+                while fin.peek() and cr.can(E.weight(fin.peek())):
+                    cr.spend(E.weight(fin.peek()))
+                    E.i(fin.pop())
                 if kreads and g >= kdue[len(kt)]:
                     kb_, ds_ = kreads.pop(0)
                     kt.append(kfrag_read(E, kb_, ds_, k_slot))
@@ -524,38 +594,79 @@ def emit_phase2(E, par, tickets, fin, v_off, k_slot=None, last=False, v_addr=Non
         kt.append(kfrag_read(E, kb_, ds_, k_slot))
     for t in rmx:
         E.i(t)
+    if lazy and not last and cfg["hoist"]:
+        for t in decide_valu(M, True):
+            E.i(t)
     if kt:
         E.wait_lds(kt[-1])
 
 
-def emit_decide(E, par, ret):
-    """does some lane's maximum of S_cur exceed the reference by more than 2^RTHR?  (rare, wave-uniform branch)"""
-    M = E.M
+def decide_valu(M, lazy=False):
+    """vcc <- exact: some lane's maximum of the tile exceeds the reference by more than 2^RTHR
+              lazy:  some row-sum partial of the lane has passed 2^lthr"""
+    if lazy:
+        ls = [M.V_L + i for i in range(2 * M.NQB)]
+        out = [f"v_max3_f32 {v(M.V_T)}, {v(ls[0])}, {v(ls[1])}, {v(ls[2])}"]
+        k = 3
+        while k < len(ls):
+            if k + 1 < len(ls):
+                out.append(f"v_max3_f32 {v(M.V_T)}, {v(M.V_T)}, {v(ls[k])}, {v(ls[k + 1])}")
+                k += 2
+            else:
+                out.append(f"v_max_f32 {v(M.V_T)}, {v(M.V_T)}, {v(ls[k])}")
+                k += 1
+        return out + [f"v_cmp_lt_f32 vcc, {s(S_LTHR)}, {v(M.V_T)}"]
     if M.NQB == 2:
-        E.i(f"v_max_f32 {v(M.V_T)}, {v(M.V_MX)}, {v(M.V_MX + 1)}")
+        out = [f"v_max_f32 {v(M.V_T)}, {v(M.V_MX)}, {v(M.V_MX + 1)}"]
     else:
-        E.i(f"v_max3_f32 {v(M.V_T)}, {v(M.V_MX)}, {v(M.V_MX + 1)}, {v(M.V_MX + 2)}")
-        E.i(f"v_max_f32 {v(M.V_T)}, {v(M.V_T)}, {v(M.V_MX + 3)}")
-    E.i(f"v_cmp_lt_f32 vcc, {s(S_THR)}, {v(M.V_T)}")
+        out = [f"v_max3_f32 {v(M.V_T)}, {v(M.V_MX)}, {v(M.V_MX + 1)}, {v(M.V_MX + 2)}",
+               f"v_max_f32 {v(M.V_T)}, {v(M.V_T)}, {v(M.V_MX + 3)}"]
+    return out + [f"v_cmp_lt_f32 vcc, {s(S_THR)}, {v(M.V_T)}"]
+
+
+def emit_decide(E, par, ret, hoisted=False, lazy=False):
+    """exact: does some lane's maximum of S_cur exceed the reference by more than 2^RTHR?  lazy: has a row sum grown past
+    2^lthr?  (rare, wave-uniform branch)
+    hoisted: vcc was already set at the end of the previous iteration's phase 2"""
+    if not hoisted:
+        for t in decide_valu(E.M, lazy):
+            E.i(t)
     E.i(f"s_mov_b32 {s(S_RET)}, {ret}")
-    E.i(f"s_cbranch_vccnz L_rescale{par}")
+    E.i(f"s_cbranch_vccnz L_{'lz' if lazy else ''}rescale{par}")
     E.label(f"L_back{ret}")
 
 
-def emit_rescale_routine(E, par, n_ret):
-    """O, l, S_cur and c_init move to a new reference: d = max(row max, floor) (floor = 0, -inf on the first tile)"""
+def emit_rescale_routine(E, par, n_ret, lazy=False):
+    """O, l, S_cur and c_init move to a new reference.
+    exact: d = max(row max, floor) (floor = 0, -inf on the first tile)
+    lazy:  d = max(0, floor(log2(row sum))): an exact power of two, the row sum comes back to [1, 2)"""
     M = E.M
-    E.label(f"L_rescale{par}")
+    E.label(f"L_{'lz' if lazy else ''}rescale{par}")
     E.i("s_nop 15")
-    for qb in range(M.NQB):
-        for t in combine_lanes(M, M.V_MX + qb, "v_max_f32"):
-            E.i(t)
-    for qb in range(M.NQB):
-        d, al = M.V_D + qb, M.V_ALPHA + qb
-        E.i(f"v_max_f32 {v(d)}, {s(S_FLOOR)}, {v(M.V_MX + qb)}")
-        E.i(f"v_add_f32 {v(M.V_M + qb)}, {v(M.V_M + qb)}, {v(d)}")
-        E.i(f"v_exp_f32 {v(al)}, -{v(d)}")
-        E.i(f"v_sub_f32 {v(M.V_MX + qb)}, {v(M.V_MX + qb)}, {v(d)}")
+    if lazy:
+        for qb in range(M.NQB):
+            d = M.V_D + qb
+            E.i(f"v_add_f32 {v(d)}, {v(M.V_L + 2 * qb)}, {v(M.V_L + 2 * qb + 1)}")
+            for t in combine_lanes(M, d, "v_add_f32"):
+                E.i(t)
+            E.i(f"v_log_f32 {v(d)}, {v(d)}")
+            E.i("s_nop 0")
+            E.i(f"v_floor_f32 {v(d)}, {v(d)}")
+            E.i(f"v_max_f32 {v(d)}, 0, {v(d)}")
+        for qb in range(M.NQB):
+            d, al = M.V_D + qb, M.V_ALPHA + qb
+            E.i(f"v_add_f32 {v(M.V_M + qb)}, {v(M.V_M + qb)}, {v(d)}")
+            E.i(f"v_exp_f32 {v(al)}, -{v(d)}")
+    else:
+        for qb in range(M.NQB):
+            for t in combine_lanes(M, M.V_MX + qb, "v_max_f32"):
+                E.i(t)
+        for qb in range(M.NQB):
+            d, al = M.V_D + qb, M.V_ALPHA + qb
+            E.i(f"v_max_f32 {v(d)}, {s(S_FLOOR)}, {v(M.V_MX + qb)}")
+            E.i(f"v_add_f32 {v(M.V_M + qb)}, {v(M.V_M + qb)}, {v(d)}")
+            E.i(f"v_exp_f32 {v(al)}, -{v(d)}")
+            E.i(f"v_sub_f32 {v(M.V_MX + qb)}, {v(M.V_MX + qb)}, {v(d)}")
     E.i("s_nop 0")
     for qb in range(M.NQB):
         d, al = M.V_D + qb, M.V_ALPHA + qb
@@ -575,6 +686,7 @@ def emit_rescale_routine(E, par, n_ret):
             for k in range(4):
                 E.i(f"v_accvgpr_write_b32 {a(A_O + no * qb + r0 + k)}, {v(M.V_T + 4 + k)}")
     E.i(f"s_mov_b32 {s(S_FLOOR)}, 0")
+    E.i("s_mov_b64 vcc, 0")          # (hoisted decision) the tile now sits at or below the new reference
     E.i("s_nop 4")
     for r in range(n_ret):
         E.i(f"s_cmp_eq_u32 {s(S_RET)}, {r}")
@@ -589,20 +701,23 @@ def emit_body(E, b, ret):
     E.comment(f"---- iteration body {b}: S_cur = buffer {B.par}, reads K slot {B.k_read_slot} / V slot {B.v_read_slot}, "
               f"refills K slot {B.k_dma_slot} / V slot {B.v_dma_slot}")
     E.in_body = True
-    E.i(f"s_waitcnt vmcnt({8 * (cfg['ahead'] - 1)})")
-    E.i("s_barrier")
+    if b % cfg["barrier_every"] == 0:
+        # everything the next barrier_every tiles read must have landed in every wave: the pieces of the last
+        # (ahead - barrier_every) iterations may stay in flight
+        E.i(f"s_waitcnt vmcnt({8 * max(0, cfg['ahead'] - cfg['barrier_every'])})")
+        E.i("s_barrier")
     # S_cur is the last tile of a key shard with padding keys (counter runs out): mask them, lane maxima again (rare)
     E.i(f"s_sub_u32 {s(S_MASKCNT)}, {s(S_MASKCNT)}, 1")
     E.i(f"s_cbranch_scc1 L_masktop{ret}")
     E.label(f"L_maskback{ret}")
     E.masktops.append((ret, B.par))
-    emit_decide(E, B.par, ret)
+    emit_decide(E, B.par, ret, hoisted=bool(cfg["hoist"]), lazy=bool(E.lazy))
     tickets, fin = emit_phase1(E, B)
     emit_phase2(E, B.par, tickets, fin, B.v_read_slot * TILE, k_slot=B.k_read_slot)
     E.in_body = False
 
 
-def emit_mask_tail(E, par):
+def emit_mask_tail(E, par, rowmax=True):
     """the last tile of the key sequence has S_TAIL < 64 valid keys: -inf on the others, lane maxima again"""
     M = E.M
     for qb in range(M.NQB):
@@ -611,8 +726,9 @@ def emit_mask_tail(E, par):
                 x = M.S(par, qb, kb) + r
                 E.i(f"v_cmp_ge_i32 vcc, {M.key_of(kb, r)}, {v(M.V_TAILV)}")
                 E.i(f"v_cndmask_b32 {v(x)}, {v(x)}, {v(M.V_NINF)}, vcc")
-    for t in rowmax_all(M, par):
-        E.i(t)
+    if rowmax:
+        for t in rowmax_all(M, par):
+            E.i(t)
 
 
 def emit_last(E, par, ret):
@@ -625,14 +741,17 @@ def emit_last(E, par, ret):
     E.i("s_nop 15")                       # S_cur was written by the MFMAs just before (one-tile problems)
     E.i(f"s_cmp_ge_u32 {s(S_TAIL)}, 64")
     E.i(f"s_cbranch_scc1 L_nomask{ret}")
-    emit_mask_tail(E, par)
+    emit_mask_tail(E, par, rowmax=not E.lazy)
     E.label(f"L_nomask{ret}")
+    if E.lazy:                            # the last tile is always checked exactly (once per workgroup: free)
+        for t in rowmax_all(M, par):
+            E.i(t)
     emit_decide(E, par, ret)
     va = M.V_VF + 4 * (M.NVF - 2)         # the last two fragment buffers hold the run-time V addresses here
     assert M.NDB <= 8
     for db in range(M.NDB):               # V^T fragment addresses of the (run-time) ring slot
         E.i(f"v_add_u32 {v(va + db)}, {s(S_VSLOT)}, {v(M.V_VOFF + db)}")
-    for t in finish_stream(M, par, [(ks, qb) for ks in range(M.NKS) for qb in range(M.NQB)]):
+    for t in finish_stream(M, par, [(ks, qb) for ks in range(M.NKS) for qb in range(M.NQB)], dot2=E.cfg["dot2"]):
         E.i(t)
     E.i("s_nop 1")
     # unpipelined: fragment by fragment through buffer 0 (this code runs once per 256-row block)
@@ -757,10 +876,7 @@ def emit_prologue(E):
             E.i(f"v_subrev_u32 {v(M.V_SRCV + j)}, {1024 * j}, {v(M.V_SRCV + j)}")
     # LDS destinations of this wave's pieces, tile steps, counters
     E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 12")
-    E.i(f"s_add_u32 {s(S_T)}, {s(S_T)}, {s(S_LDS)}")
-    for sl in range(nst):
-        E.i(f"s_add_u32 {s(S_DK + sl)}, {s(S_T)}, {sl * TILE}")
-        E.i(f"s_add_u32 {s(S_DV + sl)}, {s(S_T)}, {vring + sl * TILE}")
+    E.i(f"s_add_u32 {s(S_LDSW)}, {s(S_T)}, {s(S_LDS)}")
     E.i(f"s_lshl_b32 {s(S_KSTEP)}, {s(S_LDK)}, 6")
     E.i(f"s_lshl_b32 {s(S_VSTEP)}, {s(S_LDV)}, 6")
     E.i(f"s_sub_u32 {s(S_IT)}, {s(S_NT)}, 1")
@@ -780,7 +896,11 @@ def emit_prologue(E):
     E.i(f"s_cmp_ge_u32 {s(S_TAIL)}, 64")
     E.i(f"s_cselect_b32 {s(S_MASKCNT)}, -1, {s(S_MASKCNT)}")
     E.i(f"s_mov_b32 {s(S_FLOOR)}, 0xff800000")
-    E.i(f"s_mov_b32 {s(S_THR)}, {RTHR}")
+    # (timing ablations that drop the lane maxima must never take the rescale branch)
+    E.i(f"s_mov_b32 {s(S_ONES)}, 0x3f803f80")
+    E.i(f"s_mov_b32 {s(S_LTHR)}, {hex((127 + int(cfg['lthr'])) << 23)}")     # 2^lthr
+    E.i(f"s_mov_b32 {s(S_BIG)}, {hex((127 + 120) << 23)}")                    # 2^120
+    E.i(f"s_mov_b32 {s(S_THR)}, {'0x7f800000' if 'max' in str(cfg['abl']).split('+') else RTHR}")
     E.i(f"v_mov_b32 {v(M.V_NINF)}, 0xff800000")
     E.i(f"v_lshlrev_b32 {v(t0)}, 2, {v(M.V_G)}")
     E.i(f"v_sub_u32 {v(M.V_TAILV)}, {s(S_TAIL)}, {v(t0)}")              # key index bound seen by this lane group
@@ -956,12 +1076,15 @@ def emit_masktops(E):
     """loop-top rare path: S_cur is the last tile of a key shard and has padding keys"""
     for ret, par in E.masktops:
         E.label(f"L_masktop{ret}")
-        emit_mask_tail(E, par)
+        emit_mask_tail(E, par, rowmax=not E.lazy)
+        if E.cfg["hoist"]:
+            for t in decide_valu(E.M, bool(E.lazy)):
+                E.i(t)
         E.i(f"s_sub_u32 {s(S_MASKCNT)}, {s(S_TPS)}, 1")
         E.i(f"s_branch L_maskback{ret}")
 
 
-MODE_DEFAULTS = {32: {"cap1": 5.6, "cap2": 5.4}, 16: {"cap1": 6.2, "cap2": 5.8}}   # smallest budgets whose P words are ready in time
+MODE_DEFAULTS = {32: {"cap1": 6.0, "cap2": 4.8}, 16: {"cap1": 6.6, "cap2": 5.8}}   # smallest budgets whose P words are ready in time
 
 
 def full_cfg(cfg=None):
@@ -969,15 +1092,14 @@ def full_cfg(cfg=None):
     return dict(DEFAULT_CFG, **dict(MODE_DEFAULTS[cfg.get("mfma", DEFAULT_CFG["mfma"])], **cfg))
 
 
-def generate(cfg=None):
-    cfg = full_cfg(cfg)
+def emit_region(E, U, n_ret, exit_label):
+    """first-tile reference, the pipelined loop, the last tile -> (inline text, out-of-line text) of one loop flavour
+    (E.lazy); ret ids: 0 first tile, 1..U loop bodies, U+1 / U+2 last tile with S in buffer 0 / 1"""
+    cfg = E.cfg
     nst = cfg["nst"]
-    U = nst * 2 // math.gcd(nst, 2)
-    assert cfg["ahead"] >= 1 and cfg["ahead"] + 2 <= nst + 1, "ring too shallow for this prefetch distance"
-    E = Emitter(cfg)
-    emit_prologue(E)
-    # ret ids: 0 prologue, 1..U loop bodies, U+1 / U+2 last tile with S in buffer 0 / 1
-    n_ret = U + 3
+    E.lines = []
+    E.ool = []
+    E.masktops = []
     # first tile: unconditional "rescale" with floor = -inf sets the reference to the row maxima of S(0)
     E.i(f"s_mov_b32 {s(S_RET)}, 0")
     E.i("s_branch L_rescale0")
@@ -995,20 +1117,114 @@ def generate(cfg=None):
     for par in range(2):
         E.label(f"L_last{par}")
         emit_last(E, par, U + 1 + par)
-        E.i("s_branch L_epilogue")
+        E.i(f"s_branch {exit_label}")
+    inline = E.lines
+    E.lines = []
+    emit_rescale_routine(E, 0, n_ret)
+    emit_rescale_routine(E, 1, n_ret)
+    if E.lazy:
+        emit_rescale_routine(E, 0, n_ret, lazy=True)
+        emit_rescale_routine(E, 1, n_ret, lazy=True)
+    emit_masktops(E)
+    emit_wrap_blocks(E)
+    return inline, E.lines
+
+
+def rename_labels(lines, sfx, keep):
+    """every label DEFINED in these lines (and its uses in them) gets the suffix; `keep`: shared labels"""
+    defined = {ln[:-1] for ln in lines if ln.endswith(":") and not ln.startswith(" ")} - set(keep)
+    pat = re.compile(r"\b(" + "|".join(sorted(map(re.escape, defined), key=len, reverse=True)) + r")\b") if defined else None
+    return [pat.sub(lambda m: m.group(1) + sfx, ln) for ln in lines] if pat else lines
+
+
+def emit_vote(E):
+    """(lazy loop only) did every wave's row sums stay finite and below 2^120?  If not the whole workgroup starts over in
+    the exact-maximum loop; nothing has been written to global memory yet."""
+    M = E.M
+    t0, fl = M.V_T, M.V_VF            # the fragment ring registers are dead here (a 4-aligned tuple)
+    E.label("L_vote")
+    ls = [M.V_L + i for i in range(2 * M.NQB)]
+    E.i(f"v_add_f32 {v(t0)}, {v(ls[0])}, {v(ls[1])}")
+    for x in ls[2:]:
+        E.i(f"v_add_f32 {v(t0)}, {v(t0)}, {v(x)}")
+    E.i(f"v_cmp_nlt_f32 vcc, {v(t0)}, {s(S_BIG)}")        # NaN, inf or huge
+    E.i(f"s_mov_b32 {s(S_T)}, 1")
+    E.i("s_cbranch_vccnz L_vote_bad")
+    E.i(f"s_mov_b32 {s(S_T)}, 0")
+    E.label("L_vote_bad")
+    E.i(f"s_lshl_b32 {s(S_T + 1)}, {s(S_WV)}, 2")
+    E.i(f"s_add_u32 {s(S_T + 2)}, {s(S_LDS)}, {2 * E.cfg['nst'] * TILE}")     # the flag words sit behind the rings
+    E.i(f"s_add_u32 {s(S_T + 1)}, {s(S_T + 1)}, {s(S_T + 2)}")
+    E.i(f"v_mov_b32 {v(t0 + 1)}, {s(S_T + 1)}")
+    E.i(f"v_mov_b32 {v(t0 + 2)}, {s(S_T)}")
+    E.i(f"ds_write_b32 {v(t0 + 1)}, {v(t0 + 2)}")
+    E.i("s_waitcnt lgkmcnt(0)")
+    E.i("s_barrier")
+    E.i(f"v_mov_b32 {v(t0 + 1)}, {s(S_T + 2)}")
+    E.i(f"ds_read_b128 {v(fl, 4)}, {v(t0 + 1)}")
+    E.i("s_waitcnt lgkmcnt(0)")
+    E.i(f"v_or3_b32 {v(fl)}, {v(fl)}, {v(fl + 1)}, {v(fl + 2)}")
+    E.i(f"v_or_b32 {v(fl)}, {v(fl)}, {v(fl + 3)}")
+    E.i(f"v_cmp_ne_u32 vcc, 0, {v(fl)}")
+    E.i("s_cbranch_vccz L_epilogue")
+    E.i(f"s_mov_b32 {s(S_SAFE)}, 1")
+    E.i("s_waitcnt vmcnt(0)")
+    E.i("s_barrier")                  # every wave has read the flags and has no LDS-DMA in flight: the rings may be refilled
+    E.i("s_branch L_restart")
+
+
+def generate(cfg=None):
+    cfg = full_cfg(cfg)
+    nst = cfg["nst"]
+    U = nst * 2 // math.gcd(nst, 2)
+    assert cfg["ahead"] >= 1 and cfg["ahead"] + 2 <= nst + 1, "ring too shallow for this prefetch distance"
+    assert cfg["barrier_every"] in (1, 2) and (cfg["barrier_every"] == 1 or (nst >= cfg["ahead"] + 2 and cfg["ahead"] >= 2))
+    n_ret = U + 3
+    E = Emitter(cfg)
+    lazy = bool(cfg["lazy"])
+    if lazy:
+        E.i(f"s_mov_b32 {s(S_SAFE)}, 0")
+        E.label("L_restart")
+    emit_prologue(E)
+    head, shared_ool = E.lines, list(E.ool)
+    shared = ["L_epilogue", "L_vote", "L_restart", "L_end", "L_safe_entry"]
+    out = list(head)
+    tail = []
+    if lazy:
+        out.append(f"  s_cmp_eq_u32 {s(S_SAFE)}, 1")
+        out.append("  s_cbranch_scc1 L_safe_entry")
+        Z = copy.deepcopy(E)
+        Z.lazy = True
+        inl, ool = emit_region(Z, U, n_ret, "L_vote")
+        both = rename_labels(inl + ["@@"] + ool, "_z", shared)
+        k = both.index("@@")
+        out += both[:k]
+        tail += both[k + 1:]
+        out.append("L_safe_entry:")
+    X = copy.deepcopy(E)
+    X.lazy = False
+    inl, ool = emit_region(X, U, n_ret, "L_epilogue")
+    out += inl
+    tail += ool
+    E.lines = []
+    if lazy:
+        emit_vote(E)
     E.label("L_epilogue")
     emit_epilogue(E)
     E.i("s_branch L_end")
-    emit_rescale_routine(E, 0, n_ret)
-    emit_rescale_routine(E, 1, n_ret)
-    emit_masktops(E)
-    emit_wrap_blocks(E)
-    E.label("L_end")
-    return E.text()
+    out += E.lines
+    out += tail
+    E.lines = []
+    E.ool = shared_ool
+    emit_wrap_blocks(E)               # the shard wraps of the prologue's cursor moves
+    out += E.lines
+    out.append("L_end:")
+    return "\n".join(out) + "\n"
 
 
 def lds_bytes(cfg=None):
-    return 2 * full_cfg(cfg)["nst"] * TILE
+    c = full_cfg(cfg)
+    return 2 * c["nst"] * TILE + (VOTE_OFF_BYTES if c["lazy"] else 0)
 
 
 def to_inc(text):
