@@ -134,23 +134,56 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(GemmParams p, int 
 
   // ---- epilogue.  acc[ni][mi][r] = C[m][n], m = m0+wm*64+mi*32+l31,
   //      n = n0+wn*64+ni*32 + (r&3) + 8*(r>>2) + 4*half  -> 4 consecutive n per (r>>2)
+  if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
+    // two-phase residual epilogue (gemm_epilogue.h): the 8 quads of a row are loaded together, then added and stored
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = m0 + wm * 64 + mi * 32 + l31;
-    if (m >= p.M) continue;
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + l31;
+      const int ml = min(m, p.M - 1);           // rows past M: loaded (clamped), not stored
+      const float* gp = (p.gate_sel && p.gate_sel[ml]) ? p.gate2 : p.gate;
+      ResidIn in[2][4];
+      f32x4 gt[2][4], bv[2][4];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * half;
-        if (n >= p.N) continue;
-        f32x4 val;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b = *(const f32x4*)(p.bias + n);
+        for (int g = 0; g < 4; ++g) {
+          const int n = min(n0 + wn * 64 + ni * 32 + 8 * g + 4 * half, p.N - 4);
+          in[ni][g] = resid_load<EPI>(p, ml, n);
+          gt[ni][g] = p.gate ? *(const f32x4*)(gp + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+          bv[ni][g] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      if (m >= p.M) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) val[i] = acc[ni][mi][4 * g + i] + b[i];
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * half;
+          if (n >= p.N) continue;
+          f32x4 val;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) val[i] = acc[ni][mi][4 * g + i] + bv[ni][g][i];
+          resid_apply<EPI>(p, m, n, val, gt[ni][g], in[ni][g]);
+        }
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + l31;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * half;
+          if (n >= p.N) continue;
+          f32x4 val;
+          f32x4 b = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) val[i] = acc[ni][mi][4 * g + i] + b[i];
 
-        gemm_epilogue_quad<EPI>(p, m, n, val);
+          gemm_epilogue_quad<EPI>(p, m, n, val);
+        }
       }
     }
   }

@@ -410,16 +410,19 @@ def test_attention_two_phase_rejects_bad_selection():
         H.attention_partial(q, q, q, o, 1, 64, 64, 4, 0.1, 64 * 128, skip_shard=4)
 
 
-@pytest.mark.parametrize("gain", [6.0, 40.0])
-def test_attention_strided_qkv_and_online_softmax_rescale(attn_variant, gain):
+@pytest.mark.parametrize("gain,q_gain", [(6.0, 1.0), (6.0, 3.0)])
+def test_attention_strided_qkv_and_online_softmax_rescale(attn_variant, gain, q_gain):
     """q/k/v interleaved in one [L, 3d] buffer (the engine's layout) and a key whose score dwarfs all
-    earlier tiles, forcing the reference to move late in the loop.  gain 6: ~2^98 above the rest (attention_v5: the
-    row-sum check moves the reference); gain 40: ~2^650, the exponentials overflow and the workgroup of query 7 starts
-    over in the exact-maximum loop (tools/gen_attention_v5.py, cfg lazy)"""
+    earlier tiles, forcing the reference to move late in the loop.  q_gain 1: ~2^98 above the rest (attention_v5: the
+    row-sum check moves the reference); q_gain 3 (query 7 three times longer): ~2^290, the exponentials overflow and the
+    workgroup of query 7 starts over in the exact-maximum loop (tools/gen_attention_v5.py, cfg lazy).  (Scaling the KEY
+    further instead would put every query at |score| ~ 100 nats, where the bf16 rounding of the pre-scaled Q moves the
+    probabilities by tens of percent in any bf16 kernel.)"""
     L, heads = 512, 2
     d = heads * 128
     qkv = rnd(L, 3 * d, seed=5, dtype=torch.bfloat16)
     qkv[400, d:2 * d] = qkv[7, 0:d] * gain      # key 400 aligned with query 7
+    qkv[7, 0:d] *= q_gain
     o = torch.zeros(L, d, dtype=torch.bfloat16, device=DEV)
     H.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, heads, L, L - 3, 1, 1 / math.sqrt(128))
     want = attn_ref(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], heads, torch.arange(L - 3, device=DEV))

@@ -64,6 +64,11 @@ DEFAULT_CFG = {
                              # non-finite or >= 2^120 (a score more than ~2^67 above everything before it) starts
                              # over in the exact-maximum loop ("safe" mode, the lazy=0 stream)
     "lthr": 60,
+    "pipe": 1,               # (lazy loop, 32x32x16) the softmax finish of tile t is spread over phase 2 of iteration t-1 (key
+                             # steps 0, 1) and phase 1 of iteration t (key steps 2, 3): ONE exponential per MFMA gap, no P-word
+                             # deadline; gap contents follow the measured table of tools/gen_ubench_gap2.py
+    "v_lds": 1, "v_free": 4, # VALU consumers beside the exponential in a gap with / without an LDS read or LDS-DMA
+    "v_lds2": 2,             # ... in phase 2 (more LDS reads than gaps to spare)
     "hoist": 1,              # the rescale decision's VALU part rides behind the lane maxima of the previous iteration
     "exp_gap": 3,            # instructions (MFMAs included) between two v_exp_f32 at least
     "exp_lat": 3,            # ... between an exponential and the first instruction that reads it
@@ -298,6 +303,34 @@ class Finish:
     def __bool__(self):
         return bool(self.exq or self.restq)
 
+    def pop_exp(self):
+        """an exponential, if one is left and the transcendental unit has had its distance"""
+        if self.exq and self.E.n - self.last_exp >= self.gap:
+            t = self.exq.pop(0)
+            self.issued_at.append(self.E.n)
+            self.last_exp = self.E.n
+            self.n_exp += 1
+            return t
+        return None
+
+    def pop_rest(self):
+        if self.restq:
+            t, need = self.restq[0]
+            if need < self.n_exp and self.E.n - self.issued_at[need] >= self.lat:
+                self.restq.pop(0)
+                return t
+        return None
+
+    def drain(self):
+        """everything that is left, in a legal order (end of a phase)"""
+        E = self.E
+        while self:
+            t = self.pop_exp() or self.pop_rest()
+            if t is None:
+                E.i("s_nop 0")
+                continue
+            E.i(t)
+
     def peek(self):
         E = self.E
         if self.exq and E.n - self.last_exp >= self.gap:
@@ -441,6 +474,16 @@ def vfrag_reads(E, f, off, addr_base=None):
     step, second = (4096, 2048) if M.mfma == 32 else (8192, 4096)
     E.ds(f"ds_read_b64_tr_b16 {v(b, 2)}, {v(addr_base + db)} offset:{off + ks * step}")
     return E.ds(f"ds_read_b64_tr_b16 {v(b + 2, 2)}, {v(addr_base + db)} offset:{off + ks * step + second}")
+
+
+def vfrag_read_half(E, f, h, off, addr_base=None):
+    """one of the two transposing reads of V^T fragment f (pipelined body: one LDS read per MFMA gap)"""
+    M = E.M
+    addr_base = M.V_VOFF if addr_base is None else addr_base
+    ks, db = f // M.NDB, f % M.NDB
+    b = M.V_VF + 4 * (f % M.NVF) + 2 * h
+    step, second = (4096, 2048) if M.mfma == 32 else (8192, 4096)
+    return E.ds(f"ds_read_b64_tr_b16 {v(b, 2)}, {v(addr_base + db)} offset:{off + ks * step + h * second}")
 
 
 def kfrag_read(E, kb, ds, slot):
@@ -715,6 +758,159 @@ def emit_body(E, b, ret):
     tickets, fin = emit_phase1(E, B)
     emit_phase2(E, B.par, tickets, fin, B.v_read_slot * TILE, k_slot=B.k_read_slot)
     E.in_body = False
+
+
+def pipe_groups(M, part):
+    ks = (0, 1) if part == 0 else (2, 3)
+    return [(k, qb) for k in ks for qb in range(M.NQB)]
+
+
+def fill_gap(E, fin, vcap, extra=None):
+    """one exponential (if its distance allows) and up to vcap VALU consumers; `extra`: further VALU (list, consumed)"""
+    t = fin.pop_exp() if fin else None
+    if t:
+        E.i(t)
+    n = 0
+    while n < vcap:
+        t = fin.pop_rest() if fin else None
+        if t is None:
+            break
+        E.i(t)
+        n += 1
+    while extra and n < vcap:
+        E.i(extra.pop(0))
+        n += 1
+
+
+def emit_body_pipe(E, b, ret):
+    """lazy loop, pipelined finish.  At entry: P(t) key steps 0, 1 done (S_cur = buffer par), V^T fragments 0..3 NOT yet read.
+    phase 1: S(t+1) = K(t+1) Q^T || finish of S_cur key steps 2, 3; K(t+2) fragments of d-steps 0..4; LDS-DMA; V^T(t) 0..3
+    boundary: padding mask of S(t+1) (rare), row-sum check -> reference move (rare)
+    phase 2: O += V(t)^T P(t) || finish of S(t+1) key steps 0, 1; V^T fragments 4..15; K(t+2) d-steps 5..7"""
+    cfg, M = E.cfg, E.M
+    assert M.mfma == 32
+    B = Body(cfg, b)
+    cur, nxt = B.par, 1 - B.par
+    E.comment(f"---- pipelined iteration body {b}: S_cur = buffer {cur}")
+    E.in_body = True
+    if b % cfg["barrier_every"] == 0:
+        E.i(f"s_waitcnt vmcnt({8 * max(0, cfg['ahead'] - cfg['barrier_every'])})")
+        E.i("s_barrier")
+    # ---------------- phase 1
+    fin = Finish(E, cur, pipe_groups(M, 1))
+    dma_g = {1 + 2 * j: ("K", j) for j in range(4)}
+    dma_g.update({9 + 2 * j: ("V", j) for j in range(4)})
+    m0_g = {0: "K", 8: "V"}
+    adv_g = {8: "K", 16: "V"}
+    kread_g = {}
+    for ds in range(5):                     # K(t+2) fragments of d-step ds: free once the 4 MFMAs of the d-step are issued
+        kread_g[4 * (ds + 1)] = (0, ds)
+        kread_g[4 * (ds + 1) + 2] = (1, ds)
+    vread_g = {24 + 2 * f + h: (f, h) for f in range(4) for h in range(2)}
+    kt = []
+    tickets = {}
+    g = 0
+    for ds in range(M.NDS):
+        for kb in range(M.NKB):
+            for qb in range(M.NQB):
+                E.i(qk_mfma(M, nxt, ds, qb, kb))
+                lds = False
+                if g in m0_g:
+                    op = m0_g[g]
+                    dst = B.k_dma_slot * TILE if op == "K" else cfg["nst"] * TILE + B.v_dma_slot * TILE
+                    E.i(f"s_add_u32 m0, {s(S_LDSW)}, {dst}")
+                if g in dma_g:
+                    E.i(dma_piece(M, *dma_g[g]))
+                    lds = True
+                if g in adv_g:
+                    emit_seq(E, cursor_advance(E, adv_g[g]))
+                if g in kread_g:
+                    kt.append(kfrag_read(E, kread_g[g][0], kread_g[g][1], B.k_read_slot))
+                    lds = True
+                if g in vread_g:
+                    f, h = vread_g[g]
+                    tk = vfrag_read_half(E, f, h, B.v_read_slot * TILE)
+                    if h:
+                        tickets[f] = tk
+                    lds = True
+                fill_gap(E, fin, cfg["v_lds"] if lds else cfg["v_free"])
+                g += 1
+    fin.drain()
+    for t in decide_valu(M, True):
+        E.i(t)
+    # ---------------- boundary: S(t+1) complete, P(t) complete, PV(t) not started
+    E.i(f"s_sub_u32 {s(S_MASKCNT)}, {s(S_MASKCNT)}, 1")
+    E.i(f"s_cbranch_scc1 L_masktop{ret}")
+    E.label(f"L_maskback{ret}")
+    E.masktops.append((ret, nxt))
+    E.i(f"s_mov_b32 {s(S_RET)}, {ret}")
+    E.i(f"s_cbranch_vccnz L_lzrescale{cur}")
+    E.label(f"L_back{ret}")
+    # ---------------- phase 2
+    fin = Finish(E, nxt, pipe_groups(M, 0))
+    kread2 = [(kb, ds) for ds in range(5, M.NDS) for kb in range(M.NKB)]
+    nfr = M.NKS * M.NDB
+    wg = cfg["wait_group"]
+    g = 0
+    for ks in range(M.NKS):
+        for db in range(M.NDB):
+            f = ks * M.NDB + db
+            for qb in range(M.NQB):
+                if qb == 0:
+                    want = max(tickets[x] for x in range(f, min(nfr, f - f % wg + wg)) if x in tickets)
+                    E.wait_lds(want)
+                o = a(A_O + (qb * M.NDB + db) * M.ACC, M.ACC)
+                E.i(f"{M.mn} {o}, {v(M.V_VF + 4 * (f % M.NVF), 4)}, {v(M.P(cur, qb, ks), 4)}, {o}")
+                lds = False
+                if f + 4 < nfr:
+                    tk = vfrag_read_half(E, f + 4, qb, B.v_read_slot * TILE)
+                    if qb:
+                        tickets[f + 4] = tk
+                    lds = True
+                elif kread2:
+                    kb_, ds_ = kread2.pop(0)
+                    kt.append(kfrag_read(E, kb_, ds_, B.k_read_slot))
+                    lds = True
+                fill_gap(E, fin, cfg["v_lds2"] if lds else cfg["v_free"])
+                g += 1
+    while kread2:
+        kb_, ds_ = kread2.pop(0)
+        kt.append(kfrag_read(E, kb_, ds_, B.k_read_slot))
+    fin.drain()
+    E.wait_lds(kt[-1])
+    E.in_body = False
+
+
+def emit_pipe_entry(E):
+    """first half of the finish of tile 0 (key steps 0, 1 of buffer 0), unpipelined (once per workgroup)"""
+    fin = Finish(E, 0, pipe_groups(E.M, 0))
+    fin.drain()
+
+
+def emit_last_pipe(E, par):
+    """last tile, pipelined flavour: key steps 0, 1 of P are done, the padding mask (if any) was applied before them"""
+    M = E.M
+    E.comment(f"---- last tile (pipelined finish), S_cur = buffer {par}")
+    E.i("s_waitcnt vmcnt(0)")
+    E.i("s_barrier")
+    va = M.V_VF + 4 * (M.NVF - 2)
+    for db in range(M.NDB):
+        E.i(f"v_add_u32 {v(va + db)}, {s(S_VSLOT)}, {v(M.V_VOFF + db)}")
+    fin = Finish(E, par, pipe_groups(M, 1))
+    fin.drain()
+    E.i("s_nop 1")
+    nfr = M.NKS * M.NDB
+    for f in range(nfr):
+        ks, db = f // M.NDB, f % M.NDB
+        step, second = 4096, 2048
+        b = M.V_VF
+        E.ds(f"ds_read_b64_tr_b16 {v(b, 2)}, {v(va + db)} offset:{ks * step}")
+        t = E.ds(f"ds_read_b64_tr_b16 {v(b + 2, 2)}, {v(va + db)} offset:{ks * step + second}")
+        E.wait_lds(t)
+        for qb in range(M.NQB):
+            o = a(A_O + (qb * M.NDB + db) * M.ACC, M.ACC)
+            E.i(f"{M.mn} {o}, {v(b, 4)}, {v(M.P(par, qb, ks), 4)}, {o}")
+        E.i("s_nop 7")
 
 
 def emit_mask_tail(E, par, rowmax=True):
