@@ -192,6 +192,9 @@ class Machine:
             return np.uint32(op[1])
         if op[0] == "special" and op[1] == "m0":
             return np.uint32(w.m0)
+        if op[0] == "special" and op[1] == "vcc":
+            bits = w.vcc[32 * idx:32 * idx + 32]
+            return np.uint32(sum(int(b) << i for i, b in enumerate(bits)))
         raise RuntimeError(f"cannot scalar-read {op}")
 
     def wr(self, w, op, val, idx=0):

@@ -69,6 +69,7 @@ DEFAULT_CFG = {
                              # deadline; gap contents follow the measured table of tools/gen_ubench_gap2.py
     "v_lds": 1, "v_free": 4, # VALU consumers beside the exponential in a gap with / without an LDS read or LDS-DMA
     "v_lds2": 2,             # ... in phase 2 (more LDS reads than gaps to spare)
+    "v_dma": 1,              # ... beside an LDS-DMA piece (3: +3 % cycles, and the 10-instruction drain at the end of phase 1 is cheaper)
     "hoist": 1,              # the rescale decision's VALU part rides behind the lane maxima of the previous iteration
     "exp_gap": 3,            # instructions (MFMAs included) between two v_exp_f32 at least
     "exp_lat": 3,            # ... between an exponential and the first instruction that reads it
@@ -176,6 +177,7 @@ class Emitter:
         self.masktops = []        # (ret id, S buffer) of the loop-top mask paths
         self.ool = []             # out-of-line blocks (shard wraps) to emit behind the main code
         self.lazy = False         # this region's loop runs on the lazy reference
+        self.pipe = False         # ... with the pipelined finish
 
     ABL = {"exp": ("v_exp_f32",), "add": ("v_add_f32", "v_pk_add_f32", "v_dot2c_f32_bf16"), "cvt": ("v_cvt_pk_bf16_f32",),
            "max": ("v_max3_f32",), "lds": ("ds_read_b128", "ds_read_b64_tr_b16"), "dma": ("buffer_load_dwordx4",),
@@ -711,13 +713,30 @@ def emit_rescale_routine(E, par, n_ret, lazy=False):
             E.i(f"v_exp_f32 {v(al)}, -{v(d)}")
             E.i(f"v_sub_f32 {v(M.V_MX + qb)}, {v(M.V_MX + qb)}, {v(d)}")
     E.i("s_nop 0")
+    pipe = lazy and E.pipe
     for qb in range(M.NQB):
         d, al = M.V_D + qb, M.V_ALPHA + qb
         E.i(f"v_mul_f32 {v(M.V_L + 2 * qb)}, {v(M.V_L + 2 * qb)}, {v(al)}")
         E.i(f"v_mul_f32 {v(M.V_L + 2 * qb + 1)}, {v(M.V_L + 2 * qb + 1)}, {v(al)}")
-        for r in range(M.QBS):
-            x = M.S(par, qb, 0) + r
-            E.i(f"v_sub_f32 {v(x)}, {v(x)}, {v(d)}")
+        if pipe:
+            # phase boundary of the pipelined body: `par` = S_cur holds the FINISHED tile (packed P words, not yet
+            # multiplied into O: they scale with it), the other buffer the raw scores of the next tile
+            for r in range(M.QBS):
+                x = M.S(1 - par, qb, 0) + r
+                E.i(f"v_sub_f32 {v(x)}, {v(x)}, {v(d)}")
+            lo, hi = M.V_T + 4, M.V_T + 5
+            for ks in range(M.NKS):
+                for w in range(4):
+                    x = M.P(par, qb, ks) + w
+                    E.i(f"v_lshlrev_b32 {v(lo)}, 16, {v(x)}")
+                    E.i(f"v_and_b32 {v(hi)}, 0xffff0000, {v(x)}")
+                    E.i(f"v_mul_f32 {v(lo)}, {v(lo)}, {v(al)}")
+                    E.i(f"v_mul_f32 {v(hi)}, {v(hi)}, {v(al)}")
+                    E.i(f"v_cvt_pk_bf16_f32 {v(x)}, {v(lo)}, {v(hi)}")
+        else:
+            for r in range(M.QBS):
+                x = M.S(par, qb, 0) + r
+                E.i(f"v_sub_f32 {v(x)}, {v(x)}, {v(d)}")
         for r in range(M.ACC):
             E.i(f"v_sub_f32 {v(M.V_CI + M.ACC * qb + r)}, {v(M.V_CI + M.ACC * qb + r)}, {v(d)}")
         no = M.NDB * M.ACC                 # O registers of this query block
@@ -798,14 +817,14 @@ def emit_body_pipe(E, b, ret):
         E.i("s_barrier")
     # ---------------- phase 1
     fin = Finish(E, cur, pipe_groups(M, 1))
-    dma_g = {1 + 2 * j: ("K", j) for j in range(4)}
-    dma_g.update({9 + 2 * j: ("V", j) for j in range(4)})
-    m0_g = {0: "K", 8: "V"}
-    adv_g = {8: "K", 16: "V"}
+    dma_g = {2 + 2 * j: ("K", j) for j in range(4)}
+    dma_g.update({10 + 2 * j: ("V", j) for j in range(4)})
+    m0_g = {1: "K", 9: "V"}
+    adv_g = {9: "K", 17: "V"}
     kread_g = {}
     for ds in range(5):                     # K(t+2) fragments of d-step ds: free once the 4 MFMAs of the d-step are issued
-        kread_g[4 * (ds + 1)] = (0, ds)
-        kread_g[4 * (ds + 1) + 2] = (1, ds)
+        kread_g[4 * (ds + 1) + 1] = (0, ds)
+        kread_g[4 * (ds + 1) + 3] = (1, ds)
     vread_g = {24 + 2 * f + h: (f, h) for f in range(4) for h in range(2)}
     kt = []
     tickets = {}
@@ -815,13 +834,14 @@ def emit_body_pipe(E, b, ret):
             for qb in range(M.NQB):
                 E.i(qk_mfma(M, nxt, ds, qb, kb))
                 lds = False
+                vcap = cfg["v_free"]
                 if g in m0_g:
                     op = m0_g[g]
                     dst = B.k_dma_slot * TILE if op == "K" else cfg["nst"] * TILE + B.v_dma_slot * TILE
                     E.i(f"s_add_u32 m0, {s(S_LDSW)}, {dst}")
                 if g in dma_g:
                     E.i(dma_piece(M, *dma_g[g]))
-                    lds = True
+                    vcap = cfg["v_dma"]
                 if g in adv_g:
                     emit_seq(E, cursor_advance(E, adv_g[g]))
                 if g in kread_g:
@@ -833,7 +853,7 @@ def emit_body_pipe(E, b, ret):
                     if h:
                         tickets[f] = tk
                     lds = True
-                fill_gap(E, fin, cfg["v_lds"] if lds else cfg["v_free"])
+                fill_gap(E, fin, cfg["v_lds"] if lds else vcap)
                 g += 1
     fin.drain()
     for t in decide_valu(M, True):
@@ -850,7 +870,7 @@ def emit_body_pipe(E, b, ret):
     fin = Finish(E, nxt, pipe_groups(M, 0))
     kread2 = [(kb, ds) for ds in range(5, M.NDS) for kb in range(M.NKB)]
     nfr = M.NKS * M.NDB
-    wg = cfg["wait_group"]
+    wg = 2                                  # a fragment pair per wait: the younger one was read three MFMA pairs ago
     g = 0
     for ks in range(M.NKS):
         for db in range(M.NDB):
@@ -1272,6 +1292,14 @@ def emit_masktops(E):
     """loop-top rare path: S_cur is the last tile of a key shard and has padding keys"""
     for ret, par in E.masktops:
         E.label(f"L_masktop{ret}")
+        if E.pipe:
+            E.i("s_nop 15")       # the scores were written by the MFMAs just before
+            E.i(f"s_mov_b64 {s(S_T + 1, 2)}, vcc")                 # the row-sum decision rides in vcc
+            emit_mask_tail(E, par, rowmax=False)
+            E.i(f"s_mov_b64 vcc, {s(S_T + 1, 2)}")
+            E.i(f"s_sub_u32 {s(S_MASKCNT)}, {s(S_TPS)}, 1")
+            E.i(f"s_branch L_maskback{ret}")
+            continue
         emit_mask_tail(E, par, rowmax=not E.lazy)
         if E.cfg["hoist"]:
             for t in decide_valu(E.M, bool(E.lazy)):
@@ -1300,11 +1328,23 @@ def emit_region(E, U, n_ret, exit_label):
     E.i(f"s_mov_b32 {s(S_RET)}, 0")
     E.i("s_branch L_rescale0")
     E.label("L_back0")
+    if E.pipe:
+        # the boundary of iteration t masks tile t+1: the counter runs one tile ahead of the exact loop's
+        E.i(f"s_cmp_ge_u32 {s(S_TAIL)}, 64")
+        E.i("s_cbranch_scc1 L_pipe_nomask")
+        E.i(f"s_sub_u32 {s(S_MASKCNT)}, {s(S_TPS)}, 2")
+        E.i(f"s_cmp_lt_u32 {s(S_TPS)}, 2")
+        E.i(f"s_cselect_b32 {s(S_MASKCNT)}, 0, {s(S_MASKCNT)}")
+        E.label("L_pipe_nomask")
+        emit_pipe_entry(E)
     E.label("L_loop")
     for b in range(U):
         E.i(f"s_sub_u32 {s(S_IT)}, {s(S_IT)}, 1")        # borrow <=> no pipelined iteration left
         E.i(f"s_cbranch_scc1 L_exit{b}")
-        emit_body(E, b, 1 + b)
+        if E.pipe:
+            emit_body_pipe(E, b, 1 + b)
+        else:
+            emit_body(E, b, 1 + b)
     E.i("s_branch L_loop")
     for b in range(U):
         E.label(f"L_exit{b}")
@@ -1312,7 +1352,10 @@ def emit_region(E, U, n_ret, exit_label):
         E.i(f"s_branch L_last{b % 2}")
     for par in range(2):
         E.label(f"L_last{par}")
-        emit_last(E, par, U + 1 + par)
+        if E.pipe:
+            emit_last_pipe(E, par)
+        else:
+            emit_last(E, par, U + 1 + par)
         E.i(f"s_branch {exit_label}")
     inline = E.lines
     E.lines = []
@@ -1391,6 +1434,7 @@ def generate(cfg=None):
         out.append("  s_cbranch_scc1 L_safe_entry")
         Z = copy.deepcopy(E)
         Z.lazy = True
+        Z.pipe = bool(cfg["pipe"]) and cfg["mfma"] == 32
         inl, ool = emit_region(Z, U, n_ret, "L_vote")
         both = rename_labels(inl + ["@@"] + ool, "_z", shared)
         k = both.index("@@")
