@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagcache_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_big.hip", "gemm_fp8_big.hip", "gemm_mxfp8.hip", "attention_v3.hip", "attention_v5.hip", "elementwise.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_big.hip", "gemm_bf16_v2.hip", "gemm_fp8_big.hip", "gemm_mxfp8.hip", "attention_v3.hip", "attention_v5.hip", "elementwise.hip",
            "magcache_ops.hip", "engine.cpp", "mmdit_engine.cpp", "rule.cpp"]
 # the attention kernel's hand-interleaved VALU stream must stay scalar: the SLP vectoriser packs the row-sum
 # adds into v_pk_add_f32 and moves them out of the MFMA shadow
@@ -28,7 +28,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, h) for h in ("common.h", "ops.h", "gemm_epilogue.h", "attention_v5_body.inc",
-                                               "attention_v5_clobbers.inc", "attention_v5_config.h")]
+                                               "attention_v5_clobbers.inc", "attention_v5_config.h", "gemm_v2_body.inc",
+                                               "gemm_v2_clobbers.inc", "gemm_v2_config.h")]
     headers.append(os.path.join(HERE, "..", "include", "magcache_hip.h"))
     headers.append(os.path.join(HERE, "..", "include", "magcache_mmdit.h"))
     objdir = os.path.join(CSRC, "build")

@@ -1378,8 +1378,8 @@ mc_status mc_set_option(const char* key, int value) {
 #else
     const int gemm_max = 2;
 #endif
-    if (value < 0 || value > gemm_max)
-      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128) or 2 (256x256)");
+    if ((value < 0 || value > gemm_max) && value != 4)
+      return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 4 (256x256, 4 waves, generated stream)");
     mc::g_gemm_kernel = value;
   } else if (k == "attn_kernel") {
 #ifndef MC_AB_KERNELS

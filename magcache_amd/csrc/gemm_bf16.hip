@@ -245,6 +245,9 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
       big = 1.3 * fill_efficiency(tiles_big, 256) >= fill_efficiency(tiles_small, 512);
     }
   }
+  if (g_gemm_kernel == 4 && gemm_bf16_v2_supported(p) &&
+      (epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE || epi == EPI_F32))
+    return launch_gemm_bf16_v2(p, epi, stream);
 #ifdef MC_AB_KERNELS
   if (g_gemm_kernel == 3 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
       gemm_bf16_big_supported(p))

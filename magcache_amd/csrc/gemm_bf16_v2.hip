@@ -1,0 +1,169 @@
+// 256x256 bf16 MFMA GEMM, generation 2: 4 waves x (128 x 128) wave tiles, ONE wave per SIMD, the main loop one
+// generated asm statement (tools/gen_gemm_v2.py; the header of that file has the design and the measurements behind it).
+//   C[M,N] = A[M,K] * W[N,K]^T  (+ the fused epilogues of gemm_epilogue.h),  N % 256 == 0,  K % 128 == 0, K >= 256.
+// Same call sites as gemm_bf16_big.hip (the Linears of the Wan DiT block at M = 32768 tokens; reference call site
+// MagCache4Wan2.1/magcache_generate.py:297-298).  A third less LDS traffic per FLOP than the 8-wave kernel (32 KiB of fragments
+// per 2.1 MFLOP instead of 24 KiB per 1.05), 256 accumulators in AGPRs, 64 MFMAs per barrier with one LDS read or one
+// LDS-DMA piece per MFMA gap.  Rows of a partial last M tile are fetched as zeros (buffer range check) and not stored.
+#pragma clang diagnostic ignored "-Winline-asm"
+#include "common.h"
+#include <type_traits>
+
+#include "gemm_epilogue.h"
+#include "ops.h"
+
+#ifndef MC_GEMM_V2_BODY
+#define MC_GEMM_V2_BODY "gemm_v2_body.inc"
+#define MC_GEMM_V2_CLOBBERS "gemm_v2_clobbers.inc"
+#define MC_GEMM_V2_CONFIG "gemm_v2_config.h"
+#endif
+#include MC_GEMM_V2_CONFIG   // MC_GEMM_V2_MFMA: 32 (v_mfma_f32_32x32x16_bf16, 4 x 4 accumulator tiles) or 16 (16x16x32, 8 x 8)
+
+namespace mc {
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int V2_LDS_BYTES = 4 * 32768;      // ring of 4 sub-stages (32 k) x (A 16 KiB | W 16 KiB)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // ---- tile mapping: XCD-contiguous, grouped along M (as gemm_bf16_big.hip)
+  const int ntiles = tilesM * tilesN;
+  const int vt = xcd_remap(blockIdx.x, ntiles);
+  const int per_group = GROUP_M * tilesN;
+  const int grp = vt / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tilesM - first_m, GROUP_M);
+  const int in_grp = vt - grp * per_group;
+  const int m0 = (first_m + in_grp % gsz) * TB;
+  const int n0 = (in_grp / gsz) * TB;
+
+  const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
+  const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
+  const uint32_t lda_b = (uint32_t)p.lda * 2, ldw_b = (uint32_t)p.ldw * 2;
+  // bytes reachable from the tile's first element: rows past M / N are out of range and read zeros
+  const uint32_t a_nrec = (uint32_t)min((size_t)(p.M - m0) * lda_b - (size_t)(p.lda - p.K) * 2, (size_t)0xffffff00u);
+  const uint32_t w_nrec = (uint32_t)min((size_t)(p.N - n0) * ldw_b - (size_t)(p.ldw - p.K) * 2, (size_t)0xffffff00u);
+  const int nk = p.K / 32;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)MC_LDS_PTR(smem);
+
+  f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;
+  asm volatile(
+#include MC_GEMM_V2_BODY
+      : "={a[0:15]}"(c0), "={a[16:31]}"(c1), "={a[32:47]}"(c2), "={a[48:63]}"(c3), "={a[64:79]}"(c4), "={a[80:95]}"(c5),
+        "={a[96:111]}"(c6), "={a[112:127]}"(c7), "={a[128:143]}"(c8), "={a[144:159]}"(c9), "={a[160:175]}"(c10),
+        "={a[176:191]}"(c11), "={a[192:207]}"(c12), "={a[208:223]}"(c13), "={a[224:239]}"(c14), "={a[240:255]}"(c15)
+      : "s"(a_tile), "s"(w_tile), "s"(lda_b), "s"(ldw_b), "s"(nk), "s"(wv), "s"(lds0), "s"(a_nrec), "s"(w_nrec)
+      :
+#include MC_GEMM_V2_CLOBBERS
+  );
+  const f32x16 cc[16] = {c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15};
+
+  // ---- epilogue: a wave's 128 x 128 tile as NQ quads of 4 consecutive n for each of NR rows m of the lane
+  //   16x16x32: accumulator (nb, mb, r) = register (8 nb + mb) * 4 + r = C[m][n], m = .. + 16 mb + lane % 16,
+  //             n = .. + 16 nb + 4 (lane / 16) + r                                  -> rows mb 0..7, quads nb 0..7
+  //   32x32x16: accumulator (nb, mb, r) = register (4 nb + mb) * 16 + r,            m = .. + 32 mb + lane % 32,
+  //             n = .. + 32 nb + 8 (r / 4) + 4 (lane / 32) + r % 4                  -> rows mb 0..3, quads (nb, r / 4) 0..15
+  const int wr = wv >> 1, wc = wv & 1;
+#if MC_GEMM_V2_MFMA == 16
+  constexpr int NR = 8, NQ = 8;
+  const int mrow = lane & 15, ncol = 4 * (lane >> 4);
+  auto m_of = [&](int ri) { return m0 + wr * 128 + ri * 16 + mrow; };
+  auto n_of = [&](int qi) { return n0 + wc * 128 + qi * 16 + ncol; };
+  auto quad = [&](int ri, int qi) {
+    const f32x16& t = cc[(qi * 8 + ri) >> 2];
+    const int e = ((qi * 8 + ri) & 3) * 4;
+    return f32x4{t[e], t[e + 1], t[e + 2], t[e + 3]};
+  };
+#else
+  constexpr int NR = 4, NQ = 16;
+  const int mrow = lane & 31, ncol = 4 * (lane >> 5);
+  auto m_of = [&](int ri) { return m0 + wr * 128 + ri * 32 + mrow; };
+  auto n_of = [&](int qi) { return n0 + wc * 128 + (qi >> 2) * 32 + 8 * (qi & 3) + ncol; };
+  auto quad = [&](int ri, int qi) {
+    const f32x16& t = cc[(qi >> 2) * 4 + ri];
+    const int e = (qi & 3) * 4;
+    return f32x4{t[e], t[e + 1], t[e + 2], t[e + 3]};
+  };
+#endif
+  if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
+    // two-phase residual epilogue (gemm_epilogue.h): 8 quads are loaded together, then added and stored
+    auto resid = [&](auto with_sel) {
+      constexpr bool SEL = decltype(with_sel)::value;
+#pragma unroll
+      for (int ri = 0; ri < NR; ++ri) {
+        const int m = m_of(ri);
+        const int ml = min(m, p.M - 1);
+        const float* gp = (SEL && p.gate_sel[ml]) ? p.gate2 : p.gate;
+#pragma unroll
+        for (int q0 = 0; q0 < NQ; q0 += 8) {
+          ResidIn in[8];
+          f32x4 gt[8], bv[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int n = n_of(q0 + k);
+            in[k] = resid_load<EPI>(p, ml, n);
+            gt[k] = p.gate ? *(const f32x4*)(gp + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+            bv[k] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          if (m < p.M) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) resid_apply<EPI>(p, m, n_of(q0 + k), quad(ri, q0 + k) + bv[k], gt[k], in[k]);
+          }
+        }
+      }
+    };
+    if (p.gate_sel) resid(std::true_type{});
+    else resid(std::false_type{});
+  } else {
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+      const int m = m_of(ri);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        const int n = n_of(qi);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b = *(const f32x4*)(p.bias + n);
+        gemm_epilogue_quad<EPI>(p, m, n, quad(ri, qi) + b);
+      }
+    }
+  }
+}
+
+template <int EPI>
+hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream) {
+  const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
+  static std::atomic<uint64_t> lds_ready{0};
+  if (hipError_t e = ensure_dynamic_lds((const void*)gemm_v2_kernel<EPI>, V2_LDS_BYTES, lds_ready); e != hipSuccess) return e;
+  hipLaunchKernelGGL((gemm_v2_kernel<EPI>), dim3(tilesM * tilesN), dim3(256), V2_LDS_BYTES, stream, p, tilesM, tilesN,
+                     tilesN >= 32 ? 4 : 8);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm_bf16_v2_supported(const GemmParams& p) {
+  return p.M > 0 && p.N > 0 && (p.N % TB) == 0 && (p.K % 128) == 0 && p.K >= 256 && (p.lda % 8) == 0 && (p.ldw % 8) == 0 &&
+         (size_t)p.M * (size_t)p.lda < (1ull << 31) && (size_t)p.N * (size_t)p.ldw < (1ull << 31);
+}
+
+hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream) {
+  if (!gemm_bf16_v2_supported(p)) return hipErrorInvalidValue;
+  switch (epi) {
+    case EPI_BF16: return launch_v2_t<EPI_BF16>(p, stream);
+    case EPI_GELU_BF16: return launch_v2_t<EPI_GELU_BF16>(p, stream);
+    case EPI_RESID_GATE: return launch_v2_t<EPI_RESID_GATE>(p, stream);
+    case EPI_RESID_CAPTURE: return launch_v2_t<EPI_RESID_CAPTURE>(p, stream);
+    case EPI_F32: return launch_v2_t<EPI_F32>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mc

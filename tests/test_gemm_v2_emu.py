@@ -1,0 +1,92 @@
+"""The generated main loop of csrc/gemm_bf16_v2.hip (tools/gen_gemm_v2.py) on the functional wave emulator tools/gcn_emu.py:
+one workgroup (4 waves x 128 x 128) against an fp64 product of the same bf16 inputs, with LDS-DMA and LDS reads completing
+either at issue or only at the covering wait (a missing wait / a ring-slot race shows as poison or stale data).  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import gcn_emu as emu  # noqa: E402
+import gen_gemm_v2 as gen  # noqa: E402
+
+IN_BASE = 128
+
+
+def _bind(text):
+    pairs = {0, 1}
+    for k in range(gen.N_INPUTS - 1, -1, -1):
+        r = IN_BASE + 2 * k
+        text = text.replace(f"%{gen.IN0 + k}", f"s[{r}:{r + 1}]" if k in pairs else f"s{r}")
+    return text
+
+
+def run_tile(m_valid, K, lda_pad=0, seed=0, dma_late=False, load_late=False, mfma=32):
+    gen.MFMA = mfma
+    rng = np.random.default_rng(seed)
+    lda = K + lda_pad
+    A = emu.bf16_to_f32(emu.bf16_rne(rng.standard_normal((m_valid, lda)).astype(np.float32)))
+    W = emu.bf16_to_f32(emu.bf16_rne(rng.standard_normal((256, lda)).astype(np.float32)))
+    a_bits = emu.bf16_rne(A).astype(np.uint16)
+    w_bits = emu.bf16_rne(W).astype(np.uint16)
+    AB, WB = 0x1000_0000, 0x2000_0000
+    m = emu.Machine(_bind(gen.generate()) + "  s_endpgm\n", n_waves=4, lds_bytes=4 * gen.SUB, dma_late=dma_late, load_late=load_late)
+    m.add_buffer(AB, a_bits)
+    m.add_buffer(WB, w_bits)
+    a_nrec = m_valid * lda * 2 - lda_pad * 2
+    w_nrec = 256 * lda * 2 - lda_pad * 2
+    vals = [AB, WB, lda * 2, lda * 2, K // 32, None, 0, a_nrec, w_nrec]
+    for w in m.waves:
+        for k, val in enumerate(vals):
+            r = IN_BASE + 2 * k
+            val = w.wid if val is None else val
+            w.s[r] = np.uint32(val & 0xFFFFFFFF)
+            w.s[r + 1] = np.uint32((val >> 32) & 0xFFFFFFFF)
+    m.run()
+    got = np.zeros((256, 256), dtype=np.float32)          # [m][n]
+    lanes = np.arange(64)
+    for w in m.waves:
+        wr, wc = w.wid >> 1, w.wid & 1
+        if gen.MFMA == 16:
+            for nb in range(8):
+                for mb in range(8):
+                    for r in range(4):
+                        vals_ = emu.f32(w.a[gen.acc(nb, mb) + r])
+                        got[wr * 128 + mb * 16 + (lanes & 15), wc * 128 + nb * 16 + 4 * (lanes >> 4) + r] = vals_
+        else:
+            for nb in range(4):
+                for mb in range(4):
+                    for r in range(16):
+                        vals_ = emu.f32(w.a[gen.acc(nb, mb) + r])
+                        n = wc * 128 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lanes >> 5)
+                        got[wr * 128 + mb * 32 + (lanes & 31), n] = vals_
+    want = np.zeros((256, 256))
+    want[:m_valid] = A[:, :K].astype(np.float64) @ W[:, :K].astype(np.float64).T
+    return got, want
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("m_valid,K,lda_pad", [(256, 256, 0), (200, 384, 0), (256, 256, 64), (37, 512, 8)])
+def test_gemm_v2_stream_matches_fp64(m_valid, K, lda_pad, mfma):
+    got, want = run_tile(m_valid, K, lda_pad, mfma=mfma)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
+    assert (got[m_valid:] == 0).all()                     # rows past M: fetched as zeros
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("dma_late,load_late", [(True, False), (False, True), (True, True)])
+def test_gemm_v2_stream_is_race_free_under_late_completion(dma_late, load_late, mfma):
+    got, want = run_tile(256, 384, 0, seed=3, dma_late=dma_late, load_late=load_late, mfma=mfma)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
+
+
+def test_gemm_v2_inc_file_is_current():
+    cfg = open(os.path.join(ROOT, "magcache_amd", "csrc", "gemm_v2_config.h")).read()
+    gen.MFMA = 32 if "MC_GEMM_V2_MFMA 32" in cfg else 16
+    inc = os.path.join(ROOT, "magcache_amd", "csrc", "gemm_v2_body.inc")
+    assert open(inc).read() == gen.to_inc(gen.generate()), "regenerate with: python tools/gen_gemm_v2.py --write"

@@ -28,11 +28,12 @@ def rel_l2(a, b):
     return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20))
 
 
-@pytest.fixture(params=[1, 2, 0], ids=["gemm-128", "gemm-256", "gemm-by-shape"])
+@pytest.fixture(params=[1, 2, 4, 0], ids=["gemm-128", "gemm-256", "gemm-256-v2", "gemm-by-shape"])
 def kernel_variant(request):
     """Every GEMM test (and the attention tests, whose inputs come out of GEMMs in the engine) runs with the 128x128
-    kernel forced, with the 256x256 counted-vmcnt kernel forced wherever the shape allows, and with the shipped
-    by-shape dispatch.  One attention kernel is shipped (attention_v3.hip); the retired generations are A/B tooling
+    kernel forced, with the 256x256 counted-vmcnt kernel forced wherever the shape allows, with the generation-2
+    256x256 kernel (4 waves, generated stream, gemm_bf16_v2.hip) forced wherever ITS shape rules allow, and with the
+    shipped by-shape dispatch.  One attention kernel is shipped (attention_v3.hip); the retired generations are A/B tooling
     (tools/kernels_ab/, tools/build_ab_lib.py)."""
     lib = _lib.load()
     _lib.check(lib.mc_set_option(b"gemm_kernel", request.param))

@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Generator of the instruction stream of csrc/gemm_bf16_v2.hip: C[M,N] = A[M,K] W[N,K]^T, bf16 in, fp32 accumulators.
+
+Why a second big-tile GEMM (round 3, after attention_v5): gemm_bf16_big.hip runs 8 waves x (128 x 64) wave tiles, two waves
+per SIMD, compiler-scheduled around pinned asm; every K step each wave reads 24 KiB of fragments for 1.05 MFLOP.  hipBLASLt's
+kernel for the same shapes uses 4 waves x (128 x 128) wave tiles (256 accumulators): 32 KiB for 2.1 MFLOP, a third less LDS
+traffic per FLOP, and is 8-13 % faster at the power limit.  Round 2's attempt at that shape with compiler scheduling lost
+to the one-wave-per-SIMD issue problems that tools/ubench_gap2 has since mapped (profiles/r03/NOTES.md 10): a wave ALONE on
+a SIMD sustains the MFMA rate only if its stream is written in issue order with explicit registers, and an MFMA gap takes one
+LDS read or one LDS-DMA piece for free.  This stream is built to those rules.
+
+Shape.  Workgroup = 4 waves (2 x 2), one per SIMD, output tile 256 (M) x 256 (N); wave tile 128 x 128 = 8 x 8 accumulator
+tiles of v_mfma_f32_16x16x32_bf16 in a0..a255 (swapped operands: src0 = W rows, src1 = A rows, so a lane owns 4 consecutive n
+of one row m: 16-byte epilogue accesses).  K advances in sub-stages of 32 (one MFMA k-step): 64 MFMAs per wave and sub-stage.
+LDS: ring of 4 sub-stages x (A 256 rows + W 256 rows) x 64 B = 128 KiB, rows swizzled chunk ^= (row >> 2) & 3 on the
+LDS-DMA source side (ds_read_b128 of 16 rows x 16 B then hits 64 distinct banks).
+Pipeline of sub-stage s:  s_waitcnt vmcnt(16) + s_barrier (sub-stage s+1 has landed for every wave, every wave is done with
+the fragments of s) | 64 MFMAs on the fragments of s (registers, read during s-1) with, one per gap: the 16 ds_read_b128 of
+the fragments of s+1 (other register buffer), the 8 buffer_load ... lds pieces of sub-stage s+4 into ring slot s % 4 (its
+rows were read into registers during s-1), their M0 writes.  Lead of the LDS-DMA: 4 sub-stages = 256 MFMAs (~2 us).
+The accumulators leave the asm statement as 16 x 16-register AGPR tuples ("={a[0:15]}" ...) for the C++ epilogues of
+gemm_epilogue.h.  Validated on tools/gcn_emu.py (tests/test_gemm_v2_emu.py) before the GPU."""
+import argparse
+import os
+import re
+import sys
+
+SUB = 32768                  # one ring slot: A 16 KiB | W 16 KiB
+NSLOT = 4
+# SGPRs owned by the block
+S_A, S_W = 20, 22            # tile base pointers (64 bit)
+S_LDA, S_LDW = 24, 25        # row strides in bytes
+S_NK, S_WV, S_LDS = 26, 27, 28
+S_ANREC, S_WNREC = 29, 30
+S_ASRD, S_WSRD = 32, 36      # buffer descriptors
+S_DCUR = 40                  # byte offset (k) of the sub-stage the LDS-DMA is fetching
+S_IT = 41
+S_LDSW = 42                  # LDS address of this wave's 4 KiB inside the A part of slot 0
+S_T = 44
+S_LAST = 50
+N_INPUTS = 9
+IN0 = 16                     # the asm statement's operands 0..15 are the accumulator outputs
+
+V_FR = 0                     # fragment buffers: [p][A | W][8 fragments] x 4 registers = v0..v127
+V_BA, V_BW = 128, 132        # fragment read bases: [operand][k-step 0 | 1 (32x32x16 only)][slots 0-1 | slots 2-3]
+V_SA, V_SW = 136, 140        # LDS-DMA source offsets of this wave's 4 pieces per operand
+V_T = 144
+V_LANE = 154
+
+MFMA = 16                    # 16: v_mfma_f32_16x16x32_bf16 (8 x 8 tiles, 64 MFMAs of 16 cycles per sub-stage): 1083 TF on the QKV shape
+                             # 32: v_mfma_f32_32x32x16_bf16 (4 x 4 tiles x 2 k-steps, 32 MFMAs of 32 cycles): 920 TF
+                             # against 1150-1260 TF for gemm_bf16_big.hip on the same boxes (profiles/r03/kbench_gemm_v2_*.log).
+                             # Both: matrix pipe ~45 % busy, waves 53 % "waiting to issue": the time per sub-stage
+                             # (2270 cycles for 32 KiB of operands per CU) is an LDS-DMA feed rate of ~14 B/clk/CU; the
+                             # 8-wave kernel gets ~19 B/clk/CU with 128-byte rows.  See profiles/r03/NOTES.md 14.
+
+
+def v(n, c=1):
+    return f"v{n}" if c == 1 else f"v[{n}:{n + c - 1}]"
+
+
+def a(n, c=1):
+    return f"a{n}" if c == 1 else f"a[{n}:{n + c - 1}]"
+
+
+def s(n, c=1):
+    return f"s{n}" if c == 1 else f"s[{n}:{n + c - 1}]"
+
+
+def frag(p, op, blk, ks=0):
+    """16 x 16 x 32: blk = 16-row block 0..7;  32 x 32 x 16: blk = 32-row block 0..3, ks = k-step of 16"""
+    idx = blk if MFMA == 16 else blk * 2 + ks
+    return V_FR + p * 64 + (0 if op == "A" else 32) + 4 * idx
+
+
+def acc(nb, mb):
+    return (nb * 8 + mb) * 4 if MFMA == 16 else (nb * 4 + mb) * 16
+
+
+class E:
+    def __init__(self):
+        self.lines = []
+
+    def i(self, t):
+        self.lines.append("  " + t)
+
+    def label(self, t):
+        self.lines.append(t + ":")
+
+    def c(self, t):
+        self.lines.append("  ; " + t)
+
+
+def dma_piece(e, op, j, slot):
+    """piece j (16 rows x 64 B) of this wave's 64 rows of operand op, into ring slot `slot`"""
+    src, srd = (V_SA, S_ASRD) if op == "A" else (V_SW, S_WSRD)
+    e.i(f"s_add_u32 m0, {s(S_LDSW)}, {slot * SUB + (0 if op == 'A' else 16384) + j * 1024}")
+    e.i("s_nop 0")
+    e.i(f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(S_DCUR)} offen lds")
+
+
+def frag_read(e, p, op, blk, slot, ks=0):
+    base = (V_BA if op == "A" else V_BW) + 2 * ks + (slot >> 1)
+    off = (slot & 1) * SUB + blk * (1024 if MFMA == 16 else 2048)
+    e.i(f"ds_read_b128 {v(frag(p, op, blk, ks), 4)}, {v(base)} offset:{off}")
+
+
+def all_frags():
+    """(op, blk, ks) of a sub-stage's 16 fragment reads, in the order the MFMAs want them"""
+    if MFMA == 16:
+        return [(op, blk, 0) for blk in range(8) for op in "WA"]
+    return [(op, blk, ks) for ks in range(2) for blk in range(4) for op in "WA"]
+
+
+def emit_prologue(e):
+    e.c("---- inputs -> fixed SGPRs")
+    e.i(f"s_mov_b64 {s(S_A, 2)}, %{IN0 + 0}")
+    e.i(f"s_mov_b64 {s(S_W, 2)}, %{IN0 + 1}")
+    e.i(f"s_mov_b32 {s(S_LDA)}, %{IN0 + 2}")
+    e.i(f"s_mov_b32 {s(S_LDW)}, %{IN0 + 3}")
+    e.i(f"s_mov_b32 {s(S_NK)}, %{IN0 + 4}")
+    e.i(f"s_mov_b32 {s(S_WV)}, %{IN0 + 5}")
+    e.i(f"s_mov_b32 {s(S_LDS)}, %{IN0 + 6}")
+    e.i(f"s_mov_b32 {s(S_ANREC)}, %{IN0 + 7}")
+    e.i(f"s_mov_b32 {s(S_WNREC)}, %{IN0 + 8}")
+    for srd, base, nrec in ((S_ASRD, S_A, S_ANREC), (S_WSRD, S_W, S_WNREC)):
+        e.i(f"s_mov_b32 {s(srd)}, {s(base)}")
+        e.i(f"s_and_b32 {s(srd + 1)}, {s(base + 1)}, 0xffff")
+        e.i(f"s_mov_b32 {s(srd + 2)}, {s(nrec)}")
+        e.i(f"s_mov_b32 {s(srd + 3)}, 0x00020000")
+    t0, t1, t2, l15, g4 = V_T, V_T + 1, V_T + 2, V_T + 3, V_T + 4
+    e.i(f"v_mbcnt_lo_u32_b32 {v(V_LANE)}, -1, 0")
+    e.i(f"v_mbcnt_hi_u32_b32 {v(V_LANE)}, -1, {v(V_LANE)}")
+    e.i(f"v_and_b32 {v(l15)}, 15, {v(V_LANE)}")
+    e.i(f"v_lshrrev_b32 {v(g4)}, 4, {v(V_LANE)}")
+    # fragment read bases.  16x16x32: row = 128 w? + 16 blk + lane % 16, k chunk lane / 16;
+    #                       32x32x16: row = 128 w? + 32 blk + lane % 32, k chunk 2 ks + lane / 32;
+    # 16-byte position = chunk ^ ((row >> 2) & 3)
+    if MFMA == 16:
+        e.i(f"v_lshrrev_b32 {v(t0)}, 2, {v(l15)}")
+        e.i(f"v_xor_b32 {v(t0)}, {v(t0)}, {v(g4)}")
+        e.i(f"v_lshlrev_b32 {v(t0)}, 4, {v(t0)}")
+        e.i(f"v_lshl_add_u32 {v(t0)}, {v(l15)}, 6, {v(t0)}")             # l15 * 64 + pos * 16
+        e.i(f"v_add_u32 {v(t0)}, {s(S_LDS)}, {v(t0)}")
+        e.i(f"v_mov_b32 {v(t1)}, {v(t0)}")
+    else:
+        l31, hf = V_T + 5, V_T + 6
+        e.i(f"v_and_b32 {v(l31)}, 31, {v(V_LANE)}")
+        e.i(f"v_lshrrev_b32 {v(hf)}, 5, {v(V_LANE)}")
+        e.i(f"v_lshrrev_b32 {v(t2)}, 2, {v(l31)}")
+        e.i(f"v_and_b32 {v(t2)}, 3, {v(t2)}")                           # (row >> 2) & 3
+        e.i(f"v_xor_b32 {v(t0)}, {v(t2)}, {v(hf)}")                     # k-step 0: chunk = half
+        e.i(f"v_xor_b32 {v(t1)}, 2, {v(t0)}")                           # k-step 1: chunk = 2 + half = 2 ^ half
+        for t in (t0, t1):
+            e.i(f"v_lshlrev_b32 {v(t)}, 4, {v(t)}")
+            e.i(f"v_lshl_add_u32 {v(t)}, {v(l31)}, 6, {v(t)}")
+            e.i(f"v_add_u32 {v(t)}, {s(S_LDS)}, {v(t)}")
+    e.i(f"s_lshr_b32 {s(S_T)}, {s(S_WV)}, 1")                           # wr
+    e.i(f"s_lshl_b32 {s(S_T)}, {s(S_T)}, 13")                           # wr * 128 rows * 64 B
+    for ks, t in enumerate((t0, t1)):
+        e.i(f"v_add_u32 {v(V_BA + 2 * ks)}, {s(S_T)}, {v(t)}")
+        e.i(f"v_add_u32 {v(V_BA + 2 * ks + 1)}, {2 * SUB}, {v(V_BA + 2 * ks)}")
+    e.i(f"s_and_b32 {s(S_T)}, {s(S_WV)}, 1")                            # wc
+    e.i(f"s_lshl_b32 {s(S_T)}, {s(S_T)}, 13")
+    e.i(f"s_add_u32 {s(S_T)}, {s(S_T)}, 16384")
+    for ks, t in enumerate((t0, t1)):
+        e.i(f"v_add_u32 {v(V_BW + 2 * ks)}, {s(S_T)}, {v(t)}")
+        e.i(f"v_add_u32 {v(V_BW + 2 * ks + 1)}, {2 * SUB}, {v(V_BW + 2 * ks)}")
+    # LDS-DMA sources: piece j = tile rows 64 wv + 16 j + (lane >> 2); slot lane & 3 holds chunk (lane & 3) ^ ((row >> 2) & 3)
+    e.i(f"v_lshrrev_b32 {v(t0)}, 2, {v(V_LANE)}")                       # row in piece (0..15)
+    e.i(f"v_lshrrev_b32 {v(t1)}, 2, {v(t0)}")
+    e.i(f"v_and_b32 {v(t1)}, 3, {v(t1)}")
+    e.i(f"v_and_b32 {v(t2)}, 3, {v(V_LANE)}")
+    e.i(f"v_xor_b32 {v(t1)}, {v(t1)}, {v(t2)}")                         # chunk
+    e.i(f"v_lshlrev_b32 {v(t1)}, 4, {v(t1)}")
+    e.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 6")
+    e.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(t0)}")                        # 64 wv + row
+    for j in range(4):
+        if j:
+            e.i(f"v_add_u32 {v(t0)}, 16, {v(t0)}")
+        e.i(f"v_mul_lo_u32 {v(t2)}, {v(t0)}, {s(S_LDA)}")
+        e.i(f"v_add_u32 {v(V_SA + j)}, {v(t2)}, {v(t1)}")
+        e.i(f"v_mul_lo_u32 {v(t2)}, {v(t0)}, {s(S_LDW)}")
+        e.i(f"v_add_u32 {v(V_SW + j)}, {v(t2)}, {v(t1)}")
+    e.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 12")
+    e.i(f"s_add_u32 {s(S_LDSW)}, {s(S_T)}, {s(S_LDS)}")
+    e.i(f"s_mov_b32 {s(S_DCUR)}, 0")
+    e.c("---- accumulators = 0")
+    for r in range(256):
+        e.i(f"v_accvgpr_write_b32 {a(r)}, 0")
+    e.c("---- sub-stages 0..3 on their way")
+    for st in range(NSLOT):
+        for op in "AW":
+            for j in range(4):
+                dma_piece(e, op, j, st)
+        e.i(f"s_add_u32 {s(S_DCUR)}, {s(S_DCUR)}, 64")
+    e.i("s_waitcnt vmcnt(24)")
+    e.i("s_barrier")
+    for op, blk, ks in all_frags():
+        frag_read(e, 0, op, blk, 0, ks)
+    e.i("s_waitcnt lgkmcnt(0)")
+    e.i(f"s_lshr_b32 {s(S_IT)}, {s(S_NK)}, 2")                          # trips of the 4-body loop
+
+
+def emit_body(e, b):
+    """sub-stage s = 4 trip + b: MFMAs on fragment buffer b & 1 (slot b's rows), reads of s+1, LDS-DMA of s+4 into slot b"""
+    p = b & 1
+    e.c(f"---- sub-stage body {b}")
+    e.i("s_waitcnt vmcnt(16)")
+    e.i("s_barrier")
+    nxt = (b + 1) % NSLOT
+    fillers = [("read",) + f for f in all_frags()]
+    dmas = [("dma", op, j) for op in "AW" for j in range(4)]
+    if MFMA == 16:
+        plan = {2 + 3 * k: f for k, f in enumerate(fillers)}           # gaps 2, 5, .. 47
+        plan.update({4 + 6 * k: d for k, d in enumerate(dmas)})         # gaps 4, 10, .. 46 (never a read's gap)
+        order = [(nb, mb, 0) for nb in range(8) for mb in range(8)]
+    else:
+        # 32 gaps: a read in every even gap, an LDS-DMA piece in gaps 1, 5, 9, .. 29
+        plan = {2 * k: f for k, f in enumerate(fillers)}
+        plan.update({1 + 4 * k: d for k, d in enumerate(dmas)})
+        order = [(nb, mb, ks) for ks in range(2) for nb in range(4) for mb in range(4)]
+    mn = "v_mfma_f32_16x16x32_bf16" if MFMA == 16 else "v_mfma_f32_32x32x16_bf16"
+    n_acc = 4 if MFMA == 16 else 16
+    for g, (nb, mb, ks) in enumerate(order):
+        e.i(f"{mn} {a(acc(nb, mb), n_acc)}, {v(frag(p, 'W', nb, ks), 4)}, {v(frag(p, 'A', mb, ks), 4)}, {a(acc(nb, mb), n_acc)}")
+        f = plan.get(g)
+        if f:
+            if f[0] == "read":
+                frag_read(e, 1 - p, f[1], f[2], nxt, f[3])
+            else:
+                dma_piece(e, f[1], f[2], b)
+    e.i(f"s_add_u32 {s(S_DCUR)}, {s(S_DCUR)}, 64")
+    e.i("s_waitcnt lgkmcnt(0)")
+
+
+def generate():
+    e = E()
+    emit_prologue(e)
+    e.label("L_loop")
+    for b in range(NSLOT):
+        emit_body(e, b)
+    e.i(f"s_sub_u32 {s(S_IT)}, {s(S_IT)}, 1")
+    e.i(f"s_cmp_lg_u32 {s(S_IT)}, 0")
+    e.i("s_cbranch_scc1 L_loop")
+    e.i("s_waitcnt vmcnt(0)")          # the fetches past K (range-checked or unused) must not outlive the workgroup's LDS
+    e.i("s_nop 15")
+    e.i("s_nop 15")
+    return "\n".join(e.lines) + "\n"
+
+
+def to_inc(text):
+    out = ["// GENERATED by tools/gen_gemm_v2.py -- do not edit; regenerate with `python tools/gen_gemm_v2.py --write`"]
+    for ln in text.splitlines():
+        t = ln.split(";")[0].rstrip()
+        if not t.strip():
+            continue
+        t = re.sub(r"\bL_(\w+)", r"L_\1_%=", t)
+        out.append('"' + t.strip() + '\\n\\t"')
+    return "\n".join(out) + "\n"
+
+
+def clobbers():
+    regs = [f"v{i}" for i in range(256)] + [f"s{i}" for i in range(20, S_LAST + 1)] + ["vcc", "scc", "m0", "memory"]
+    out, line = ["// GENERATED by tools/gen_gemm_v2.py: registers owned by the asm block (the AGPRs are its outputs)"], ""
+    for r in regs:
+        tok = f'"{r}", '
+        if len(line) + len(tok) > 116:
+            out.append(line.rstrip())
+            line = ""
+        line += tok
+    out.append(line.rstrip().rstrip(","))
+    return "\n".join(out) + "\n"
+
+
+def main():
+    global MFMA
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--write", action="store_true")
+    ap.add_argument("--asm")
+    ap.add_argument("--mfma", type=int, default=MFMA)
+    args = ap.parse_args()
+    MFMA = args.mfma
+    text = generate()
+    if args.asm:
+        open(args.asm, "w").write(text)
+    if args.write:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        d = os.path.join(root, "magcache_amd", "csrc")
+        open(os.path.join(d, "gemm_v2_body.inc"), "w").write(to_inc(text))
+        open(os.path.join(d, "gemm_v2_clobbers.inc"), "w").write(clobbers())
+        open(os.path.join(d, "gemm_v2_config.h"), "w").write("// GENERATED by tools/gen_gemm_v2.py\n#define MC_GEMM_V2_MFMA %d\n" % MFMA)
+    n = sum(1 for l in text.splitlines() if l.startswith("  ") and not l.strip().startswith(";"))
+    print(f"{n} instructions", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
