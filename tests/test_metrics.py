@@ -1,8 +1,9 @@
 """Host-side quality metrics vs the reference's own functions.  PSNR: the reference file is pure
 numpy, its outputs are committed as golden values (tests/golden/metrics_golden.json, made by
-oracle/gen_golden_metrics.py).  SSIM: the reference needs cv2, which does not exist here -- parity
-unpinned; checked against an independent scipy.ndimage restatement of the same cv2 calls and against
-the metric's identities."""
+oracle/gen_golden_metrics.py).  SSIM: the reference imports cv2 (absent here) for two calls; the golden
+generator executes the reference's OWN calculate_ssim.py with a two-function stand-in for them (the Gaussian
+kernel formula OpenCV documents, and a correlation whose border the reference cuts off) and commits its outputs;
+also checked against an independent scipy.ndimage restatement and against the metric's identities."""
 import json
 import os
 
@@ -41,6 +42,19 @@ def _ssim_scipy(img1, img2):
     mu1, mu2 = f(img1), f(img2)
     s1, s2, s12 = f(img1 ** 2) - mu1 ** 2, f(img2 ** 2) - mu2 ** 2, f(img1 * img2) - mu1 * mu2
     return (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))).mean()
+
+
+def test_ssim_matches_reference_golden(golden_dir):
+    """outputs of the reference's calculate_ssim.py (executed by oracle/gen_golden_metrics.py, cv2 reduced to the two
+    calls it makes) on the seeded videos"""
+    g = json.load(open(os.path.join(golden_dir, "metrics_golden.json")))
+    a, b = _videos(g["seed"], tuple(g["shape"]))
+    got = MT.calculate_ssim(a, b)
+    for t, v in g["ssim_value"].items():
+        assert got["value"][int(t)] == pytest.approx(v, rel=0, abs=1e-12)
+    for t, v in g["ssim_std"].items():
+        assert got["value_std"][int(t)] == pytest.approx(v, rel=0, abs=1e-12)
+    assert MT.ssim(a[0, 0, 1], b[0, 0, 1]) == pytest.approx(g["ssim_frame_0_channel_1"], rel=0, abs=1e-12)
 
 
 def test_ssim_vs_independent_restatement_and_identities():
