@@ -24,8 +24,8 @@ def _bind(text):
     return text
 
 
-def run_tile(m_valid, K, lda_pad=0, seed=0, dma_late=False, load_late=False, mfma=32):
-    gen.MFMA = mfma
+def run_tile(m_valid, K, lda_pad=0, seed=0, dma_late=False, load_late=False, mfma=32, row=64):
+    gen.MFMA, gen.ROW = mfma, row
     rng = np.random.default_rng(seed)
     lda = K + lda_pad
     A = emu.bf16_to_f32(emu.bf16_rne(rng.standard_normal((m_valid, lda)).astype(np.float32)))
@@ -68,19 +68,22 @@ def run_tile(m_valid, K, lda_pad=0, seed=0, dma_late=False, load_late=False, mfm
     return got, want
 
 
-@pytest.mark.parametrize("mfma", [32, 16])
+SHAPES = [(32, 64), (16, 64), (16, 128)]      # (MFMA shape, LDS row bytes)
+
+
+@pytest.mark.parametrize("mfma,row", SHAPES)
 @pytest.mark.parametrize("m_valid,K,lda_pad", [(256, 256, 0), (200, 384, 0), (256, 256, 64), (37, 512, 8)])
-def test_gemm_v2_stream_matches_fp64(m_valid, K, lda_pad, mfma):
-    got, want = run_tile(m_valid, K, lda_pad, mfma=mfma)
+def test_gemm_v2_stream_matches_fp64(m_valid, K, lda_pad, mfma, row):
+    got, want = run_tile(m_valid, K, lda_pad, mfma=mfma, row=row)
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
     assert (got[m_valid:] == 0).all()                     # rows past M: fetched as zeros
 
 
-@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("mfma,row", SHAPES)
 @pytest.mark.parametrize("dma_late,load_late", [(True, False), (False, True), (True, True)])
-def test_gemm_v2_stream_is_race_free_under_late_completion(dma_late, load_late, mfma):
-    got, want = run_tile(256, 384, 0, seed=3, dma_late=dma_late, load_late=load_late, mfma=mfma)
+def test_gemm_v2_stream_is_race_free_under_late_completion(dma_late, load_late, mfma, row):
+    got, want = run_tile(256, 384, 0, seed=3, dma_late=dma_late, load_late=load_late, mfma=mfma, row=row)
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
 
@@ -88,5 +91,6 @@ def test_gemm_v2_stream_is_race_free_under_late_completion(dma_late, load_late, 
 def test_gemm_v2_inc_file_is_current():
     cfg = open(os.path.join(ROOT, "magcache_amd", "csrc", "gemm_v2_config.h")).read()
     gen.MFMA = 32 if "MC_GEMM_V2_MFMA 32" in cfg else 16
+    gen.ROW = 128 if "MC_GEMM_V2_ROW 128" in cfg else 64
     inc = os.path.join(ROOT, "magcache_amd", "csrc", "gemm_v2_body.inc")
     assert open(inc).read() == gen.to_inc(gen.generate()), "regenerate with: python tools/gen_gemm_v2.py --write"

@@ -67,6 +67,13 @@ def s(n, c=1):
     return f"s{n}" if c == 1 else f"s[{n}:{n + c - 1}]"
 
 
+ROW = 64                     # bytes of a row in the LDS ring.  64: ring of four 32-k sub-stages (above; measured: every 128-byte cache
+                             # line is requested twice, TCP_TCC_READ_REQ 61.5 M vs 28.4 M for the 8-wave kernel).
+                             # 128 (MFMA 16 only): ring of TWO 64-k tiles, an LDS-DMA piece = 8 rows x 128 B (full lines), one
+                             # barrier per 64 k; the tile kt+2 is fetched during the second k-step of tile kt (lead 128 MFMAs).
+                             # Built and emulator-validated at the end of round 3, NOT yet measured (no GPU minutes left).
+
+
 def frag(p, op, blk, ks=0):
     """16 x 16 x 32: blk = 16-row block 0..7;  32 x 32 x 16: blk = 32-row block 0..3, ks = k-step of 16"""
     idx = blk if MFMA == 16 else blk * 2 + ks
@@ -234,7 +241,147 @@ def emit_body(e, b):
     e.i("s_waitcnt lgkmcnt(0)")
 
 
+def dma_piece128(e, op, j, slot):
+    """piece j (8 rows x 128 B) of this wave's 64 rows of operand op, into ring slot `slot` (64 KiB: A 32 KiB | W 32 KiB)"""
+    src, srd = (V_S128, S_ASRD) if op == "A" else (V_S128 + 8, S_WSRD)
+    e.i(f"s_add_u32 m0, {s(S_LDSW)}, {slot * 65536 + (0 if op == 'A' else 32768) + j * 1024}")
+    e.i("s_nop 0")
+    e.i(f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(S_DCUR)} offen lds")
+
+
+def frag_read128(e, p, op, blk, slot, ks):
+    base = V_B128 + (0 if op == "A" else 4) + 2 * ks + slot
+    e.i(f"ds_read_b128 {v(frag(p, op, blk), 4)}, {v(base)} offset:{blk * 2048}")
+
+
+V_B128 = 156                 # ROW 128: fragment read bases [A | W][k-step][slot] = v156..v163
+V_S128 = 164                 # ROW 128: LDS-DMA source offsets [A | W][8 pieces] = v164..v179
+
+
+def emit_prologue128(e):
+    V_SA, V_SW = V_S128, V_S128 + 8
+    e.c("---- inputs -> fixed SGPRs")
+    for k, dst in enumerate((s(S_A, 2), s(S_W, 2), s(S_LDA), s(S_LDW), s(S_NK), s(S_WV), s(S_LDS), s(S_ANREC), s(S_WNREC))):
+        e.i(f"s_mov_b{64 if k < 2 else 32} {dst}, %{IN0 + k}")
+    for srd, base, nrec in ((S_ASRD, S_A, S_ANREC), (S_WSRD, S_W, S_WNREC)):
+        e.i(f"s_mov_b32 {s(srd)}, {s(base)}")
+        e.i(f"s_and_b32 {s(srd + 1)}, {s(base + 1)}, 0xffff")
+        e.i(f"s_mov_b32 {s(srd + 2)}, {s(nrec)}")
+        e.i(f"s_mov_b32 {s(srd + 3)}, 0x00020000")
+    t0, t1, t2, l15, g4 = V_T, V_T + 1, V_T + 2, V_T + 3, V_T + 4
+    e.i(f"v_mbcnt_lo_u32_b32 {v(V_LANE)}, -1, 0")
+    e.i(f"v_mbcnt_hi_u32_b32 {v(V_LANE)}, -1, {v(V_LANE)}")
+    e.i(f"v_and_b32 {v(l15)}, 15, {v(V_LANE)}")
+    e.i(f"v_lshrrev_b32 {v(g4)}, 4, {v(V_LANE)}")
+    # fragment read bases: row = 128 w? + 16 blk + lane % 16 (128-byte rows), chunk 4 ks + lane / 16,
+    # 16-byte position = chunk ^ ((row >> 1) & 7)  (gemm_bf16_big.hip's swizzle, tests/test_gemm_layout_model.py)
+    e.i(f"v_lshrrev_b32 {v(t2)}, 1, {v(l15)}")                          # (row >> 1) & 7
+    for ks in range(2):
+        t = t0 if ks == 0 else t1
+        e.i(f"v_or_b32 {v(t)}, {4 * ks}, {v(g4)}")
+        e.i(f"v_xor_b32 {v(t)}, {v(t)}, {v(t2)}")
+        e.i(f"v_lshlrev_b32 {v(t)}, 4, {v(t)}")
+        e.i(f"v_lshl_add_u32 {v(t)}, {v(l15)}, 7, {v(t)}")               # l15 * 128 + pos * 16
+        e.i(f"v_add_u32 {v(t)}, {s(S_LDS)}, {v(t)}")
+    e.i(f"s_lshr_b32 {s(S_T)}, {s(S_WV)}, 1")                           # wr
+    e.i(f"s_lshl_b32 {s(S_T)}, {s(S_T)}, 14")                           # wr * 128 rows * 128 B
+    e.i(f"s_and_b32 {s(S_T + 1)}, {s(S_WV)}, 1")                        # wc
+    e.i(f"s_lshl_b32 {s(S_T + 1)}, {s(S_T + 1)}, 14")
+    e.i(f"s_add_u32 {s(S_T + 1)}, {s(S_T + 1)}, 32768")
+    for oi, st in enumerate((S_T, S_T + 1)):
+        for ks, t in enumerate((t0, t1)):
+            b = V_B128 + 4 * oi + 2 * ks
+            e.i(f"v_add_u32 {v(b)}, {s(st)}, {v(t)}")
+            e.i(f"v_add_u32 {v(b + 1)}, 65536, {v(b)}")
+    # LDS-DMA sources: piece j = tile rows 64 wv + 8 j + (lane >> 3); slot lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7)
+    e.i(f"v_lshrrev_b32 {v(t0)}, 3, {v(V_LANE)}")                       # row in piece (0..7)
+    e.i(f"v_lshrrev_b32 {v(t1)}, 1, {v(t0)}")                           # (row >> 1) & 3 -- bit 2 comes from the piece index
+    e.i(f"v_and_b32 {v(t2)}, 7, {v(V_LANE)}")
+    e.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 6")
+    e.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(t0)}")                        # 64 wv + row in piece
+    for j in range(8):
+        # row = 64 wv + 8 j + r: (row >> 1) & 7 = ((8 j + r) >> 1) & 7 = (4 j + (r >> 1)) & 7 = (4 (j & 1)) | (r >> 1)
+        e.i(f"v_or_b32 {v(V_T + 5)}, {4 * (j & 1)}, {v(t1)}")
+        e.i(f"v_xor_b32 {v(V_T + 5)}, {v(V_T + 5)}, {v(t2)}")           # chunk
+        e.i(f"v_lshlrev_b32 {v(V_T + 5)}, 4, {v(V_T + 5)}")
+        e.i(f"v_add_u32 {v(V_T + 6)}, {8 * j}, {v(t0)}")                # tile row
+        e.i(f"v_mul_lo_u32 {v(V_T + 7)}, {v(V_T + 6)}, {s(S_LDA)}")
+        e.i(f"v_add_u32 {v(V_SA + j)}, {v(V_T + 7)}, {v(V_T + 5)}")
+        e.i(f"v_mul_lo_u32 {v(V_T + 7)}, {v(V_T + 6)}, {s(S_LDW)}")
+        e.i(f"v_add_u32 {v(V_SW + j)}, {v(V_T + 7)}, {v(V_T + 5)}")
+    e.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 13")                          # this wave's 64 rows x 128 B inside an operand tile
+    e.i(f"s_add_u32 {s(S_LDSW)}, {s(S_T)}, {s(S_LDS)}")
+    e.i(f"s_mov_b32 {s(S_DCUR)}, 0")
+    e.c("---- accumulators = 0")
+    for r in range(256):
+        e.i(f"v_accvgpr_write_b32 {a(r)}, 0")
+    e.c("---- K tiles 0, 1 on their way; fragments of (tile 0, k-step 0)")
+    for st in range(2):
+        for op in "AW":
+            for j in range(8):
+                dma_piece128(e, op, j, st)
+        e.i(f"s_add_u32 {s(S_DCUR)}, {s(S_DCUR)}, 128")
+    e.i("s_waitcnt vmcnt(16)")
+    e.i("s_barrier")
+    for blk in range(8):
+        frag_read128(e, 0, "W", blk, 0, 0)
+        frag_read128(e, 0, "A", blk, 0, 0)
+    e.i("s_waitcnt lgkmcnt(0)")
+    e.i(f"s_lshr_b32 {s(S_IT)}, {s(S_NK)}, 2")                          # nk counts 32-k steps: trips of the 2-tile loop
+
+
+def emit_tile128(e, b):
+    """K tile kt = 2 trip + b in ring slot b.
+    k-step 0: 64 MFMAs on fragment buffer 0 || reads of (kt, k-step 1) -> buffer 1
+    barrier: every wave is done reading slot b; tile kt+1 (slot 1 - b) has landed for every wave
+    k-step 1: 64 MFMAs on buffer 1 || reads of (kt+1, k-step 0) -> buffer 0, the 16 LDS-DMA pieces of tile kt+2 -> slot b"""
+    e.c(f"---- K tile body {b}, k-step 0")
+    reads = [(op, blk) for blk in range(8) for op in "WA"]
+    plan = {2 + 3 * k: r for k, r in enumerate(reads)}
+    g = 0
+    for nb in range(8):
+        for mb in range(8):
+            e.i(f"v_mfma_f32_16x16x32_bf16 {a(acc(nb, mb), 4)}, {v(frag(0, 'W', nb), 4)}, {v(frag(0, 'A', mb), 4)}, {a(acc(nb, mb), 4)}")
+            if g in plan:
+                frag_read128(e, 1, plan[g][0], plan[g][1], b, 1)
+            g += 1
+    e.i("s_waitcnt lgkmcnt(0)")
+    e.i("s_waitcnt vmcnt(0)")
+    e.i("s_barrier")
+    e.c(f"---- K tile body {b}, k-step 1")
+    dmas = [(op, j) for op in "AW" for j in range(8)]
+    plan = {1 + 3 * k: ("read",) + r for k, r in enumerate(reads)}      # 1, 4, .. 46
+    plan.update({3 * k: ("dma",) + d for k, d in enumerate(dmas)})      # 0, 3, .. 45
+    g = 0
+    for nb in range(8):
+        for mb in range(8):
+            e.i(f"v_mfma_f32_16x16x32_bf16 {a(acc(nb, mb), 4)}, {v(frag(1, 'W', nb), 4)}, {v(frag(1, 'A', mb), 4)}, {a(acc(nb, mb), 4)}")
+            f = plan.get(g)
+            if f:
+                if f[0] == "read":
+                    frag_read128(e, 0, f[1], f[2], 1 - b, 0)
+                else:
+                    dma_piece128(e, f[1], f[2], b)
+            g += 1
+    e.i(f"s_add_u32 {s(S_DCUR)}, {s(S_DCUR)}, 128")
+    e.i("s_waitcnt lgkmcnt(0)")
+
+
 def generate():
+    if ROW == 128:
+        assert MFMA == 16
+        e = E()
+        emit_prologue128(e)
+        e.label("L_loop")
+        for b in range(2):
+            emit_tile128(e, b)
+        e.i(f"s_sub_u32 {s(S_IT)}, {s(S_IT)}, 1")
+        e.i(f"s_cmp_lg_u32 {s(S_IT)}, 0")
+        e.i("s_cbranch_scc1 L_loop")
+        e.i("s_waitcnt vmcnt(0)")
+        e.i("s_nop 15")
+        e.i("s_nop 15")
+        return "\n".join(e.lines) + "\n"
     e = E()
     emit_prologue(e)
     e.label("L_loop")
@@ -274,13 +421,15 @@ def clobbers():
 
 
 def main():
-    global MFMA
+    global MFMA, ROW
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--asm")
     ap.add_argument("--mfma", type=int, default=MFMA)
+    ap.add_argument("--row", type=int, default=ROW)
     args = ap.parse_args()
     MFMA = args.mfma
+    ROW = args.row
     text = generate()
     if args.asm:
         open(args.asm, "w").write(text)
@@ -289,7 +438,7 @@ def main():
         d = os.path.join(root, "magcache_amd", "csrc")
         open(os.path.join(d, "gemm_v2_body.inc"), "w").write(to_inc(text))
         open(os.path.join(d, "gemm_v2_clobbers.inc"), "w").write(clobbers())
-        open(os.path.join(d, "gemm_v2_config.h"), "w").write("// GENERATED by tools/gen_gemm_v2.py\n#define MC_GEMM_V2_MFMA %d\n" % MFMA)
+        open(os.path.join(d, "gemm_v2_config.h"), "w").write("// GENERATED by tools/gen_gemm_v2.py\n#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n" % (MFMA, ROW))
     n = sum(1 for l in text.splitlines() if l.startswith("  ") and not l.strip().startswith(";"))
     print(f"{n} instructions", file=sys.stderr)
 
