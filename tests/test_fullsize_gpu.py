@@ -257,7 +257,8 @@ def test_hunyuan_full_depth_reduced_length():
 
 
 @pytest.mark.slow
-@pytest.mark.skipif(os.environ.get("MC_SKIP_SLOW") == "1", reason="MC_SKIP_SLOW=1")
+@pytest.mark.skipif(os.environ.get("MC_RUN_SLOW") != "1", reason="9 minutes on one MI355X: set MC_RUN_SLOW=1 (tools/gpu_session.sh pytest_slow); "
+                    "last result: profiles/r03/pytest_gpu_r03_final.log, profiles/r03/fullsize_parity.json")
 def test_hunyuan_full_depth_720p_129f():
     """BASELINE.json config 2 at full depth AND full length: HunyuanVideo 720p 129 frames, 118 800 image + 256 text
     tokens, all 20 double + 40 single blocks (reference forward MagCache4HunyuanVideo/magcache_sample_video.py:105-140)."""
