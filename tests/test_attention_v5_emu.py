@@ -199,6 +199,21 @@ def test_v5_lazy_rescale_routine_with_a_low_threshold(n_keys, mfma):
 
 
 @pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("valid,n_shards,skip", [(100, 3, -1), (37, 4, 2), (130, 3, 0)])
+def test_v5_reference_moves_and_padding_masks_at_the_same_boundaries(valid, n_shards, skip, mfma):
+    """low row-sum threshold (the reference moves every few tiles) on key shards whose last tile is padded with large
+    garbage: the mask of the NEXT tile and the reference move of the finished one meet at the same phase boundary"""
+    pb = Problem(valid, n_shards, q_amp=3.0, seed=31 + valid, pad_value=30.0)
+    first = 1 if skip == 0 else 0
+    out_bits, _, m = launch(pb, first_shard=first, skip=skip, dma_late=True, load_late=True, cfg={"mfma": mfma, "lthr": 3})
+    got = emu.bf16_to_f32(out_bits[:, pb.head * 128:(pb.head + 1) * 128].astype(np.uint32))
+    want, _ = pb.reference([sh for sh in range(n_shards) if sh != skip])
+    assert np.isfinite(got).all()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 8e-3
+    assert all(int(w.s[S_SAFE]) == 0 for w in m.waves)
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
 def test_v5_exact_maximum_stream_alone(mfma):
     # cfg lazy = 0: only the exact loop is generated (what round 3 shipped first)
     rel, got, want, _ = run_block(448, q_amp=4.0, seed=5, spike=True, dma_late=True, load_late=True, cfg={"mfma": mfma, "lazy": 0})
