@@ -79,7 +79,7 @@ def main():
         b = [i for i, l in enumerate(lines) if "iteration body 1" in l][0]
     gaps = gaps_of(lines[a:b])
     hist = collections.Counter()
-    known, n_known = 0.0, 0
+    known, n_known, est = 0.0, 0, 0.0
     for i, gp in enumerate(gaps):
         c = collections.Counter(kind(m) for m in gp)
         key = (c["e"], c["v"], c["l"])
@@ -89,12 +89,17 @@ def main():
         if cyc:
             known += cyc
             n_known += 1
-        print(f"gap {i:3d}: {desc:18s} {'' if cyc is None else f'{cyc:5.1f} cycles in the probe'}")
+        # outside the table: issue slots of 4 cycles -- MFMA 3, exp 2, VALU 1, LDS read 2 next to VALU, LDS-DMA 2 (+ its M0
+        # write), SALU / satisfied waits 1/2 -- never below the bare period
+        guess = max(36.0, 4.0 * (3 + 2 * c["e"] + c["v"] + 2 * c["l"] + 2 * c["d"] + 0.5 * c["s"]))
+        est += cyc if cyc else guess
+        print(f"gap {i:3d}: {desc:18s} {f'~{guess:5.1f} (slot count)' if cyc is None else f'{cyc:5.1f} cycles in the probe'}")
     print("\ncompositions:", ", ".join(f"{k} x{v}" for k, v in hist.most_common()))
     tot = collections.Counter(kind(m) for gp in gaps for m in gp)
     print(f"{len(gaps)} gaps; exp {tot['e']}, VALU {tot['v']}, LDS reads {tot['l']}, LDS-DMA {tot['d']}, SALU/waits {tot['s']}")
     if n_known:
         print(f"{n_known} gaps have a probe entry: mean {known / n_known:.1f} cycles (bare MFMA stream: 35.9)")
+    print(f"estimate for the body: {est:.0f} cycles = {est / len(gaps):.2f} per MFMA (table where it has an entry, slot count elsewhere)")
 
 
 if __name__ == "__main__":
