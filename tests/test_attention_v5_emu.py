@@ -225,6 +225,14 @@ def test_v5_exact_maximum_stream_alone(mfma):
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 5e-3
 
 
+@pytest.mark.parametrize("cfg", [{"pair_reads": 1}, {"k_p1": 2, "pair_reads": 1}, {"k_p1": 3}])
+def test_v5_pipelined_body_read_placement_options(cfg):
+    # generator options kept for the next schedule search (both fragment reads in one gap, K reads moved to phase 2)
+    rel, got, want, _ = run_block(300, dma_late=True, load_late=True, seed=9, cfg=cfg)
+    assert np.isfinite(got).all()
+    assert rel < 5e-3, rel
+
+
 def test_v5_two_deep_ring_variant_is_also_right():
     rel, got, want, _ = run_block(300, dma_late=True, load_late=True, seed=7, cfg={"nst": 2, "ahead": 1, "barrier_every": 1})
     assert np.isfinite(got).all()

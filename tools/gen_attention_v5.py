@@ -69,6 +69,10 @@ DEFAULT_CFG = {
                              # deadline; gap contents follow the measured table of tools/gen_ubench_gap2.py
     "v_lds": 1, "v_free": 4, # VALU consumers beside the exponential in a gap with / without an LDS read or LDS-DMA
     "v_lds2": 2,             # ... in phase 2 (more LDS reads than gaps to spare)
+    "pair_reads": 0,         # (not yet measured) 1: both transposing reads of a V^T fragment in ONE phase-2 gap, the other gap of
+                             # the MFMA pair stays free for exp + v_free VALU (tools/stream_report.py: 14 gaps of exp + 2 VALU +
+                             # read cost 41 table-cycles each)
+    "k_p1": 5,               # (5 measured) K(t+2) d-steps whose fragments are read in phase 1; the rest go to phase 2
     "v_dma": 1,              # ... beside an LDS-DMA piece (3: +3 % cycles, and the 10-instruction drain at the end of phase 1 is cheaper)
     "hoist": 1,              # the rescale decision's VALU part rides behind the lane maxima of the previous iteration
     "exp_gap": 3,            # instructions (MFMAs included) between two v_exp_f32 at least
@@ -822,7 +826,7 @@ def emit_body_pipe(E, b, ret):
     m0_g = {1: "K", 9: "V"}
     adv_g = {9: "K", 17: "V"}
     kread_g = {}
-    for ds in range(5):                     # K(t+2) fragments of d-step ds: free once the 4 MFMAs of the d-step are issued
+    for ds in range(cfg["k_p1"]):           # K(t+2) fragments of d-step ds: free once the 4 MFMAs of the d-step are issued
         kread_g[4 * (ds + 1) + 1] = (0, ds)
         kread_g[4 * (ds + 1) + 3] = (1, ds)
     vread_g = {24 + 2 * f + h: (f, h) for f in range(4) for h in range(2)}
@@ -868,7 +872,8 @@ def emit_body_pipe(E, b, ret):
     E.label(f"L_back{ret}")
     # ---------------- phase 2
     fin = Finish(E, nxt, pipe_groups(M, 0))
-    kread2 = [(kb, ds) for ds in range(5, M.NDS) for kb in range(M.NKB)]
+    kread2 = [(kb, ds) for ds in range(cfg["k_p1"], M.NDS) for kb in range(M.NKB)]
+    pair = bool(cfg["pair_reads"])
     nfr = M.NKS * M.NDB
     wg = 2                                  # a fragment pair per wait: the younger one was read three MFMA pairs ago
     g = 0
@@ -882,7 +887,16 @@ def emit_body_pipe(E, b, ret):
                 o = a(A_O + (qb * M.NDB + db) * M.ACC, M.ACC)
                 E.i(f"{M.mn} {o}, {v(M.V_VF + 4 * (f % M.NVF), 4)}, {v(M.P(cur, qb, ks), 4)}, {o}")
                 lds = False
-                if f + 4 < nfr:
+                if f + 4 < nfr and pair:
+                    if qb == 0:
+                        vfrag_read_half(E, f + 4, 0, B.v_read_slot * TILE)
+                        tickets[f + 4] = vfrag_read_half(E, f + 4, 1, B.v_read_slot * TILE)
+                        lds = True
+                    elif kread2 and len(kread2) > 2 * (nfr - 5 - f):      # more K reads left than V-free gaps at the end
+                        kb_, ds_ = kread2.pop(0)
+                        kt.append(kfrag_read(E, kb_, ds_, B.k_read_slot))
+                        lds = True
+                elif f + 4 < nfr:
                     tk = vfrag_read_half(E, f + 4, qb, B.v_read_slot * TILE)
                     if qb:
                         tickets[f + 4] = tk
