@@ -9,17 +9,26 @@ explicit hazard padding; hipcc only wraps it (kernel arguments in SGPRs, launch)
 csrc/attention_v5_body.inc (a C string for one asm statement); tests/test_attention_v5_emu.py executes it on the
 functional emulator tools/gcn_emu.py.
 
-Shape: workgroup = 4 waves = 256 query rows of one head; wave = 64 rows.  Per 64-key tile t:
-   phase 1  S(t+1)^T = K(t+1) Q^T              ||  P(t) = exp2(S(t)) (first part), row sums, bf16 pack IN PLACE,
-                                                    LDS-DMA of K(t+2+A) / V(t+A), first V^T fragments of phase 2
-   phase 2  O^T += V(t)^T P(t)^T               ||  rest of P(t), V^T fragments (ds_read_b64_tr_b16) just in time,
-                                                    K(t+2) fragments -> AGPRs (ds_read_b128), lane maxima of S(t+1)
-   one counted s_waitcnt vmcnt + s_barrier per tile; K / V tiles in NST-deep LDS rings, A tiles ahead.
+Shape: workgroup = 4 waves = 256 query rows of one head; wave = 64 rows.
+The stream that ships (cfg lazy = 1, pipe = 1, 32x32x16), per 64-key tile t:
+   phase 1   S(t+1)^T = K(t+1) Q^T (32 MFMA)   ||  key steps 2, 3 of the finish of S(t): exp2, row sums, bf16 pack IN PLACE;
+                                                    LDS-DMA of K(t+4) / V(t+2); K(t+2) fragments of d-steps 0..4; V^T(t) 0..3
+   boundary  padding mask of S(t+1) (rare), row-sum check -> reference move (rare, one tile late, exact power of two)
+   phase 2   O^T += V(t)^T P(t)^T (32 MFMA)    ||  key steps 0, 1 of the finish of S(t+1); V^T fragments 4..15 one read per gap;
+                                                    K(t+2) d-steps 5..7
+   ONE exponential per MFMA gap over the whole iteration, every gap one of the compositions tools/gen_ubench_gap2.py
+   measured to be free (exp + 1 VALU + one LDS read / LDS-DMA piece, or exp + 4 VALU); no lane maxima in the loop (LAZY
+   reference); a workgroup whose row sums end non-finite or >= 2^120 votes and starts over in the exact loop below before
+   anything is written.  One s_waitcnt vmcnt(0) + s_barrier per TWO tiles; K / V tiles in 4-deep LDS rings, 2 tiles ahead.
+The exact loop (cfg lazy = 0; also the second pass of an overflowed workgroup, and the only form of the 16x16x32 shape):
+   phase 1   S(t+1)^T = K(t+1) Q^T             ||  P(t) = exp2(S(t)) (first part), row sums, pack; LDS-DMA; first V^T fragments
+   phase 2   O^T += V(t)^T P(t)^T              ||  rest of P(t), V^T fragments just in time, K(t+2) fragments, lane maxima of
+                                                    S(t+1); deferred rescale when a lane maximum exceeds the reference by 2^RTHR
 Two MFMA shapes (cfg "mfma"):
-   32: v_mfma_f32_32x32x16_bf16, wave = 2 query blocks x 32 rows, 32 MFMAs per phase (the shape of attention_v3.hip);
+   32: v_mfma_f32_32x32x16_bf16, wave = 2 query blocks x 32 rows, 32 MFMAs per phase (default: fewest cycles);
    16: v_mfma_f32_16x16x32_bf16, wave = 4 query blocks x 16 rows, 64 MFMAs per phase -- the same fragment reads, VALU
-       work and registers, but the shape that draws less power per FLOP (tools/ubench_mfma_issue2.cpp: 2030 vs 1800
-       TFLOP/s on random operands at the power limit); the kernel is power-limited (profiles/r03), so this is the lever.
+       work and registers, less power per FLOP (tools/ubench_mfma_issue2.cpp: 2030 vs 1800 TFLOP/s on random operands at
+       the power limit): faster back to back (power-limited), slower inside the engine (profiles/r03/NOTES.md 4, 5).
 Same math as attention_v3.hip: Q pre-multiplied by scale*log2(e), accumulators of S start from -m (c_init), deferred
 rescale (wave-uniform rare branch when a lane maximum exceeds the reference by more than 2^RTHR), S^T accumulators consumed
 directly as the B operand of the PV MFMA (contraction index permuted consistently on both operands), K rows swizzled
