@@ -35,23 +35,57 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // ---- tile mapping: XCD-contiguous, grouped along M (as gemm_bf16_big.hip)
   const int ntiles = tilesM * tilesN;
-  const int vt = xcd_remap(blockIdx.x, ntiles);
-  const int per_group = GROUP_M * tilesN;
-  const int grp = vt / per_group;
-  const int first_m = grp * GROUP_M;
-  const int gsz = min(tilesM - first_m, GROUP_M);
-  const int in_grp = vt - grp * per_group;
-  const int m0 = (first_m + in_grp % gsz) * TB;
-  const int n0 = (in_grp / gsz) * TB;
-
-  const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
-  const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
+  int m0 = 0, n0 = 0;
+  auto place = [&](int t, int& tm0, int& tn0) {
+    const int vt = xcd_remap(t, ntiles);
+    const int per_group = GROUP_M * tilesN;
+    const int grp = vt / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(tilesM - first_m, GROUP_M);
+    const int in_grp = vt - grp * per_group;
+    tm0 = (first_m + in_grp % gsz) * TB;
+    tn0 = (in_grp / gsz) * TB;
+  };
   const uint32_t lda_b = (uint32_t)p.lda * 2, ldw_b = (uint32_t)p.ldw * 2;
-  // bytes reachable from the tile's first element: rows past M / N are out of range and read zeros
-  const uint32_t a_nrec = (uint32_t)min((size_t)(p.M - m0) * lda_b - (size_t)(p.lda - p.K) * 2, (size_t)0xffffff00u);
-  const uint32_t w_nrec = (uint32_t)min((size_t)(p.N - n0) * ldw_b - (size_t)(p.ldw - p.K) * 2, (size_t)0xffffff00u);
+  // bytes reachable from a tile's first element: rows past M / N are out of range and read zeros
+  auto a_nrec_of = [&](int tm0) { return (uint32_t)min((size_t)(p.M - tm0) * lda_b - (size_t)(p.lda - p.K) * 2, (size_t)0xffffff00u); };
+  auto w_nrec_of = [&](int tn0) { return (uint32_t)min((size_t)(p.N - tn0) * ldw_b - (size_t)(p.ldw - p.K) * 2, (size_t)0xffffff00u); };
   const int nk = p.K / 32;
   const uint32_t lds0 = (uint32_t)(uintptr_t)MC_LDS_PTR(smem);
+
+#if MC_GEMM_V2_PERSIST
+  // one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...: the asm statement is one trip; its last two K tiles fetch
+  // the first two of the NEXT output tile, which land in the LDS ring under the epilogue below (tools/gen_gemm_v2.py)
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  place(tile, m0, n0);
+  const int next_tile = tile + (int)gridDim.x;
+  int nm0 = 0, nn0 = 0;
+  const bool more = next_tile < ntiles;
+  if (more) place(next_tile, nm0, nn0);
+  const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
+  const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
+  const bf16_t* a_next = p.A + (size_t)nm0 * p.lda;
+  const bf16_t* w_next = p.W + (size_t)nn0 * p.ldw;
+  const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
+  const uint32_t a_nrec_n = __builtin_amdgcn_readfirstlane(more ? a_nrec_of(nm0) : 0u);
+  const uint32_t w_nrec_n = __builtin_amdgcn_readfirstlane(more ? w_nrec_of(nn0) : 0u);
+  const int first = __builtin_amdgcn_readfirstlane(tile == (int)blockIdx.x ? 1 : 0);
+  f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;
+  asm volatile(
+#include MC_GEMM_V2_BODY
+      : "={a[0:15]}"(c0), "={a[16:31]}"(c1), "={a[32:47]}"(c2), "={a[48:63]}"(c3), "={a[64:79]}"(c4), "={a[80:95]}"(c5),
+        "={a[96:111]}"(c6), "={a[112:127]}"(c7), "={a[128:143]}"(c8), "={a[144:159]}"(c9), "={a[160:175]}"(c10),
+        "={a[176:191]}"(c11), "={a[192:207]}"(c12), "={a[208:223]}"(c13), "={a[224:239]}"(c14), "={a[240:255]}"(c15)
+      : "s"(a_tile), "s"(w_tile), "s"(lda_b), "s"(ldw_b), "s"(nk), "s"(wv), "s"(lds0), "s"(a_nrec), "s"(w_nrec), "s"(a_next),
+        "s"(w_next), "s"(a_nrec_n), "s"(w_nrec_n), "s"(first)
+      :
+#include MC_GEMM_V2_CLOBBERS
+  );
+#else
+  place(blockIdx.x, m0, n0);
+  const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
+  const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
+  const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
 
   f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;
   asm volatile(
@@ -63,6 +97,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       :
 #include MC_GEMM_V2_CLOBBERS
   );
+#endif
   const f32x16 cc[16] = {c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15};
 
   // ---- epilogue: a wave's 128 x 128 tile as NQ quads of 4 consecutive n for each of NR rows m of the lane
@@ -135,6 +170,11 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       }
     }
   }
+#if MC_GEMM_V2_PERSIST
+  }   // tile loop
+  // the last trip's "next tile" fetches (zeros: num_records 0) still write the ring: they must not outlive the workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 template <int EPI>
@@ -142,7 +182,18 @@ hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream) {
   const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
   static std::atomic<uint64_t> lds_ready{0};
   if (hipError_t e = ensure_dynamic_lds((const void*)gemm_v2_kernel<EPI>, V2_LDS_BYTES, lds_ready); e != hipSuccess) return e;
-  hipLaunchKernelGGL((gemm_v2_kernel<EPI>), dim3(tilesM * tilesN), dim3(256), V2_LDS_BYTES, stream, p, tilesM, tilesN,
+  int grid = tilesM * tilesN;
+#if MC_GEMM_V2_PERSIST
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+  }
+  if (grid > n_cu) grid = n_cu;
+#endif
+  hipLaunchKernelGGL((gemm_v2_kernel<EPI>), dim3(grid), dim3(256), V2_LDS_BYTES, stream, p, tilesM, tilesN,
                      tilesN >= 32 ? 4 : 8);
   return hipGetLastError();
 }

@@ -94,3 +94,68 @@ def test_gemm_v2_inc_file_is_current():
     gen.ROW = 128 if "MC_GEMM_V2_ROW 128" in cfg else 64
     inc = os.path.join(ROOT, "magcache_amd", "csrc", "gemm_v2_body.inc")
     assert open(inc).read() == gen.to_inc(gen.generate()), "regenerate with: python tools/gen_gemm_v2.py --write"
+
+
+# ---------------------------------------------------------------- persistent form (ROW 128): two trips of one workgroup
+def _bind_n(text, n):
+    pairs = {0, 1, 9, 10}
+    for k in range(n - 1, -1, -1):
+        r = IN_BASE + 2 * k
+        text = text.replace(f"%{gen.IN0 + k}", f"s[{r}:{r + 1}]" if k in pairs else f"s{r}")
+    return text
+
+
+def _read_acc16(m):
+    got = np.zeros((256, 256), dtype=np.float32)
+    lanes = np.arange(64)
+    for w in m.waves:
+        wr, wc = w.wid >> 1, w.wid & 1
+        for nb in range(8):
+            for mb in range(8):
+                for r in range(4):
+                    got[wr * 128 + mb * 16 + (lanes & 15), wc * 128 + nb * 16 + 4 * (lanes >> 4) + r] = emu.f32(w.a[gen.acc(nb, mb) + r])
+    return got
+
+
+@pytest.mark.parametrize("dma_late,load_late", [(False, False), (True, True)])
+def test_gemm_v2_persistent_trips_hand_the_ring_over(dma_late, load_late):
+    """trip 1 (first = 1) computes tile X and, during its last two K tiles, fetches K tiles 0, 1 of tile Y; the registers
+    are then scrambled (the C++ epilogue owns them); trip 2 (first = 0, no next tile) starts from the queued fetches"""
+    gen.MFMA, gen.ROW, gen.PERSIST = 16, 128, 1
+    try:
+        text = _bind_n(gen.generate(), 14) + "  s_endpgm\n"
+    finally:
+        gen.PERSIST = 0
+    K, lda = 384, 384
+    rng = np.random.default_rng(17)
+    mats = [emu.bf16_to_f32(emu.bf16_rne(rng.standard_normal((256, lda)).astype(np.float32))) for _ in range(4)]   # Ax Wx Ay Wy
+    bases = [0x1000_0000, 0x2000_0000, 0x3000_0000, 0x4000_0000]
+    nrec = 256 * lda * 2
+    lds = None
+    prev = None
+    outs = []
+    for trip, (ia, iw, first) in enumerate(((0, 1, 1), (2, 3, 0))):
+        m = emu.Machine(text, n_waves=4, lds_bytes=4 * gen.SUB, dma_late=dma_late, load_late=load_late)
+        if lds is not None:
+            m.lds = lds                         # the ring lives on
+        lds = m.lds
+        for b, x in zip(bases, mats):
+            m.add_buffer(b, emu.bf16_rne(x).astype(np.uint16))
+        nxt = (bases[2], bases[3], nrec, nrec) if trip == 0 else (0, 0, 0, 0)
+        vals = [bases[ia], bases[iw], lda * 2, lda * 2, K // 32, None, 0, nrec, nrec, nxt[0], nxt[1], nxt[2], nxt[3], first]
+        for wi, w in enumerate(m.waves):
+            if prev is not None:
+                w.vm_q = prev.waves[wi].vm_q    # fetches still in flight when the first trip's asm statement ended
+            w.v[:] = np.uint32(0x7FC0DEAD)      # the compiler owns the registers between the two statements
+            for k, val in enumerate(vals):
+                r = IN_BASE + 2 * k
+                val = w.wid if val is None else val
+                w.s[r] = np.uint32(val & 0xFFFFFFFF)
+                w.s[r + 1] = np.uint32((val >> 32) & 0xFFFFFFFF)
+        m.run()
+        outs.append(_read_acc16(m))
+        prev = m
+    for got, (ia, iw) in zip(outs, ((0, 1), (2, 3))):
+        want = mats[ia][:, :K].astype(np.float64) @ mats[iw][:, :K].astype(np.float64).T
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build stream variants of gemm_bf16_v2 for interleaved A/B runs (tools/kbench.bin with KBENCH_OPT_i=gemm_kernel=4):
 
-    tools/build_gemm_v2_variants.py  r128:mfma=16,row=128  m32:mfma=32,row=64
+    tools/build_gemm_v2_variants.py  r128:mfma=16,row=128  r128p:mfma=16,row=128,persist=1  m32:mfma=32,row=64
 
 Each variant gets build_variants/g2_<name>/libmagcache_hip.so = the shipped objects with gemm_bf16_v2.hip recompiled against
 that variant's generated stream (tools/gen_gemm_v2.py)."""
@@ -19,18 +19,18 @@ B.build()
 for spec in sys.argv[1:]:
     name, _, rest = spec.partition(":")
     kv = dict(x.split("=") for x in rest.split(",") if x)
-    gen.MFMA, gen.ROW = int(kv.get("mfma", 16)), int(kv.get("row", 64))
+    gen.MFMA, gen.ROW, gen.PERSIST = int(kv.get("mfma", 16)), int(kv.get("row", 64)), int(kv.get("persist", 0))
     out = os.path.join(ROOT, "build_variants", "g2_" + name)
     os.makedirs(out, exist_ok=True)
     text = gen.generate()
     open(os.path.join(out, "gemm_v2_body.inc"), "w").write(gen.to_inc(text))
     open(os.path.join(out, "gemm_v2_clobbers.inc"), "w").write(gen.clobbers())
-    open(os.path.join(out, "gemm_v2_config.h"), "w").write("#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n" % (gen.MFMA, gen.ROW))
+    open(os.path.join(out, "gemm_v2_config.h"), "w").write("#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n#define MC_GEMM_V2_PERSIST %d\n" % (gen.MFMA, gen.ROW, gen.PERSIST))
     obj = os.path.join(out, "gemm_bf16_v2.hip.o")
     defs = [f'-DMC_GEMM_V2_BODY="{out}/gemm_v2_body.inc"', f'-DMC_GEMM_V2_CLOBBERS="{out}/gemm_v2_clobbers.inc"',
             f'-DMC_GEMM_V2_CONFIG="{out}/gemm_v2_config.h"']
     subprocess.check_call([B.HIPCC] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, "gemm_bf16_v2.hip"), "-o", obj],
-                          stderr=subprocess.DEVNULL)
+                          )
     objs = [os.path.join(B.CSRC, "build", s + ".o") for s in B.SOURCES if s != "gemm_bf16_v2.hip"] + [obj]
     lib = os.path.join(out, "libmagcache_hip.so")
     subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)

@@ -37,8 +37,10 @@ S_DCUR = 40                  # byte offset (k) of the sub-stage the LDS-DMA is f
 S_IT = 41
 S_LDSW = 42                  # LDS address of this wave's 4 KiB inside the A part of slot 0
 S_T = 44
-S_LAST = 50
-N_INPUTS = 9
+S_ASRD2, S_WSRD2 = 52, 56    # (persistent form) descriptors of the workgroup's NEXT output tile
+S_DCUR2, S_FIRST = 60, 61
+S_LAST = 62
+N_INPUTS = 9                 # + 5 in the persistent form: next A / W tile pointers, their num_records, first-trip flag
 IN0 = 16                     # the asm statement's operands 0..15 are the accumulator outputs
 
 V_FR = 0                     # fragment buffers: [p][A | W][8 fragments] x 4 registers = v0..v127
@@ -67,6 +69,10 @@ def s(n, c=1):
     return f"s{n}" if c == 1 else f"s[{n}:{n + c - 1}]"
 
 
+PERSIST = 0                  # (ROW 128 only; built at the end of round 3, not measured) 1: the asm statement is one trip of a
+                             # persistent tile loop: the LDS ring runs on ACROSS output tiles -- the last two K tiles of a trip
+                             # fetch K tiles 0, 1 of the workgroup's next output tile (second descriptor pair), which land under
+                             # the C++ epilogue; a non-first trip starts from them instead of fetching.
 ROW = 64                     # bytes of a row in the LDS ring.  64: ring of four 32-k sub-stages (above; measured: every 128-byte cache
                              # line is requested twice, TCP_TCC_READ_REQ 61.5 M vs 28.4 M for the 8-wave kernel).
                              # 128 (MFMA 16 only): ring of TWO 64-k tiles, an LDS-DMA piece = 8 rows x 128 B (full lines), one
@@ -241,12 +247,13 @@ def emit_body(e, b):
     e.i("s_waitcnt lgkmcnt(0)")
 
 
-def dma_piece128(e, op, j, slot):
-    """piece j (8 rows x 128 B) of this wave's 64 rows of operand op, into ring slot `slot` (64 KiB: A 32 KiB | W 32 KiB)"""
-    src, srd = (V_S128, S_ASRD) if op == "A" else (V_S128 + 8, S_WSRD)
+def dma_piece128(e, op, j, slot, nxt=False):
+    """piece j (8 rows x 128 B) of this wave's 64 rows of operand op, into ring slot `slot` (64 KiB: A 32 KiB | W 32 KiB);
+    nxt: from the next output tile (persistent form)"""
+    src, srd = (V_S128, S_ASRD2 if nxt else S_ASRD) if op == "A" else (V_S128 + 8, S_WSRD2 if nxt else S_WSRD)
     e.i(f"s_add_u32 m0, {s(S_LDSW)}, {slot * 65536 + (0 if op == 'A' else 32768) + j * 1024}")
     e.i("s_nop 0")
-    e.i(f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(S_DCUR)} offen lds")
+    e.i(f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(S_DCUR2 if nxt else S_DCUR)} offen lds")
 
 
 def frag_read128(e, p, op, blk, slot, ks):
@@ -268,6 +275,13 @@ def emit_prologue128(e):
         e.i(f"s_and_b32 {s(srd + 1)}, {s(base + 1)}, 0xffff")
         e.i(f"s_mov_b32 {s(srd + 2)}, {s(nrec)}")
         e.i(f"s_mov_b32 {s(srd + 3)}, 0x00020000")
+    if PERSIST:
+        for srd, k in ((S_ASRD2, 9), (S_WSRD2, 10)):
+            e.i(f"s_mov_b64 {s(srd, 2)}, %{IN0 + k}")
+            e.i(f"s_and_b32 {s(srd + 1)}, {s(srd + 1)}, 0xffff")
+            e.i(f"s_mov_b32 {s(srd + 2)}, %{IN0 + k + 2}")                # 0: no next tile -> the fetches read zeros
+            e.i(f"s_mov_b32 {s(srd + 3)}, 0x00020000")
+        e.i(f"s_mov_b32 {s(S_FIRST)}, %{IN0 + 13}")
     t0, t1, t2, l15, g4 = V_T, V_T + 1, V_T + 2, V_T + 3, V_T + 4
     e.i(f"v_mbcnt_lo_u32_b32 {v(V_LANE)}, -1, 0")
     e.i(f"v_mbcnt_hi_u32_b32 {v(V_LANE)}, -1, {v(V_LANE)}")
@@ -316,11 +330,20 @@ def emit_prologue128(e):
     for r in range(256):
         e.i(f"v_accvgpr_write_b32 {a(r)}, 0")
     e.c("---- K tiles 0, 1 on their way; fragments of (tile 0, k-step 0)")
+    if PERSIST:
+        e.i(f"s_cmp_eq_u32 {s(S_FIRST)}, 0")
+        e.i("s_cbranch_scc1 L_queued")
     for st in range(2):
         for op in "AW":
             for j in range(8):
                 dma_piece128(e, op, j, st)
         e.i(f"s_add_u32 {s(S_DCUR)}, {s(S_DCUR)}, 128")
+    if PERSIST:
+        e.i("s_branch L_fetching")
+        e.label("L_queued")                 # the previous trip queued them (and the epilogue's stores sit behind them)
+        e.i(f"s_mov_b32 {s(S_DCUR)}, 256")
+        e.i("s_waitcnt vmcnt(0)")
+        e.label("L_fetching")
     e.i("s_waitcnt vmcnt(16)")
     e.i("s_barrier")
     for blk in range(8):
@@ -330,8 +353,8 @@ def emit_prologue128(e):
     e.i(f"s_lshr_b32 {s(S_IT)}, {s(S_NK)}, 2")                          # nk counts 32-k steps: trips of the 2-tile loop
 
 
-def emit_tile128(e, b):
-    """K tile kt = 2 trip + b in ring slot b.
+def emit_tile128(e, b, nxt=False):
+    """K tile kt = 2 trip + b in ring slot b (nxt: the trip's last two K tiles fetch from the next output tile).
     k-step 0: 64 MFMAs on fragment buffer 0 || reads of (kt, k-step 1) -> buffer 1
     barrier: every wave is done reading slot b; tile kt+1 (slot 1 - b) has landed for every wave
     k-step 1: 64 MFMAs on buffer 1 || reads of (kt+1, k-step 0) -> buffer 0, the 16 LDS-DMA pieces of tile kt+2 -> slot b"""
@@ -361,9 +384,9 @@ def emit_tile128(e, b):
                 if f[0] == "read":
                     frag_read128(e, 0, f[1], f[2], 1 - b, 0)
                 else:
-                    dma_piece128(e, f[1], f[2], b)
+                    dma_piece128(e, f[1], f[2], b, nxt)
             g += 1
-    e.i(f"s_add_u32 {s(S_DCUR)}, {s(S_DCUR)}, 128")
+    e.i(f"s_add_u32 {s(S_DCUR2 if nxt else S_DCUR)}, {s(S_DCUR2 if nxt else S_DCUR)}, 128")
     e.i("s_waitcnt lgkmcnt(0)")
 
 
@@ -372,6 +395,22 @@ def generate():
         assert MFMA == 16
         e = E()
         emit_prologue128(e)
+        if PERSIST:
+            e.i(f"s_mov_b32 {s(S_DCUR2)}, 0")
+            e.label("L_loop")
+            e.i(f"s_cmp_eq_u32 {s(S_IT)}, 1")
+            e.i("s_cbranch_scc1 L_lasttrip")
+            for b in range(2):
+                emit_tile128(e, b)
+            e.i(f"s_sub_u32 {s(S_IT)}, {s(S_IT)}, 1")
+            e.i("s_branch L_loop")
+            e.label("L_lasttrip")
+            for b in range(2):
+                emit_tile128(e, b, nxt=True)
+            # the next tile's K tiles 0, 1 stay in flight under the epilogue (the caller drains them behind its last tile)
+            e.i("s_nop 15")
+            e.i("s_nop 15")
+            return "\n".join(e.lines) + "\n"
         e.label("L_loop")
         for b in range(2):
             emit_tile128(e, b)
@@ -408,7 +447,9 @@ def to_inc(text):
 
 
 def clobbers():
-    regs = [f"v{i}" for i in range(256)] + [f"s{i}" for i in range(20, S_LAST + 1)] + ["vcc", "scc", "m0", "memory"]
+    # v0..v191: fragments, bases, offsets, temporaries (the highest register any layout uses is v179); v192..v255 stay with
+    # the compiler (the persistent kernel needs a few for SGPR spills across the statement)
+    regs = [f"v{i}" for i in range(192)] + [f"s{i}" for i in range(20, S_LAST + 1)] + ["vcc", "scc", "m0", "memory"]
     out, line = ["// GENERATED by tools/gen_gemm_v2.py: registers owned by the asm block (the AGPRs are its outputs)"], ""
     for r in regs:
         tok = f'"{r}", '
@@ -421,15 +462,17 @@ def clobbers():
 
 
 def main():
-    global MFMA, ROW
+    global MFMA, ROW, PERSIST
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--asm")
     ap.add_argument("--mfma", type=int, default=MFMA)
     ap.add_argument("--row", type=int, default=ROW)
+    ap.add_argument("--persist", type=int, default=PERSIST)
     args = ap.parse_args()
     MFMA = args.mfma
     ROW = args.row
+    PERSIST = args.persist
     text = generate()
     if args.asm:
         open(args.asm, "w").write(text)
@@ -438,7 +481,7 @@ def main():
         d = os.path.join(root, "magcache_amd", "csrc")
         open(os.path.join(d, "gemm_v2_body.inc"), "w").write(to_inc(text))
         open(os.path.join(d, "gemm_v2_clobbers.inc"), "w").write(clobbers())
-        open(os.path.join(d, "gemm_v2_config.h"), "w").write("// GENERATED by tools/gen_gemm_v2.py\n#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n" % (MFMA, ROW))
+        open(os.path.join(d, "gemm_v2_config.h"), "w").write("// GENERATED by tools/gen_gemm_v2.py\n#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n#define MC_GEMM_V2_PERSIST %d\n" % (MFMA, ROW, PERSIST))
     n = sum(1 for l in text.splitlines() if l.startswith("  ") and not l.strip().startswith(";"))
     print(f"{n} instructions", file=sys.stderr)
 
