@@ -267,6 +267,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     backend = os.environ.get("MC_BENCH_BACKEND", "nccl")   # tests: "gloo" runs N ranks on ONE GPU
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py measures the HIP path on an MI355X: no GPU is visible here (there is no CPU fallback)")
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
