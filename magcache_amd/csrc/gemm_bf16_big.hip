@@ -112,6 +112,15 @@ constexpr int OFF_AM0 = 0, OFF_AM1 = HALF_BYTES, OFF_WN0 = 2 * HALF_BYTES, OFF_W
 
 #define MC_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// epilogues that run the persistent tile loop (one workgroup per CU walks tiles; the next tile's first two K tiles are
+// queued before the epilogue).  MC_PERSIST_RESID: the residual epilogues too (their x loads then queue behind that LDS-DMA).
+#ifndef MC_PERSIST_RESID
+#define MC_PERSIST_RESID 0
+#endif
+constexpr bool big_persistent(int epi) {
+  return epi == EPI_BF16 || epi == EPI_GELU_BF16 || (MC_PERSIST_RESID && (epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE));
+}
+
 struct FragA {  // one A half of a wave: 64 rows x 64 k = [m block of 16][k step of 32]
   bf16x8 v[4][2];
 };
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
   const int wr = wv >> 2, wc = wv & 3;
 
   // ---- tile mapping: XCD-contiguous, grouped along M so neighbouring tiles share W panels in L2
-  constexpr bool PERSIST = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16);
+  constexpr bool PERSIST = big_persistent(EPI);
   const int ntiles = tilesM * tilesN;
   const int tstride = PERSIST ? (int)gridDim.x : ntiles;
   int m0 = 0, n0 = 0;
@@ -370,58 +379,89 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p, int tile
       bq[nh][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (p.bias) bq[nh][nb] = *(const f32x4*)(p.bias + en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp);
     }
+  constexpr bool RESID = (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE);
+  f32x4 g1[2][2];   // residual epilogues: the gate values of this lane's 4 quads
+  if constexpr (RESID) {
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        g1[nh][nb] = p.gate ? *(const f32x4*)(p.gate + en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp) : f32x4{1.f, 1.f, 1.f, 1.f};
+  }
   const int next_tile = tile + tstride;
   const bool more = PERSIST && next_tile < ntiles;
   if (PERSIST) {
-    // the bias values must have ARRIVED before the next tile's LDS-DMA is queued behind them: the compiler's own wait for
-    // them (it cannot see the asm DMAs) would otherwise also wait for those
+    // the bias (and gate) values must have ARRIVED before the next tile's LDS-DMA is queued behind them: the compiler's own
+    // wait for them (it cannot see the asm DMAs) would otherwise also wait for those
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::"v"(bq[0][0]), "v"(bq[0][1]), "v"(bq[1][0]), "v"(bq[1][1]));
+    if constexpr (RESID) asm volatile("" ::"v"(g1[0][0]), "v"(g1[0][1]), "v"(g1[1][0]), "v"(g1[1][1]));
     if (more) {
       setup_tile(next_tile);
       prologue_dma();
     }
   }
-  if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
+  if constexpr (RESID) {
     // two-phase residual epilogue (gemm_epilogue.h): a batch of quads is loaded together, then added and stored
-    constexpr int MBB = 2;      // m blocks per batch: 8 quads = 32 (+ 16 for the capture's x0) registers, no spills
+    // m blocks per batch and batches in flight: (2, 2) = 16 quads = 64 registers beside the 128 accumulators; the capture
+    // epilogue also carries x0 (2 registers per quad) and a second store stream, so it runs (1, 2)
+#ifndef MC_EPI_MBB
+#define MC_EPI_MBB 2
+#endif
+#ifndef MC_EPI_DEPTH
+#define MC_EPI_DEPTH 2
+#endif
+    constexpr int MBB = (EPI == EPI_RESID_CAPTURE) ? 1 : MC_EPI_MBB;
     auto resid = [&](auto with_sel) {
       constexpr bool SEL = decltype(with_sel)::value;          // per-row choice between two gate vectors (Wan2.2 TI2V)
-      f32x4 g1[2][2], g2[2][2];
+      constexpr int DEPTH = SEL ? 1 : MC_EPI_DEPTH;            // (the second gate vector takes the second batch's registers)
+      f32x4 g2[2][2];
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const int n = en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp;
-          g1[nh][nb] = p.gate ? *(const f32x4*)(p.gate + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-          g2[nh][nb] = SEL ? *(const f32x4*)(p.gate2 + n) : g1[nh][nb];
-        }
-#pragma unroll
-      for (int b0 = 0; b0 < 8; b0 += MBB) {                    // m block index 4 mh + mb
-        ResidIn in[MBB][2][2];
-        uint8_t sel[MBB];
+        for (int nb = 0; nb < 2; ++nb)
+          g2[nh][nb] = SEL ? *(const f32x4*)(p.gate2 + en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp) : g1[nh][nb];
+      // Batches of MBB m blocks (MBB * 4 quads) run through a DEPTH-deep software pipeline: the loads of batch b + DEPTH are
+      // issued right behind the stores of batch b, so the wait in front of batch b + 1 is a COUNTED one (the stores of b and
+      // the loads of b + DEPTH may still be in flight).  Round 3's form (load a batch, wait, add, store, next batch) drained
+      // loads AND the previous batch's stores with vmcnt(0) four times per tile: 4 x (load + store round trip) with the
+      // matrix pipe idle.
+      constexpr int NBATCH = 8 / MBB;
+      ResidIn in[DEPTH][MBB][2][2];
+      uint8_t sel[DEPTH][MBB];
+      auto load_batch = [&](int b, int slot) {
 #pragma unroll
         for (int j = 0; j < MBB; ++j) {
-          const int m = min(em0 + wr * 128 + (b0 + j) * 16 + l15, p.M - 1);   // rows past M: loaded (clamped), not stored
-          sel[j] = SEL ? p.gate_sel[m] : (uint8_t)0;
+          const int m = min(em0 + wr * 128 + (b * MBB + j) * 16 + l15, p.M - 1);   // rows past M: loaded (clamped), not stored
+          sel[slot][j] = SEL ? p.gate_sel[m] : (uint8_t)0;
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-              in[j][nh][nb] = resid_load<EPI>(p, m, en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp);
+              in[slot][j][nh][nb] = resid_load<EPI>(p, m, en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp);
         }
+      };
+      auto apply_batch = [&](int b, int slot) {
 #pragma unroll
         for (int j = 0; j < MBB; ++j) {
-          const int m = em0 + wr * 128 + (b0 + j) * 16 + l15;
+          const int mblk = b * MBB + j;
+          const int m = em0 + wr * 128 + mblk * 16 + l15;
           if (m >= p.M) continue;
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
               resid_apply<EPI>(p, m, en0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp,
-                               acc[(b0 + j) >> 2][(b0 + j) & 3][nh][nb] + bq[nh][nb],
-                               (SEL && sel[j]) ? g2[nh][nb] : g1[nh][nb], in[j][nh][nb]);
+                               acc[mblk >> 2][mblk & 3][nh][nb] + bq[nh][nb],
+                               (SEL && sel[slot][j]) ? g2[nh][nb] : g1[nh][nb], in[slot][j][nh][nb]);
         }
+      };
+#pragma unroll
+      for (int b = 0; b < DEPTH; ++b) load_batch(b, b);
+#pragma unroll
+      for (int b = 0; b < NBATCH; ++b) {
+        apply_batch(b, b % DEPTH);
+        if (b + DEPTH < NBATCH) load_batch(b + DEPTH, b % DEPTH);
       }
     };
     if (p.gate_sel) resid(std::true_type{});
@@ -466,7 +506,7 @@ hipError_t launch_big_t(const GemmParams& p, hipStream_t stream) {
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
   }
-  if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+  if (big_persistent(EPI)) {
     if (grid > n_cu) grid = n_cu;
   }
   hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(grid), dim3(512), 2 * STAGE_BYTES, stream, p,

@@ -64,26 +64,43 @@ def _version_of(t):
         return None
 
 
+def _fingerprint(t):
+    """Two 64-bit checksums of a tensor's BYTES, computed on its device (sum and position-weighted sum of the raw words,
+    wrapping int64 arithmetic): any single changed element changes it.  Only used when MAGCACHE_COMPARE_CONDITIONING=1."""
+    v = t.detach().contiguous()
+    words = v.view(torch.int16 if v.element_size() == 2 else (torch.int32 if v.element_size() == 4 else torch.uint8))
+    w = words.reshape(-1).to(torch.int64)
+    idx = torch.arange(w.numel(), dtype=torch.int64, device=w.device) * 2654435761 + 1
+    return torch.stack([w.sum(), (w * idx).sum()])
+
+
+def _compare_conditioning():
+    return os.environ.get("MAGCACHE_COMPARE_CONDITIONING") == "1"
+
+
 def _tensor_key(t):
     """Identity of a conditioning tensor WITHOUT reading it (a content compare is a device-to-host sync on every
     forward): the tensor object is kept alive, so its storage cannot be recycled for different data, and an in-place
     write bumps `_version`.  A caller that rebuilds the tensor every step only pays the re-upload.
-    Limits (ADVICE r02): writes that bypass the version counter (`.data.copy_()`, `set_()`, a numpy view of a
-    `from_numpy` tensor) are not seen -- conditioning tensors must not be mutated through such paths, or
-    MAGCACHE_COMPARE_CONDITIONING=1 restores the content compare.  Tensors created under `torch.inference_mode()` have
-    no readable counter: they are re-uploaded on every call (correct, just not cached)."""
-    return (t, _version_of(t))
+    Limits (ADVICE r02 / r03): writes that bypass the version counter (`.data.copy_()`, `set_()`, a numpy view of a
+    `from_numpy` tensor) are not seen -- conditioning tensors must not be mutated through such paths.  With
+    MAGCACHE_COMPARE_CONDITIONING=1 the key also carries a checksum of the tensor's bytes taken at upload time
+    (`_fingerprint`) and every later call recomputes and compares it (one small device-to-host sync per conditioning
+    tensor and forward): such writes are then seen too, for the SAME tensor object as well.  Tensors created under
+    `torch.inference_mode()` have no readable counter: they are re-uploaded on every call (correct, just not cached)."""
+    return (t, _version_of(t), _fingerprint(t) if _compare_conditioning() else None)
 
 
 def _same_tensor(key, t):
-    k, ver = key
+    k, ver, fp = key
     now = _version_of(t)
     if ver is None or now is None:          # no counter to trust: treat as changed
         return False
     same = k is t and ver == now or (k.data_ptr() == t.data_ptr() and k.shape == t.shape and k.dtype == t.dtype and
                                      k.device == t.device and ver == _version_of(k) == now)
-    if same and os.environ.get("MAGCACHE_COMPARE_CONDITIONING") == "1" and k is not t:
-        same = bool(torch.equal(k, t))
+    if same and _compare_conditioning():
+        # content check against the checksum taken when the tensor was uploaded (a key made without one is stale)
+        same = fp is not None and bool(torch.equal(fp, _fingerprint(t)))
     return same
 
 
@@ -173,14 +190,18 @@ class WanModelHIP:
             # t * mask).  The engine takes them as a device vector and selects between two modulation sets per token.
             # Limits, checked here because the engine would silently modulate with min / max otherwise: one
             # sample, at least seq_len entries, AT MOST TWO distinct values (what TI2V uses: 0 on the conditioning
-            # frame, the step's t elsewhere).  The value check reads the tensor (one small device sync) and runs only
-            # when the tensor object or its version changes.
+            # frame, the step's t elsewhere).  The value check reads the tensor -- a device-to-host sync -- so it runs only
+            # when the tensor object or its version changes, and NOT AT ALL for a tensor whose builder vouches for it
+            # (`t._mc_two_valued = True`, set by wan22.sample_ti2v on its `mask * t`: a sampler that rebuilds t every step
+            # would otherwise sync on every forward) or with MAGCACHE_VALIDATE_TOKEN_T=0; the engine still
+            # counts the tokens that carry neither value (engine.token_timestep_record()).
             assert t.shape[0] == 1 or t.dim() == 1, "one sample per call"
             tv = t.reshape(-1)
             assert tv.numel() >= self.engine.seq_len, f"t has {tv.numel()} entries, the sequence {self.engine.seq_len}"
             tv = tv[:self.engine.seq_len]
             k = getattr(self, "_tok_t_key", None)
-            if k is None or not _same_tensor(k, t):
+            trusted = getattr(t, "_mc_two_valued", False) or os.environ.get("MAGCACHE_VALIDATE_TOKEN_T") == "0"
+            if not trusted and (k is None or not _same_tensor(k, t)):
                 n = int(torch.unique(tv).numel())
                 if n > 2:
                     raise ValueError(f"per-token timesteps with {n} distinct values: the engine supports at most two "

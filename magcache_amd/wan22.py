@@ -282,6 +282,8 @@ def sample_ti2v(model, noise, context, context_null, sampling_steps=50, shift=5.
     for i in range(sampling_steps):
         t = torch.tensor([float(ts[i])], device=device)
         tt = t if mask_tok is None else mask_tok * t                   # [1, seq_len]: 0 on the conditioning frame
+        if mask_tok is not None:
+            tt._mc_two_valued = True                                   # a 0/1 mask times one scalar: no value check needed
         eps_c = model([latent], t=tt, context=[context], seq_len=seq_len)[0]
         eps_u = model([latent], t=tt, context=[context_null], seq_len=seq_len)[0]
         v = lc([1.0 - guide_scale, guide_scale], [eps_u.contiguous(), eps_c.contiguous()])

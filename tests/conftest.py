@@ -14,6 +14,31 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: full-depth x full-length parity runs (minutes each); MC_SKIP_SLOW=1 skips the 2.5-minute one, the 9-minute one runs only with MC_RUN_SLOW=1")
 
 
+def tolerance_probe(key, value):
+    """record the MEASURED margin behind a tolerance bar (gpurun_out/tolerance_probe.json on the GPU box; the round's copy is
+    committed as profiles/rNN/tolerance_probe.json and the bars in the tests are set from it)"""
+    import json
+    try:
+        path = os.path.join(ROOT, "gpurun_out", "tolerance_probe.json")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = value
+        json.dump(data, open(path, "w"), indent=1)
+    except OSError:
+        pass
+
+
+def calib_errors(got, want):
+    """max |difference| and max relative difference per calibration statistic (lists per step)"""
+    import numpy as np
+    out = {}
+    for k in ("norm_ratio", "norm_std", "cos_dis"):
+        g, w = np.asarray(got[k], dtype=np.float64), np.asarray(want[k], dtype=np.float64)
+        out[k] = dict(max_abs=float(np.abs(g - w).max()), max_rel=float((np.abs(g - w) / np.maximum(np.abs(w), 1e-12)).max()),
+                      min_abs_value=float(np.abs(w).min()))
+    return out
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

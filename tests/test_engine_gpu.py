@@ -13,6 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from conftest import tolerance_probe as _probe  # noqa: E402  measured margins of the tolerance bars, for the record
 from magcache_amd import _lib  # noqa: E402
 from magcache_amd import model as M  # noqa: E402
 from magcache_amd.engine import Engine, MC_MODE_FULL, MC_MODE_SKIP  # noqa: E402
@@ -304,16 +305,6 @@ def test_magcache_loop_vs_reference_golden(golden, hip_model):
     assert r.dtype == torch.float32 and tuple(r.shape) == (L, meta["cfg"]["dim"]) and bool(torch.isfinite(r).all())
 
 
-def _probe(key, value):
-    """measured margins of the tolerance bars, for the record (gpurun_out/tolerance_probe.json)"""
-    try:
-        path = os.path.join(ROOT, "gpurun_out", "tolerance_probe.json")
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        data = json.load(open(path)) if os.path.exists(path) else {}
-        data[key] = value
-        json.dump(data, open(path, "w"), indent=1)
-    except OSError:
-        pass
 
 
 def test_skip_is_exactly_cached_residual_add(golden, hip_model):
@@ -342,12 +333,13 @@ def test_calibration_vs_reference_golden(golden, hip_model, golden_dir, tmp_path
     sample(hip_model, x, torch.from_numpy(g["ctx"]).to(DEV), torch.from_numpy(g["ctx_null"]).to(DEV),
            sampling_steps=steps, shift=meta["shift"], guide_scale=meta["guide"])
     assert len(hip_model.norm_ratio) == 2 * steps - 2
-    # tolerance: the statistics are means over 360 tokens of bf16-noisy residuals
+    # tolerance: the reference's mag_ratios tables carry 5 decimals (magcache_generate.py:910-912); the measured differences
+    # from the golden of the reference's own magcache_calibration are <= 1e-4 (profiles/r03/tolerance_probe.json), bar 5e-4
     _probe("calibration_vs_golden", {k: float(np.abs(np.array(getattr(hip_model, k)) - np.array(want[k])).max())
                                      for k in ("norm_ratio", "norm_std", "cos_dis")})
-    np.testing.assert_allclose(hip_model.norm_ratio, want["norm_ratio"], atol=1e-2)
-    np.testing.assert_allclose(hip_model.norm_std, want["norm_std"], atol=1e-2)
-    np.testing.assert_allclose(hip_model.cos_dis, want["cos_dis"], atol=1e-2)
+    np.testing.assert_allclose(hip_model.norm_ratio, want["norm_ratio"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(hip_model.norm_std, want["norm_std"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(hip_model.cos_dis, want["cos_dis"], rtol=0, atol=5e-4)
     assert json.load(open(tmp_path / "wan2_1_mag_ratio.json")) == hip_model.norm_ratio
     M.disable_magcache(hip_model)
 
