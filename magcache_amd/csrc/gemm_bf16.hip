@@ -245,8 +245,14 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
       big = 1.3 * fill_efficiency(tiles_big, 256) >= fill_efficiency(tiles_small, 512);
     }
   }
-  if (g_gemm_kernel == 4 && gemm_bf16_v2_supported(p) &&
-      (epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE || epi == EPI_F32))
+  // generation 2 (4 waves x 128 x 128, generated stream, round 4: schedule "h" + row-major epilogues) takes the three hot
+  // epilogues wherever the 8-wave kernel would run: +16 % QKV, +17 % cross-attention Q, +9 % O + residual, +3.5 % FFN-1,
+  // +1.7 % FFN-2 in one interleaved run (profiles/r04/kbench_gemm_v2h_lean.log), bit-identical results.  gemm_kernel = 4
+  // forces it for every epilogue it has (the others run its generic, slow epilogue code), 2 forces the 8-wave kernel.
+  const bool v2_epi = epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE;
+  if (gemm_bf16_v2_supported(p) &&
+      ((g_gemm_kernel == 0 && big && v2_epi) ||
+       (g_gemm_kernel == 4 && (v2_epi || epi == EPI_RESID_CAPTURE || epi == EPI_F32))))
     return launch_gemm_bf16_v2(p, epi, stream);
 #ifdef MC_AB_KERNELS
   if (g_gemm_kernel == 3 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&

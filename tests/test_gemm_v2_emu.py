@@ -92,8 +92,14 @@ def test_gemm_v2_inc_file_is_current():
     cfg = open(os.path.join(ROOT, "magcache_amd", "csrc", "gemm_v2_config.h")).read()
     gen.MFMA = 32 if "MC_GEMM_V2_MFMA 32" in cfg else 16
     gen.ROW = 128 if "MC_GEMM_V2_ROW 128" in cfg else 64
+    gen.PERSIST = 1 if "MC_GEMM_V2_PERSIST 1" in cfg else 0
+    gen.SCHED = "h" if "MC_GEMM_V2_SCHED_H 1" in cfg else "r3"
     inc = os.path.join(ROOT, "magcache_amd", "csrc", "gemm_v2_body.inc")
-    assert open(inc).read() == gen.to_inc(gen.generate()), "regenerate with: python tools/gen_gemm_v2.py --write"
+    try:
+        assert open(inc).read() == gen.to_inc(gen.generate()), \
+            "regenerate with: python tools/gen_gemm_v2.py --write --mfma 16 --row 128 --persist 1 --sched h"
+    finally:
+        gen.PERSIST, gen.SCHED = 0, "r3"
 
 
 # ---------------------------------------------------------------- persistent form (ROW 128): two trips of one workgroup
@@ -117,16 +123,18 @@ def _read_acc16(m):
     return got
 
 
-@pytest.mark.parametrize("dma_late,load_late", [(False, False), (True, True)])
-def test_gemm_v2_persistent_trips_hand_the_ring_over(dma_late, load_late):
+@pytest.mark.parametrize("sched,K", [("r3", 384), ("h", 256), ("h", 384), ("h", 768)])
+@pytest.mark.parametrize("dma_late,load_late", [(False, False), (True, True), (True, False), (False, True)])
+def test_gemm_v2_persistent_trips_hand_the_ring_over(dma_late, load_late, sched, K):
     """trip 1 (first = 1) computes tile X and, during its last two K tiles, fetches K tiles 0, 1 of tile Y; the registers
-    are then scrambled (the C++ epilogue owns them); trip 2 (first = 0, no next tile) starts from the queued fetches"""
-    gen.MFMA, gen.ROW, gen.PERSIST = 16, 128, 1
+    are then scrambled (the C++ epilogue owns them); trip 2 (first = 0, no next tile) starts from the queued fetches.
+    sched "h" = the round-4 schedule (slot released operand by operand, counted waits)."""
+    gen.MFMA, gen.ROW, gen.PERSIST, gen.SCHED = 16, 128, 1, sched
     try:
         text = _bind_n(gen.generate(), 14) + "  s_endpgm\n"
     finally:
-        gen.PERSIST = 0
-    K, lda = 384, 384
+        gen.PERSIST, gen.SCHED = 0, "r3"
+    lda = K
     rng = np.random.default_rng(17)
     mats = [emu.bf16_to_f32(emu.bf16_rne(rng.standard_normal((256, lda)).astype(np.float32))) for _ in range(4)]   # Ax Wx Ay Wy
     bases = [0x1000_0000, 0x2000_0000, 0x3000_0000, 0x4000_0000]

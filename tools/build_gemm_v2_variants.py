@@ -2,6 +2,7 @@
 """Build stream variants of gemm_bf16_v2 for interleaved A/B runs (tools/kbench.bin with KBENCH_OPT_i=gemm_kernel=4):
 
     tools/build_gemm_v2_variants.py  r128:mfma=16,row=128  r128p:mfma=16,row=128,persist=1  m32:mfma=32,row=64
+    tools/build_gemm_v2_variants.py  h:mfma=16,row=128,persist=1,sched=h
 
 Each variant gets build_variants/g2_<name>/libmagcache_hip.so = the shipped objects with gemm_bf16_v2.hip recompiled against
 that variant's generated stream (tools/gen_gemm_v2.py)."""
@@ -20,14 +21,21 @@ for spec in sys.argv[1:]:
     name, _, rest = spec.partition(":")
     kv = dict(x.split("=") for x in rest.split(",") if x)
     gen.MFMA, gen.ROW, gen.PERSIST = int(kv.get("mfma", 16)), int(kv.get("row", 64)), int(kv.get("persist", 0))
+    gen.SCHED = kv.get("sched", "r3")
+    for k, val in kv.items():                 # any further generator knob, e.g. H_RD=2
+        if k.isupper():
+            setattr(gen, k, int(val))
     out = os.path.join(ROOT, "build_variants", "g2_" + name)
     os.makedirs(out, exist_ok=True)
     text = gen.generate()
     open(os.path.join(out, "gemm_v2_body.inc"), "w").write(gen.to_inc(text))
     open(os.path.join(out, "gemm_v2_clobbers.inc"), "w").write(gen.clobbers())
-    open(os.path.join(out, "gemm_v2_config.h"), "w").write("#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n#define MC_GEMM_V2_PERSIST %d\n" % (gen.MFMA, gen.ROW, gen.PERSIST))
+    open(os.path.join(out, "gemm_v2_config.h"), "w").write(gen.config_h())
     obj = os.path.join(out, "gemm_bf16_v2.hip.o")
-    defs = [f'-DMC_GEMM_V2_BODY="{out}/gemm_v2_body.inc"', f'-DMC_GEMM_V2_CLOBBERS="{out}/gemm_v2_clobbers.inc"',
+    extra = ["-DMC_V2_NO_EPI"] if kv.get("noepi") else []
+    if kv.get("epiabl"):
+        extra.append("-DMC_V2_EPI_ABL=" + kv["epiabl"])
+    defs = extra + [f'-DMC_GEMM_V2_BODY="{out}/gemm_v2_body.inc"', f'-DMC_GEMM_V2_CLOBBERS="{out}/gemm_v2_clobbers.inc"',
             f'-DMC_GEMM_V2_CONFIG="{out}/gemm_v2_config.h"']
     subprocess.check_call([B.HIPCC] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, "gemm_bf16_v2.hip"), "-o", obj],
                           )

@@ -80,6 +80,19 @@ ROW = 64                     # bytes of a row in the LDS ring.  64: ring of four
                              # Built and emulator-validated at the end of round 3, NOT yet measured (no GPU minutes left).
 
 
+SCHED = "r3"                 # (ROW 128) schedule of a K tile:
+                             # "r3" (round 3): the whole tile kt+2 is fetched during the second k-step of tile kt behind ONE
+                             #   vmcnt(0) + barrier per k-step: measured 1089-1127 TF on the QKV shape, the waves parked 32 % of
+                             #   their cycles at that wait (profiles/r04/pmc_gemm_qkv_g2_r128p.txt).
+                             # "h" (round 4): the cadence of the library's hand-scheduled 256x256x64 kernel (read from its code
+                             #   object: 4 waves, 128x128 wave tiles, LDS-DMA, two tiles in flight): the ring slot of tile kt is
+                             #   released OPERAND BY OPERAND as soon as its last fragment has been read -- W after 8 reads
+                             #   (barrier at gap 19), A after the next 8 (barrier at gap 51) -- and re-filled with tile kt+2
+                             #   right away (lead ~150 MFMAs instead of ~80); the landing of tile kt+1 is awaited per operand
+                             #   with COUNTED waits (vmcnt(20) at gap 67, vmcnt(16) at gap 104), never vmcnt(0); one LDS read or
+                             #   one LDS-DMA piece per two MFMA gaps.  Always the persistent form.
+
+
 def frag(p, op, blk, ks=0):
     """16 x 16 x 32: blk = 16-row block 0..7;  32 x 32 x 16: blk = 32-row block 0..3, ks = k-step of 16"""
     idx = blk if MFMA == 16 else blk * 2 + ks
@@ -265,7 +278,7 @@ V_B128 = 156                 # ROW 128: fragment read bases [A | W][k-step][slot
 V_S128 = 164                 # ROW 128: LDS-DMA source offsets [A | W][8 pieces] = v164..v179
 
 
-def emit_prologue128(e):
+def emit_prologue128(e, fetch=True):
     V_SA, V_SW = V_S128, V_S128 + 8
     e.c("---- inputs -> fixed SGPRs")
     for k, dst in enumerate((s(S_A, 2), s(S_W, 2), s(S_LDA), s(S_LDW), s(S_NK), s(S_WV), s(S_LDS), s(S_ANREC), s(S_WNREC))):
@@ -329,6 +342,8 @@ def emit_prologue128(e):
     e.c("---- accumulators = 0")
     for r in range(256):
         e.i(f"v_accvgpr_write_b32 {a(r)}, 0")
+    if not fetch:
+        return
     e.c("---- K tiles 0, 1 on their way; fragments of (tile 0, k-step 0)")
     if PERSIST:
         e.i(f"s_cmp_eq_u32 {s(S_FIRST)}, 0")
@@ -389,8 +404,128 @@ def emit_tile128(e, b, nxt=False):
     e.i(f"s_add_u32 {s(S_DCUR2 if nxt else S_DCUR)}, {s(S_DCUR2 if nxt else S_DCUR)}, 128")
     e.i("s_waitcnt lgkmcnt(0)")
 
+ABL = 0                      # schedule "h" timing ablations (results WRONG by construction; the prologue always runs, so every
+                             # register holds finite data): 1 no fragment reads in the loop, 2 no LDS-DMA, 4 no barriers,
+                             # 8 no s_waitcnt in the loop
+
+
+def emit_tile_h(e, b, nxt=False):
+    """SCHED "h": K tile kt = 2 trip + b in ring slot b; fragment buffer 0 = k-step 0, buffer 1 = k-step 1.
+    gaps   0..14   reads of W (kt, k-step 1)                                  | MFMAs 0..63 on buffer 0
+    gap    18/19   lgkmcnt(0), barrier: every wave is done with the W rows of slot b
+    gaps  21..44   LDS-DMA of the 8 W pieces of tile kt+2 -> slot b  ||  reads of A (kt, k-step 1)
+    gap    50/51   lgkmcnt(0), barrier: every wave is done with the A rows of slot b
+    gaps  53..62   LDS-DMA of A pieces 0..3 of tile kt+2                      | MFMAs 64..127 on buffer 1
+    gap    67/68   vmcnt(20), barrier: the W rows of tile kt+1 (slot 1-b) have landed for every wave
+    gaps  69..83   reads of W (kt+1, k-step 0)  ||  gaps 86..95 LDS-DMA of A pieces 4..7
+    gap  104/105   vmcnt(16), barrier: the A rows of tile kt+1 have landed
+    gaps 106..120  reads of A (kt+1, k-step 0)
+    In-order retirement per wave, issue order W0..7 A0..7 per tile: at gap 67 this tile's 12 pieces and the previous tile's
+    8 A pieces may be in flight (20), at gap 104 only this tile's 16."""
+    e.c(f"---- K tile body {b} (schedule h)")
+    plan = {}
+
+    def at(g, fn, kind=0):
+        if not (ABL & kind):
+            plan.setdefault(g, []).append(fn)
+
+    def m0_of(op, j):
+        return lambda: e.i(f"s_add_u32 m0, {s(S_LDSW)}, {b * 65536 + (0 if op == 'A' else 32768) + j * 1024}")
+
+    def dma_of(op, j):
+        src, srd = (V_S128, S_ASRD2 if nxt else S_ASRD) if op == "A" else (V_S128 + 8, S_WSRD2 if nxt else S_WSRD)
+        return lambda: e.i(f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(S_DCUR2 if nxt else S_DCUR)} offen lds")
+
+    def read_of(p, op, blk, slot, ks):
+        return lambda: frag_read128(e, p, op, blk, slot, ks)
+
+    for i in range(8):
+        at(2 * i, read_of(1, "W", i, b, 1), 1)
+    at(18, lambda: e.i("s_waitcnt lgkmcnt(0)"), 8)
+    at(19, lambda: e.i("s_barrier"), 4)
+    for i in range(8):
+        at(20 + 3 * i, m0_of("W", i), 2)
+        at(21 + 3 * i, dma_of("W", i), 2)
+        at(23 + 3 * i, read_of(1, "A", i, b, 1), 1)
+    at(50, lambda: e.i("s_waitcnt lgkmcnt(0)"), 8)
+    at(51, lambda: e.i("s_barrier"), 4)
+    for i in range(4):
+        at(52 + 3 * i, m0_of("A", i), 2)
+        at(53 + 3 * i, dma_of("A", i), 2)
+    at(67, lambda: e.i("s_waitcnt vmcnt(20)"), 8)
+    at(68, lambda: e.i("s_barrier"), 4)
+    for i in range(8):
+        at(69 + 2 * i, read_of(0, "W", i, 1 - b, 0), 1)
+    for i in range(4):
+        at(85 + 3 * i, m0_of("A", 4 + i), 2)
+        at(86 + 3 * i, dma_of("A", 4 + i), 2)
+    at(104, lambda: e.i("s_waitcnt vmcnt(16)"), 8)
+    at(105, lambda: e.i("s_barrier"), 4)
+    for i in range(8):
+        at(106 + 2 * i, read_of(0, "A", i, 1 - b, 0), 1)
+    cur = S_DCUR2 if nxt else S_DCUR
+    at(122, lambda: e.i(f"s_add_u32 {s(cur)}, {s(cur)}, 128"))
+    g = 0
+    for ks in range(2):
+        for nb in range(8):
+            for mb in range(8):
+                e.i(f"v_mfma_f32_16x16x32_bf16 {a(acc(nb, mb), 4)}, {v(frag(ks, 'W', nb), 4)}, {v(frag(ks, 'A', mb), 4)}, {a(acc(nb, mb), 4)}")
+                for fn in plan.get(g, []):
+                    fn()
+                g += 1
+    if not (ABL & 8):
+        e.i("s_waitcnt lgkmcnt(0)")
+
+
+def emit_prologue_h(e):
+    """as emit_prologue128 up to the fetches; then K tiles 0, 1 in the order the loop expects (W pieces before A pieces)"""
+    emit_prologue128(e, fetch=False)
+    e.c("---- K tiles 0, 1 on their way (W before A, like every later tile); fragments of (tile 0, k-step 0)")
+    e.i(f"s_cmp_eq_u32 {s(S_FIRST)}, 0")
+    e.i("s_cbranch_scc1 L_queued")
+    for st in range(2):
+        for op in "WA":
+            for j in range(8):
+                dma_piece128(e, op, j, st)
+        e.i(f"s_add_u32 {s(S_DCUR)}, {s(S_DCUR)}, 128")
+    e.i("s_waitcnt vmcnt(16)")
+    e.i("s_branch L_fetching")
+    # The previous trip queued K tiles 0, 1 of this output tile.  CONTRACT with the kernel around the statement (schedule h):
+    # it waits vmcnt(0) right BEHIND the previous statement, before its epilogue issues anything -- so both tiles have landed
+    # and NO wait is needed here; the epilogue's stores may still be in flight (a vmcnt(0) here waited for all of them: the
+    # whole output tile's write-back with the matrix pipe idle).  They are older than every LDS-DMA of this trip, so the
+    # counted waits of the loop stay correct (stricter, never laxer).
+    e.label("L_queued")
+    e.i(f"s_mov_b32 {s(S_DCUR)}, 256")
+    e.label("L_fetching")
+    e.i("s_barrier")
+    for blk in range(8):
+        frag_read128(e, 0, "W", blk, 0, 0)
+        frag_read128(e, 0, "A", blk, 0, 0)
+    e.i("s_waitcnt lgkmcnt(0)")
+    e.i(f"s_lshr_b32 {s(S_IT)}, {s(S_NK)}, 2")                          # nk counts 32-k steps: trips of the 2-tile loop
+
 
 def generate():
+    if ROW == 128 and SCHED == "h":
+        assert MFMA == 16 and PERSIST
+        e = E()
+        emit_prologue_h(e)
+        e.i(f"s_mov_b32 {s(S_DCUR2)}, 0")
+        e.label("L_loop")
+        e.i(f"s_cmp_eq_u32 {s(S_IT)}, 1")
+        e.i("s_cbranch_scc1 L_lasttrip")
+        for b in range(2):
+            emit_tile_h(e, b)
+        e.i(f"s_sub_u32 {s(S_IT)}, {s(S_IT)}, 1")
+        e.i("s_branch L_loop")
+        e.label("L_lasttrip")
+        for b in range(2):
+            emit_tile_h(e, b, nxt=True)
+        # the next tile's K tiles 0, 1 stay in flight under the epilogue (the caller drains them behind its last tile)
+        e.i("s_nop 15")
+        e.i("s_nop 15")
+        return "\n".join(e.lines) + "\n"
     if ROW == 128:
         assert MFMA == 16
         e = E()
@@ -446,6 +581,11 @@ def to_inc(text):
     return "\n".join(out) + "\n"
 
 
+def config_h():
+    return ("// GENERATED by tools/gen_gemm_v2.py\n#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n#define MC_GEMM_V2_PERSIST %d\n"
+            "#define MC_GEMM_V2_SCHED_H %d\n" % (MFMA, ROW, PERSIST, 1 if SCHED == "h" else 0))
+
+
 def clobbers():
     # v0..v191: fragments, bases, offsets, temporaries (the highest register any layout uses is v179); v192..v255 stay with
     # the compiler (the persistent kernel needs a few for SGPR spills across the statement)
@@ -462,14 +602,16 @@ def clobbers():
 
 
 def main():
-    global MFMA, ROW, PERSIST
+    global MFMA, ROW, PERSIST, SCHED
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--asm")
     ap.add_argument("--mfma", type=int, default=MFMA)
     ap.add_argument("--row", type=int, default=ROW)
     ap.add_argument("--persist", type=int, default=PERSIST)
+    ap.add_argument("--sched", default=SCHED)
     args = ap.parse_args()
+    SCHED = args.sched
     MFMA = args.mfma
     ROW = args.row
     PERSIST = args.persist
@@ -481,7 +623,7 @@ def main():
         d = os.path.join(root, "magcache_amd", "csrc")
         open(os.path.join(d, "gemm_v2_body.inc"), "w").write(to_inc(text))
         open(os.path.join(d, "gemm_v2_clobbers.inc"), "w").write(clobbers())
-        open(os.path.join(d, "gemm_v2_config.h"), "w").write("// GENERATED by tools/gen_gemm_v2.py\n#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n#define MC_GEMM_V2_PERSIST %d\n" % (MFMA, ROW, PERSIST))
+        open(os.path.join(d, "gemm_v2_config.h"), "w").write(config_h())
     n = sum(1 for l in text.splitlines() if l.startswith("  ") and not l.strip().startswith(";"))
     print(f"{n} instructions", file=sys.stderr)
 
