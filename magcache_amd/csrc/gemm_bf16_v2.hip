@@ -61,6 +61,16 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
   const uint32_t lds0 = (uint32_t)(uintptr_t)MC_LDS_PTR(smem);
 
 #if MC_GEMM_V2_PERSIST
+#ifndef MC_V2_STAGGER
+#define MC_V2_STAGGER 0
+#endif
+  // (experiment) de-phased start for the residual epilogues: with every CU in its epilogue at once the x read-modify-write
+  // is HBM-bound (134 MB per round of tiles) while the memory system idles during the main loops; four phase groups per
+  // XCD start MC_V2_STAGGER x ~4 us apart
+  if constexpr (EPI == EPI_RESID_GATE && MC_V2_STAGGER > 0) {
+    const int ph = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < ph * MC_V2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...: the asm statement is one trip; its last two K tiles fetch
   // the first two of the NEXT output tile, which land in the LDS ring under the epilogue below (tools/gen_gemm_v2.py)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -185,23 +195,32 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       // the rows past M through the check)
       // residual form: the 8 x loads of m block mb + 1 are issued BEFORE m block mb is transposed and applied (two register
       // sets), pinned there by sched_barrier: the waits in front of the adds are then counted ones
-      f32x4 xin[2][4][2];
+#ifndef MC_V2_XAHEAD
+#define MC_V2_XAHEAD 1
+#endif
+      constexpr int XA = MC_V2_XAHEAD, XS = XA + 1;     // m blocks loaded ahead, register sets
+      f32x4 xin[XS][4][2];
       auto load_x = [&](int mb, int set) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
+#if MC_V2_EPI_ABL == 4    // timing ablation: no x loads
+          xin[set][i][0] = xin[set][i][1] = gA;
+#else
           xin[set][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow, 0, 0));
           xin[set][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow + 16, 0, 0));
+#endif
         }
       };
       if constexpr (EPI == EPI_RESID_GATE) {
-        load_x(0, 0);
+#pragma unroll
+        for (int b = 0; b < XA; ++b) load_x(b, b);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int mb = 0; mb < 8; ++mb) {
         if constexpr (EPI == EPI_RESID_GATE) {
-          if (mb + 1 < 8) load_x(mb + 1, (mb + 1) & 1);
+          if (mb + XA < 8) load_x(mb + XA, (mb + XA) % XS);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
           const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
           if constexpr (EPI == EPI_RESID_GATE) {
             // x[row][8 c16 .. + 7] += gate * bf16 value (the Linear's output was rounded to bf16 above, like autocast)
-            f32x4 xa = xin[mb & 1][i][0], xb = xin[mb & 1][i][1];
+            f32x4 xa = xin[mb % XS][i][0], xb = xin[mb % XS][i][1];
             const u32x4 w = rowv[i];
             xa[0] += __uint_as_float(w[0] << 16) * gA[0];
             xa[1] += __uint_as_float(w[0] & 0xffff0000u) * gA[1];
@@ -231,8 +250,12 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
             xb[1] += __uint_as_float(w[2] & 0xffff0000u) * gB[1];
             xb[2] += __uint_as_float(w[3] << 16) * gB[2];
             xb[3] += __uint_as_float(w[3] & 0xffff0000u) * gB[3];
+#if MC_V2_EPI_ABL == 3    // timing ablation: no x stores
+            asm volatile("" ::"v"(xa), "v"(xb));
+#else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xa), rio, vrow, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb), rio, vrow + 16, 0, 0);
+#endif
           } else {
             __builtin_amdgcn_raw_buffer_store_b128(rowv[i], rio, vrow, 0, 0);
           }

@@ -11,7 +11,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: full-depth x full-length parity runs (minutes each); MC_SKIP_SLOW=1 skips the 2.5-minute one, the 9-minute one runs only with MC_RUN_SLOW=1")
+    config.addinivalue_line("markers", "slow: full-depth x full-length parity runs (minutes each); they run only with MC_RUN_SLOW=1 (tools/gpu_session.sh <tag> pytest_slow)")
 
 
 def tolerance_probe(key, value):

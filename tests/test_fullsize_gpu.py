@@ -187,7 +187,8 @@ def test_wan14_one_block_720p_length():
 
 
 @pytest.mark.slow
-@pytest.mark.skipif(os.environ.get("MC_SKIP_SLOW") == "1", reason="MC_SKIP_SLOW=1")
+@pytest.mark.skipif(os.environ.get("MC_RUN_SLOW") != "1", reason="2.5 minutes on one MI355X: set MC_RUN_SLOW=1 (tools/gpu_session.sh "
+                    "pytest_slow); its last run is profiles/r04/fullsize_parity.json")
 def test_wan14_forty_layers_720p_full_length_error_growth():
     """BASELINE.json config 3's model at full depth AND full length on one GPU: Wan2.1-T2V-14B, 40 layers, 720p 81 frames
     = 75 600 tokens (reference call path MagCache4Wan2.1/magcache_generate.py:297-305), per-layer error growth against

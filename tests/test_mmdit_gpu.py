@@ -119,10 +119,11 @@ def test_flux_calibration_vs_reference_golden(flux):
             x = x + float(sig[i + 1] - sig[i]) * o
     assert len(cls.norm_ratio) == steps - 2
     tolerance_probe("flux_calibration_vs_golden", calib_errors({k: getattr(cls, k) for k in ("norm_ratio", "norm_std", "cos_dis")}, want))
-    # tolerance: statistics of bf16-operand residuals against the fp32 reference run
-    np.testing.assert_allclose(cls.norm_ratio, want["norm_ratio"], rtol=2e-2, atol=2e-3)
-    np.testing.assert_allclose(cls.norm_std, want["norm_std"], rtol=5e-2, atol=3e-3)
-    np.testing.assert_allclose(cls.cos_dis, want["cos_dis"], rtol=5e-2, atol=2e-3)
+    # bars = 3x the measured differences (profiles/r04/tolerance_probe.json: 3.1e-4 / 1.6e-4 / 1.2e-4 for FLUX, 2.8e-4 /
+    # 7e-5 / 1e-4 for HunyuanVideo); the reference's tables carry 5 decimals
+    np.testing.assert_allclose(cls.norm_ratio, want["norm_ratio"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(cls.norm_std, want["norm_std"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(cls.cos_dis, want["cos_dis"], rtol=0, atol=4e-4)
     cls.forward = MM.flux_plain_forward
 
 
@@ -217,9 +218,11 @@ def test_hunyuan_calibration_vs_reference_golden(hunyuan):
             x = x + float(sig[i + 1] - sig[i]) * o
     assert len(cls.norm_ratio) == steps - 1
     tolerance_probe("hunyuan_calibration_vs_golden", calib_errors({k: getattr(cls, k) for k in ("norm_ratio", "norm_std", "cos_dis")}, want))
-    np.testing.assert_allclose(cls.norm_ratio, want["norm_ratio"], rtol=2e-2, atol=2e-3)
-    np.testing.assert_allclose(cls.norm_std, want["norm_std"], rtol=5e-2, atol=3e-3)
-    np.testing.assert_allclose(cls.cos_dis, want["cos_dis"], rtol=5e-2, atol=2e-3)
+    # bars = 3x the measured differences (profiles/r04/tolerance_probe.json: 3.1e-4 / 1.6e-4 / 1.2e-4 for FLUX, 2.8e-4 /
+    # 7e-5 / 1e-4 for HunyuanVideo); the reference's tables carry 5 decimals
+    np.testing.assert_allclose(cls.norm_ratio, want["norm_ratio"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(cls.norm_std, want["norm_std"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(cls.cos_dis, want["cos_dis"], rtol=0, atol=4e-4)
     cls.forward = MM.hunyuan_plain_forward
     cls.cnt = 0
 

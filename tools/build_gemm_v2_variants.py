@@ -33,6 +33,10 @@ for spec in sys.argv[1:]:
     open(os.path.join(out, "gemm_v2_config.h"), "w").write(gen.config_h())
     obj = os.path.join(out, "gemm_bf16_v2.hip.o")
     extra = ["-DMC_V2_NO_EPI"] if kv.get("noepi") else []
+    if kv.get("xahead"):
+        extra.append("-DMC_V2_XAHEAD=" + kv["xahead"])
+    if kv.get("stagger"):
+        extra.append("-DMC_V2_STAGGER=" + kv["stagger"])
     if kv.get("epiabl"):
         extra.append("-DMC_V2_EPI_ABL=" + kv["epiabl"])
     defs = extra + [f'-DMC_GEMM_V2_BODY="{out}/gemm_v2_body.inc"', f'-DMC_GEMM_V2_CLOBBERS="{out}/gemm_v2_clobbers.inc"',
