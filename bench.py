@@ -236,7 +236,41 @@ def cpu_baseline(cfg, max_threads):
                 seconds_per_forward_extrapolated=t_full)
 
 
+STAGE = ["start"]        # where a failure happened (reported in the error line of a multi-GPU run)
+
+
+def stage(name):
+    STAGE[0] = name
+
+
 def main():
+    """N > 1: every failure -- an exception in any self-check, a collective that times out (3 minutes, set at
+    init_process_group), a layout that does not fit -- ends in ONE parseable JSON line from rank 0 with "value": null,
+    "error" and "stage" instead of a traceback only (the scaling run is the first time this code meets more than one GPU)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return bench_main()
+    try:
+        return bench_main()
+    except BaseException as e:   # noqa: BLE001  (SystemExit from argparse included: the line is the contract)
+        import traceback
+        if rank == 0:
+            print(json.dumps({"metric": "denoising steps/sec (MagCache on), Wan2.1-T2V-1.3B 480p 81f", "value": None,
+                              "unit": "steps/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
+                              "error": f"{type(e).__name__}: {e}"[:2000], "stage": STAGE[0],
+                              "traceback_tail": traceback.format_exc()[-1500:]}), flush=True)
+        else:
+            sys.stderr.write(f"[rank {rank}] failed at stage {STAGE[0]}: {type(e).__name__}: {e}\n")
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+        raise SystemExit(1 if not isinstance(e, SystemExit) else e.code)
+
+
+def bench_main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -316,10 +350,14 @@ def main():
         extra["rccl_world"] = int(ones[0])
         extra["comm_backend"] = dist.get_backend()
     if world > 1:
+        import datetime
+        stage("init_process_group")
+        tmo = datetime.timedelta(seconds=int(os.environ.get("MC_BENCH_COLLECTIVE_TIMEOUT_S", "180")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(device))
+            dist.init_process_group("nccl", device_id=torch.device(device), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        stage("first all-reduce")
         # how many ranks really joined the communicator (an all-reduce of ones on the data-path backend)
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)
@@ -329,12 +367,22 @@ def main():
         if args.layout != "auto":
             assert args.layout in names, f"--layout {args.layout} needs an even number of ranks"
             names = [args.layout]
+        stage("process groups")
         layouts = {n: PAR.ParallelLayout(cfg_parallel=(n == "cfg2sp")) for n in names}   # every rank builds every group
         models = {}
+        # memory: --layout auto holds one engine per candidate layout on every GPU until the ablation has chosen
+        # (weights + workspace each: 2.8 + 2.1 GB at 1.3B); refuse early, with the numbers, rather than fail in hipMalloc
+        free_b, total_b = torch.cuda.mem_get_info()
+        need_b = len(names) * 6.5e9
+        extra["hbm_free_gb_at_start"] = round(free_b / 1e9, 1)
+        if free_b < need_b:
+            raise RuntimeError(f"{len(names)} engines need ~{need_b / 1e9:.0f} GB, {free_b / 1e9:.1f} GB free of {total_b / 1e9:.0f} GB "
+                               "(use --layout sp or --layout cfg2sp to build one)")
         # ---- sequence-parallel self-check: the overlapped forward (local-shard attention beside the K/V all-gather)
         # must agree with the serialised one; otherwise run without the overlap
         check_name = next((n for n in names if layouts[n].sp_size > 1), None)
         if check_name is not None:
+            stage("sequence-parallel self-check")
             models[check_name] = make_model(layouts[check_name], check_name)
             m = M.disable_magcache(models[check_name])
             tt = torch.tensor([500.0], device=device)
@@ -356,6 +404,7 @@ def main():
             extra["rccl_inplace_gather"] = getattr(sp, "inplace_checked", None)
         # ---- layout ablation: 2 no-cache steps of every candidate after 1 untimed step; the faster one is benchmarked
         if len(names) > 1:
+            stage("layout ablation")
             abl = {}
             for n in names:
                 if n not in models:
@@ -382,8 +431,10 @@ def main():
         model = make_model(None, "single")
 
     M.disable_magcache(model)
+    stage("warm-up")
     if args.warmup > 0:
         run(model, layout, args.warmup)
+    stage("timed region 1 (MagCache)")
     # ---- timed region 1: K steps with MagCache
     M.init_magcache(model, args.steps, args.magcache_thresh, args.magcache_K, args.retention_ratio,
                     mag_ratios=TABLES["wan2.1_t2v_1.3B"])
@@ -401,6 +452,7 @@ def main():
         skipped = int(cnt[0])
     # ---- timed region 2: the same K steps with the cache off
     t_nc, psnr, attn_live = None, None, None
+    stage("timed region 2 (no cache)")
     if not args.no_nocache:
         M.disable_magcache(model)
         # hipEvent pairs around every self-attention launch of THIS timed region, on the launch stream
@@ -415,6 +467,7 @@ def main():
         t_mc = max_over_ranks(t_mc)
         t_nc = max_over_ranks(t_nc) if t_nc is not None else None
 
+    stage("report")
     if rank == 0:
         # the shim caches the text context per prompt (mc_set_context): its K / V projections are not in the forwards
         fl = flops_forward(cfg, SEQ, ctx_cached=True)
@@ -472,8 +525,9 @@ def main():
                                 "avg_launch_ms": attn_live[0] / attn_live[1],
                                 "measured": "rank 0, hipEvent pairs around every self-attention launch of the timed "
                                             "no-cache region; per-GPU rate",
-                                "kernel": "self-attention (attn_fwd_v5_kernel for one key shard, attn_fwd_v3_kernel for the "
-                                          "sequence-parallel two-phase form)"}
+                                "kernel": "self-attention, attn_fwd_v5_kernel (32x32x16 lazy / pipelined stream) for every form of "
+                                          "the call: one key shard, and the sequence-parallel local-shard + remote-shards "
+                                          "launches with the log-sum-exp merge"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
         print(json.dumps(line), flush=True)

@@ -68,7 +68,7 @@ def wan_case(cfg, grid, seed, q_scale, ctx_valid):
     lat = torch.randn(16, *grid, generator=g, device=DEV)
     ctx = torch.randn(512, cfg["text_dim"], generator=g, device=DEV)[:ctx_valid].contiguous()
     t = torch.tensor([487.0], device=DEV)
-    oracle = FC.build_wan_oracle(cfg, sd, DEV)
+    oracle = FC.build_wan_oracle({k: v for k, v in cfg.items() if k != "fp8_linear"}, sd, DEV)
     eng = Engine(cfg, grid, device=DEV, n_branches=2, calibration=False)
     eng.load_weights(sd)
     del sd
@@ -76,7 +76,7 @@ def wan_case(cfg, grid, seed, q_scale, ctx_valid):
     return oracle, eng, lat, t, ctx
 
 
-def run_wan_layers(cfg, grid, seed, q_scale, ctx_valid, tag):
+def run_wan_layers(cfg, grid, seed, q_scale, ctx_valid, tag, capture_exact=True):
     """Per-layer comparison of the engine's residual stream with the fp32 checker and with the autocast-mode checker."""
     oracle, eng, lat, t, ctx = wan_case(cfg, grid, seed, q_scale, ctx_valid)
     L, d = eng.seq_len, cfg["dim"]
@@ -107,7 +107,10 @@ def run_wan_layers(cfg, grid, seed, q_scale, ctx_valid, tag):
     # the residual captured by the fused epilogue of the last layer == x_out - ori_x of the same run (:299-301)
     x0 = eng.buffer("x0", torch.bfloat16).view(-1, d)[:L]
     cap = eng.residual(0)
-    assert torch.equal(cap, xe - x0.float()), "fused residual capture != x - ori_x at full size"
+    if capture_exact:
+        assert torch.equal(cap, xe - x0.float()), "fused residual capture != x - ori_x at full size"
+    else:       # the fp8 GEMMs capture in their own epilogue: same arithmetic, checked to rounding
+        assert FC.rel_l2(cap, xe - x0.float()) < 1e-6
     report(tag, res)
     del oracle, eng
     free()
@@ -153,7 +156,7 @@ def test_wan13_calibration_statistics_full_length_vs_fp32():
     lat = torch.randn(16, *grid, generator=g, device=DEV)
     lat2 = lat + 0.25 * torch.randn(16, *grid, generator=g, device=DEV)          # the next step's latent
     ctx = torch.randn(512, cfg["text_dim"], generator=g, device=DEV)
-    oracle = FC.build_wan_oracle(cfg, sd, DEV)
+    oracle = FC.build_wan_oracle({k: v for k, v in cfg.items() if k != "fp8_linear"}, sd, DEV)
     eng = Engine(cfg, grid, device=DEV, n_branches=2, calibration=True)
     eng.load_weights(sd)
     del sd
@@ -184,6 +187,26 @@ def test_wan14_one_block_720p_length():
     cfg = dict(WAN_T2V_14B, num_layers=1)
     res = run_wan_layers(cfg, (21, 90, 160), seed=5, q_scale=4.0, ctx_valid=512, tag="wan14B_1block_L75600_qx4")
     check(res)
+
+
+@pytest.mark.parametrize("fp8,layers", [(2, 1), (2, 4), (1, 4)])
+def test_wan14b_widths_full_length_fp8_linears(fp8, layers):
+    """BASELINE.json config 5's "fp8 MFMA weight path" AT SIZE: Wan 14B widths (d 5120, 40 heads,
+    ffn 13 824) x L = 75 600 tokens with the QKV / FFN Linears on the e4m3 MFMA kernels (2: MX block scales, gemm_mxfp8.hip;
+    1: per-row / per-channel scales, gemm_fp8_big.hip), one block and four blocks, against the fp32 checker and the
+    reference's bf16-autocast mode.  An OPTIONAL reduced-precision mode, never the headline: e4m3 carries 3 mantissa bits, so
+    the bar is not the bf16 one.  Measured (profiles/r04/fullsize_parity.json): residual stream 1.7e-2 after block 0, 1.6e-2
+    after block 3 (no growth over depth), output 1.6e-2 ... 1.8e-2 against 5.4e-3 ... 6.1e-3 for the reference's bf16 mode,
+    PSNR vs fp32 51-52 dB; both fp8 modes alike on Gaussian operands.  Stated bar = 2x the measurement: rel-L2 <= 3.5e-2 at
+    every layer and on the output, PSNR >= 45 dB."""
+    cfg = dict(WAN_T2V_14B, num_layers=layers, fp8_linear=fp8)
+    res = run_wan_layers(cfg, (21, 90, 160), seed=5, q_scale=4.0, ctx_valid=512,
+                         tag=f"wan14B_{layers}block_L75600_qx4_fp8_linear{fp8}", capture_exact=False)
+    for r in res["layers"]:
+        assert r["e_hip"] <= 3.5e-2, r
+    assert res["out_e_hip"] <= 3.5e-2 and res["out_psnr_hip_db"] >= 45.0, {k: v for k, v in res.items() if k != "layers"}
+    # and the mode really differs from the bf16 engine's error level (the option switches kernels)
+    assert res["out_e_hip"] > 1.5 * res["out_e_ac"], res
 
 
 @pytest.mark.slow

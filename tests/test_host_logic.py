@@ -643,3 +643,20 @@ def test_nearest_interp_c_python_and_oracle_agree_on_random_lengths():
         lib.mc_nearest_interp(a, n_src, out, n_dst)
         assert list(out) == [float(x) for x in want], (n_src, n_dst)
         assert [float(x) for x in M.nearest_interp(src, n_dst)] == [float(x) for x in want], (n_src, n_dst)
+
+
+def test_bench_multi_gpu_failure_ends_in_a_parseable_line():
+    """bench.py --gpus N with N > 1: a failure at any stage (here: no GPU is visible in this container) must still give
+    the driver ONE JSON line from rank 0, with "value": null, the reason and the stage, and a non-zero exit code."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999",
+               PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("a GPU is visible here: the failure path is not exercised")
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:] + r.stderr[-1000:]
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == 2 and "no GPU" in line["error"] and line["stage"]

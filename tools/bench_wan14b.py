@@ -12,10 +12,16 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from magcache_amd import model as M  # noqa: E402
 from magcache_amd.engine import MC_MODE_FULL, MC_MODE_SKIP, WAN_T2V_14B, synthetic_weights  # noqa: E402
 
+import argparse  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--fp8_linear", type=int, default=0, choices=(0, 1, 2),
+                help="OPTIONAL reduced-precision mode (BASELINE.json config 5's fp8 MFMA weight path): 1 per-row scales, 2 MX")
+args = ap.parse_args()
 DEV = "cuda:0"
 grid = (21, 90, 160)
 L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
-cfg = WAN_T2V_14B
+cfg = dict(WAN_T2V_14B, fp8_linear=args.fp8_linear) if args.fp8_linear else WAN_T2V_14B
 m = M.WanModelHIP(cfg, grid, device=DEV, calibration=False)
 m.engine.load_weights(synthetic_weights(cfg, seed=0, device=DEV))
 g = torch.Generator(device=DEV).manual_seed(42)
@@ -39,6 +45,7 @@ ts, s1 = timed(lambda: e.forward(lat, 900.0, ctx, branch=0, mode=MC_MODE_SKIP).c
 d, f, nl = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
 fl = nl * (8.0 * L * d * d + 4.0 * L * L * d + 4.0 * L * d * d + 4.0 * 512 * d * d + 4.0 * L * 512 * d + 4.0 * L * d * f)
 print(json.dumps({"config": "Wan2.1-T2V-14B 1280x720 81 frames: 75600 tokens, d=5120, 40 heads, ffn 13824, 40 layers; one GPU",
+                  "fp8_linear": args.fp8_linear,
                   "full_forward_s": t2, "first_forward_s": t1, "skipped_forward_ms": ts * 1e3,
                   "model_pflop_per_forward": fl / 1e15, "model_tflops_per_s": fl / t2 / 1e12,
                   "deterministic": bool(torch.equal(o1, o2)), "finite": bool(torch.isfinite(o2).all()),
