@@ -209,6 +209,51 @@ def test_wan14b_widths_full_length_fp8_linears(fp8, layers):
     assert res["out_e_hip"] > 1.5 * res["out_e_ac"], res
 
 
+def test_wan22_i2v_a14b_two_experts_fp8_at_width():
+    """BASELINE.json config 5 (Wan2.2 I2V-A14B 720p + fp8 weight path) at its WIDTHS and LENGTH, reduced depth: two experts
+    (d 5120, 40 heads, ffn 13 824, 36-channel x ++ y input, 2 blocks each) over 75 600 tokens, the two-expert sampler loop
+    with MagCache in i2v mode (shared state, split-step retention gate, MagCache4Wan2.2/magcache_generate.py:294-303,
+    340-352), once on the bf16 engine and once with fp8_linear = 2 (MX).  The skip schedule is host arithmetic on the
+    table: it must be the same in both precisions and contain skips after the expert switch, and the fp8 run's
+    final latent must stay within 35 dB of the bf16 run's (measured 53 dB, 6 of 20 forwards skipped)."""
+    from magcache_amd import wan22
+    from magcache_amd.engine import WAN_I2V_14B
+    grid = (21, 90, 160)
+    base = {k: v for k, v in WAN_I2V_14B.items() if k not in ("clip_dim", "model_type")}     # Wan2.2 i2v: y concat, no CLIP branch
+    base = dict(base, num_layers=2)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    noise = torch.randn(16, *grid, generator=g, device=DEV)
+    y = torch.randn(20, *grid, generator=g, device=DEV)
+    ctx, ctxn = (torch.randn(512, base["text_dim"], generator=g, device=DEV) for _ in range(2))
+    steps, shift, boundary = 10, 5.0, 0.9
+    split = wan22.high_noise_steps(shift, steps, boundary)
+    assert 0 < split < steps
+    table = wan22.table_without_pad("wan2.2_i2v_A14B")
+    finals, scheds = {}, {}
+    for fp8 in (0, 2):
+        cfg = dict(base, fp8_linear=fp8) if fp8 else base
+        hi, lo = wan22.make_experts(cfg, grid, device=DEV, name=f"WanModelHIP22Width{fp8}")
+        hi.engine.load_weights(synthetic_weights(cfg, seed=21, device=DEV))
+        lo.engine.load_weights(synthetic_weights(cfg, seed=22, device=DEV))
+        wan22.init_magcache(hi, table, steps, 0.12, 2, 0.2, split_steps=split, mode="i2v")
+        modes = []
+        for e in (hi, lo):
+            orig = e.engine.forward
+            e.engine.forward = (lambda orig, tag: lambda *a, **k: (modes.append((tag, k["mode"])), orig(*a, **k))[1])(orig, e is hi)
+        finals[fp8] = wan22.sample(hi, lo, noise, ctx, ctxn, boundary, sampling_steps=steps, shift=shift, guide_scale=(3.5, 3.5),
+                                   y=y).clone()
+        scheds[fp8] = modes
+        assert type(hi).cnt == 0 and bool(torch.isfinite(finals[fp8]).all())
+        del hi, lo
+        free()
+    assert scheds[0] == scheds[2] and len(scheds[0]) == 2 * steps
+    assert any((not is_hi) and m == 1 for is_hi, m in scheds[0])
+    ps = FC.psnr(finals[2], finals[0])
+    report("wan22_i2v_a14b_two_experts_2blocks_L75600_fp8_vs_bf16", dict(psnr_db=ps, skipped=sum(m == 1 for _, m in scheds[0]),
+                                                                       forwards=len(scheds[0]), split_step=split))
+    assert ps >= 35.0, ps
+
+
 @pytest.mark.slow
 @pytest.mark.skipif(os.environ.get("MC_RUN_SLOW") != "1", reason="2.5 minutes on one MI355X: set MC_RUN_SLOW=1 (tools/gpu_session.sh "
                     "pytest_slow); its last run is profiles/r04/fullsize_parity.json")
