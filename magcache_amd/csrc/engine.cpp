@@ -1381,6 +1381,9 @@ mc_status mc_set_option(const char* key, int value) {
     if ((value < 0 || value > gemm_max) && value != 4)
       return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 4 (256x256, 4 waves, generated stream)");
     mc::g_gemm_kernel = value;
+  } else if (k == "gemm_defer") {
+    if (value != 0 && value != 1) return fail(MC_EINVAL, "gemm_defer must be 0 (residual epilogues in place) or 1 (deferred into the next tile's main loop)");
+    mc::g_gemm_defer = value;
   } else if (k == "attn_kernel") {
 #ifndef MC_AB_KERNELS
     if (value != 0 && value != 3 && value != 5)

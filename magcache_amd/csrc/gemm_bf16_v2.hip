@@ -3,10 +3,23 @@
 //   C[M,N] = A[M,K] * W[N,K]^T  (+ the fused epilogues of gemm_epilogue.h),  N % 256 == 0,  K % 128 == 0, K >= 256.
 // Same call sites as gemm_bf16_big.hip (the Linears of the Wan DiT block at M = 32768 tokens; reference call site
 // MagCache4Wan2.1/magcache_generate.py:297-298).  A third less LDS traffic per FLOP than the 8-wave kernel (32 KiB of fragments
-// per 2.1 MFLOP instead of 24 KiB per 1.05), 256 accumulators in AGPRs, 64 MFMAs per barrier with one LDS read or one
-// LDS-DMA piece per MFMA gap.  Rows of a partial last M tile are fetched as zeros (buffer range check) and not stored.
+// per 2.1 MFLOP instead of 24 KiB per 1.05), 256 accumulators in AGPRs.  Rows of a partial last M tile are fetched as zeros
+// (buffer range check) and not stored.
+//
+// Round 4 (what ships; profiles/r04/NOTES.md has the measurements in order):
+//   * stream: schedule "h" -- the ring slot of a K tile is released operand by operand and refilled two tiles ahead, counted
+//     waits only (the cadence of the library's hand-scheduled 256x256x64 kernel); persistent tile loop, the next output
+//     tile's first two K tiles fly under the epilogue.  Main loop alone: 1523 TF on the QKV shape (2128 on zero operands).
+//   * epilogues (bf16 store, GELU, gated residual): the accumulators are read from their AGPRs quad by quad, rounded to
+//     bf16, TRANSPOSED through a private 4 KiB strip of LDS and leave row-major -- every global access is 16 bytes per
+//     lane and whole 128-byte lines per row.  (The MFMA layout's own 8-byte stores cost ~60 cycles of the CU's address path
+//     each: 1264 vs 1531 TF with the stores compiled out.)
+//   * the gated residual epilogue is DEFERRED: the tile's bf16 values go to a per-workgroup scratch tile (L2-resident,
+//     128 KiB), and x += gate * value runs INSIDE the next output tile's main loop (asm, 32 chunks over 8 pairs of K
+//     tiles, loads ~130 MFMA gaps ahead of their use); only the workgroup's last tile pays for it in the open.
 #pragma clang diagnostic ignored "-Winline-asm"
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 
 #include "gemm_epilogue.h"
@@ -17,15 +30,26 @@
 #define MC_GEMM_V2_CLOBBERS "gemm_v2_clobbers.inc"
 #define MC_GEMM_V2_CONFIG "gemm_v2_config.h"
 #endif
-#include MC_GEMM_V2_CONFIG   // MC_GEMM_V2_MFMA: 32 (v_mfma_f32_32x32x16_bf16, 4 x 4 accumulator tiles) or 16 (16x16x32, 8 x 8)
-
-#ifndef MC_V2_EPI_ABL
-#define MC_V2_EPI_ABL 0
+#include MC_GEMM_V2_CONFIG   // MC_GEMM_V2_MFMA (32 | 16), _ROW (64 | 128), _PERSIST, _SCHED_H, _DEFER: what the stream was generated as
+#ifndef MC_GEMM_V2_SCHED_H
+#define MC_GEMM_V2_SCHED_H 0
 #endif
-#ifndef MC_V2_LEAN_RESID
-#define MC_V2_LEAN_RESID 1   // the buffer-intrinsic form of the residual epilogue: hipcc sinks its loads to their uses (one
-#endif                       // round trip per quad) and two rows of a tile came out wrong on the GPU -- off, see the notes
+#ifndef MC_GEMM_V2_DEFER
+#define MC_GEMM_V2_DEFER 0
+#endif
+#ifndef MC_V2_EPI_ABL      // timing ablations of the epilogues (tools/build_gemm_v2_variants.py ...,epiabl=N; results WRONG):
+#define MC_V2_EPI_ABL 0    // 1 no stores (bf16 forms), 3 no x stores, 4 no x loads (residual form, not deferred)
+#endif
+#ifndef MC_V2_DEFER_ABL
+#define MC_V2_DEFER_ABL 0
+#endif
+#ifndef MC_V2_XAHEAD
+#define MC_V2_XAHEAD 1     // residual form, not deferred: m blocks of x loaded ahead (2, 3, 5 measured: no faster)
+#endif
+
 namespace mc {
+
+int g_gemm_defer = 1;   // mc_set_option("gemm_defer", 0): residual epilogues in place (A/B, debugging)
 
 namespace {
 
@@ -33,11 +57,26 @@ constexpr int TB = 256;
 constexpr int V2_RING_BYTES = 4 * 32768;     // the operand ring (two 64 KiB K tiles, or four 32 KiB sub-stages)
 constexpr int V2_STRIP_BYTES = 16 * 272;      // per wave: the epilogue's transposition strip (16 rows x 128 bf16, rows padded)
 constexpr int V2_LDS_BYTES = V2_RING_BYTES + 4 * V2_STRIP_BYTES;
+constexpr int V2_SCRATCH_ELEMS = TB * TB;     // per workgroup: the deferred epilogue's bf16 tile
+#ifndef MC_GEMM_V2_DEFER_PAIRS
+#define MC_GEMM_V2_DEFER_PAIRS 8
+#endif
+constexpr int V2_DEFER_MIN_K = (MC_GEMM_V2_DEFER_PAIRS + 1) * 128;   // the pairs of K tiles that carry the deferred chunks, one more ends the trip
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+#define MC_V2_OUTS                                                                                                   \
+  "={a[0:31]}"(c0), "={a[32:63]}"(c1), "={a[64:95]}"(c2), "={a[96:127]}"(c3), "={a[128:159]}"(c4), "={a[160:191]}"(c5), \
+      "={a[192:223]}"(c6), "={a[224:255]}"(c7)
+
+__device__ __forceinline__ float agpr_read(float a) {
+  float x;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
+  return x;
+}
 
 template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M) {
+__global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M, bf16_t* scratch_all) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // ---- tile mapping: XCD-contiguous, grouped along M (as gemm_bf16_big.hip)
@@ -59,292 +98,377 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
   auto w_nrec_of = [&](int tn0) { return (uint32_t)min((size_t)(p.N - tn0) * ldw_b - (size_t)(p.ldw - p.K) * 2, (size_t)0xffffff00u); };
   const int nk = p.K / 32;
   const uint32_t lds0 = (uint32_t)(uintptr_t)MC_LDS_PTR(smem);
+  constexpr bool LEAN = MC_GEMM_V2_MFMA == 16 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RESID_GATE);
+  constexpr bool CAN_DEFER = MC_GEMM_V2_PERSIST && MC_GEMM_V2_SCHED_H && MC_GEMM_V2_DEFER && EPI == EPI_RESID_GATE;
+
+  // ---- the lean epilogues.  to_scratch false: this tile's own epilogue (bf16 / GELU store, or x += gate * value right
+  //      here); true: bf16 values into the workgroup's scratch tile (the residual update follows in the next trip's main loop)
+  auto lean_epilogue = [&](const f32x32 (&cc)[8], int tm0, int tn0, bool to_scratch, bf16_t* scr) {
+    // nothing lane-dependent lives across the asm statement: lane ids are recomputed here
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int l15 = ln & 15, g4 = ln >> 4, rr = ln >> 4, c16 = ln & 15;
+    const int wr_ = wv >> 1, wc_ = wv & 1;
+    const uint32_t rows = (uint32_t)min(p.M - tm0, TB);
+    // the accumulators STAY in their AGPRs until the quad is needed (an asm read per element): handed to the compiler as
+    // values it copied all 256 into VGPRs first and, the register file full, serialised the epilogue's loads
+    auto acc_quad = [&](int mb, int nb) {
+      const int e = (nb * 8 + mb) * 4;
+      const f32x32& t = cc[e >> 5];
+      return f32x4{agpr_read(t[e & 31]), agpr_read(t[(e & 31) + 1]), agpr_read(t[(e & 31) + 2]), agpr_read(t[(e & 31) + 3])};
+    };
+    // bias quads of this lane: columns tn0 + 128 wc + 16 nb + 4 g4 + 0..3
+    const uint32_t voff_n = (uint32_t)(wc_ * 128 + 4 * g4) * 4u;
+    f32x4 bq[8];
+    if (p.bias) {
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias + tn0), 0, TB * 4, 0x00020000);
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) bq[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, voff_n + nb * 64, 0, 0));
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) bq[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- the lane's bf16(acc + bias) values go through a private strip of LDS (16 rows x 128 columns, rows padded to 272
+    // bytes: conflict-free ds_write_b64 / ds_read_b128) and come back ROW-MAJOR: lane -> row rr (+ 4 i), columns 8 c16 .. + 7.
+    // LDS instructions of one wave execute in order and the strip belongs to one wave: no barrier, no wait between a pass's
+    // writes and reads.
+    char* strip = smem + V2_RING_BYTES + wv * V2_STRIP_BYTES;
+    const uint32_t wr_off = (uint32_t)(l15 * 272 + g4 * 8), rd_off = (uint32_t)(rr * 272 + c16 * 16);
+    const bool resid_here = EPI == EPI_RESID_GATE && !to_scratch;
+    f32x4 gA = {1.f, 1.f, 1.f, 1.f}, gB = gA;      // residual form: gate of columns 8 c16 .. + 7
+    __amdgpu_buffer_rsrc_t rio;
+    uint32_t vio, row_b;
+    if (EPI == EPI_RESID_GATE && to_scratch) {
+      row_b = TB * 2u;
+      rio = __builtin_amdgcn_make_buffer_rsrc((void*)scr, 0, TB * TB * 2, 0x00020000);
+      vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 2u;
+    } else if (EPI == EPI_RESID_GATE) {
+      if (p.gate) {
+        const float* gp = p.gate + tn0 + wc_ * 128 + c16 * 8;
+        gA = *(const f32x4*)gp;
+        gB = *(const f32x4*)(gp + 4);
+      }
+      row_b = (uint32_t)p.ldx * 4u;
+      rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (size_t)tm0 * p.ldx + tn0), 0, rows * row_b, 0x00020000);
+      vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 4u;
+    } else {
+      row_b = (uint32_t)p.ldc * 2u;
+      rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cb + (size_t)tm0 * p.ldc + tn0), 0, rows * row_b, 0x00020000);
+      vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 2u;
+    }
+    // (row offsets live in the VGPR offset, which the hardware range-checks together with the immediate: rows past M are
+    // dropped.)  Residual form here: the 8 x loads of m block mb + XA are issued BEFORE m block mb is transposed and
+    // applied, pinned by sched_barrier -- hipcc otherwise sinks every load to its use (one round trip per pair of loads).
+    constexpr int XA = MC_V2_XAHEAD, XS = XA + 1;
+    f32x4 xin[XS][4][2];
+    auto load_x = [&](int mb, int set) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
+#if MC_V2_EPI_ABL == 4
+        xin[set][i][0] = xin[set][i][1] = gA;
+#else
+        xin[set][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow, 0, 0));
+        xin[set][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow + 16, 0, 0));
+#endif
+      }
+    };
+    if (resid_here) {
+#pragma unroll
+      for (int b = 0; b < XA; ++b) load_x(b, b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      if (resid_here) {
+        if (mb + XA < 8) load_x(mb + XA, (mb + XA) % XS);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        f32x4 val = acc_quad(mb, nb) + bq[nb];
+        if constexpr (EPI == EPI_GELU_BF16) {
+          const f32x2 y0 = gelu_tanh_fast2(bf16_round2(val[0], val[1])), y1 = gelu_tanh_fast2(bf16_round2(val[2], val[3]));
+          val = f32x4{y0[0], y0[1], y1[0], y1[1]};
+        }
+        *(u32x2*)(strip + wr_off + nb * 32) = u32x2{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
+      }
+      u32x4 rowv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rowv[i] = *(const u32x4*)(strip + rd_off + i * (4 * 272));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
+        if (resid_here) {
+          // x[row][8 c16 .. + 7] += gate * bf16 value (the Linear's output was rounded to bf16 above, like autocast)
+          f32x4 xa = xin[mb % XS][i][0], xb = xin[mb % XS][i][1];
+          const u32x4 w = rowv[i];
+          xa[0] += __uint_as_float(w[0] << 16) * gA[0];
+          xa[1] += __uint_as_float(w[0] & 0xffff0000u) * gA[1];
+          xa[2] += __uint_as_float(w[1] << 16) * gA[2];
+          xa[3] += __uint_as_float(w[1] & 0xffff0000u) * gA[3];
+          xb[0] += __uint_as_float(w[2] << 16) * gB[0];
+          xb[1] += __uint_as_float(w[2] & 0xffff0000u) * gB[1];
+          xb[2] += __uint_as_float(w[3] << 16) * gB[2];
+          xb[3] += __uint_as_float(w[3] & 0xffff0000u) * gB[3];
+#if MC_V2_EPI_ABL == 3
+          asm volatile("" ::"v"(xa), "v"(xb));
+#else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xa), rio, vrow, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb), rio, vrow + 16, 0, 0);
+#endif
+        } else {
+#if MC_V2_EPI_ABL == 1
+          asm volatile("" ::"v"(rowv[i]));
+#else
+          __builtin_amdgcn_raw_buffer_store_b128(rowv[i], rio, vrow, 0, 0);
+#endif
+        }
+      }
+      if (resid_here) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- the deferred residual update of a workgroup's LAST tile (no next main loop to hide it in): the asm stream's
+  // chunk arithmetic restated -- x[row][8 c16 .. + 7] += gate * scratch value, 4 rows x 128 columns per chunk and wave
+  auto deferred_tail = [&](int tm0, int tn0, bf16_t* scr) {
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int rr = ln >> 4, c16 = ln & 15, wr_ = wv >> 1, wc_ = wv & 1;
+    const uint32_t rows = (uint32_t)min(p.M - tm0, TB), ldx_b = (uint32_t)p.ldx * 4u;
+    f32x4 gA = {1.f, 1.f, 1.f, 1.f}, gB = gA;
+    if (p.gate) {
+      const float* gp = p.gate + tn0 + wc_ * 128 + c16 * 8;
+      gA = *(const f32x4*)gp;
+      gB = *(const f32x4*)(gp + 4);
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)scr, 0, TB * TB * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (size_t)tm0 * p.ldx + tn0), 0, rows * ldx_b, 0x00020000);
+    const uint32_t vs = (uint32_t)(wr_ * 128 + rr) * (TB * 2u) + (uint32_t)(wc_ * 128 + c16 * 8) * 2u;
+    const uint32_t vx = (uint32_t)(wr_ * 128 + rr) * ldx_b + (uint32_t)(wc_ * 128 + c16 * 8) * 4u;
+    // the scratch rows were written by THIS wave a moment ago: they have to be in L2 before they are read back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (int c0 = 0; c0 < 32; c0 += 4) {
+      u32x4 w[4];
+      f32x4 xa[4], xb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        w[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, vs + (uint32_t)(c0 + k) * (4 * TB * 2u), 0, 16 /* sc1: from L2 */);
+        xa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vx + (uint32_t)(c0 + k) * 4u * ldx_b, 0, 0));
+        xb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vx + (uint32_t)(c0 + k) * 4u * ldx_b + 16, 0, 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xa[k][0] += __uint_as_float(w[k][0] << 16) * gA[0];
+        xa[k][1] += __uint_as_float(w[k][0] & 0xffff0000u) * gA[1];
+        xa[k][2] += __uint_as_float(w[k][1] << 16) * gA[2];
+        xa[k][3] += __uint_as_float(w[k][1] & 0xffff0000u) * gA[3];
+        xb[k][0] += __uint_as_float(w[k][2] << 16) * gB[0];
+        xb[k][1] += __uint_as_float(w[k][2] & 0xffff0000u) * gB[1];
+        xb[k][2] += __uint_as_float(w[k][3] << 16) * gB[2];
+        xb[k][3] += __uint_as_float(w[k][3] & 0xffff0000u) * gB[3];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xa[k]), rx, vx + (uint32_t)(c0 + k) * 4u * ldx_b, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb[k]), rx, vx + (uint32_t)(c0 + k) * 4u * ldx_b + 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- generic epilogues (residual capture, fp32 store, the 32x32x16 stream): gemm_epilogue.h on the MFMA layout
+  //   16x16x32: accumulator (nb, mb, r) = register (8 nb + mb) * 4 + r = C[m][n], m = .. + 16 mb + lane % 16,
+  //             n = .. + 16 nb + 4 (lane / 16) + r                                  -> rows mb 0..7, quads nb 0..7
+  //   32x32x16: accumulator (nb, mb, r) = register (4 nb + mb) * 16 + r,            m = .. + 32 mb + lane % 32,
+  //             n = .. + 32 nb + 8 (r / 4) + 4 (lane / 32) + r % 4                  -> rows mb 0..3, quads (nb, r / 4) 0..15
+  auto generic_epilogue = [&](const f32x32 (&cc)[8]) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int wr = wv >> 1, wc = wv & 1;
+#if MC_GEMM_V2_MFMA == 16
+    constexpr int NR = 8, NQ = 8;
+    const int mrow = lane & 15, ncol = 4 * (lane >> 4);
+    auto m_of = [&](int ri) { return m0 + wr * 128 + ri * 16 + mrow; };
+    auto n_of = [&](int qi) { return n0 + wc * 128 + qi * 16 + ncol; };
+    auto quad = [&](int ri, int qi) {
+      const int e = (qi * 8 + ri) * 4;
+      const f32x32& t = cc[e >> 5];
+      return f32x4{t[e & 31], t[(e & 31) + 1], t[(e & 31) + 2], t[(e & 31) + 3]};
+    };
+#else
+    constexpr int NR = 4, NQ = 16;
+    const int mrow = lane & 31, ncol = 4 * (lane >> 5);
+    auto m_of = [&](int ri) { return m0 + wr * 128 + ri * 32 + mrow; };
+    auto n_of = [&](int qi) { return n0 + wc * 128 + (qi >> 2) * 32 + 8 * (qi & 3) + ncol; };
+    auto quad = [&](int ri, int qi) {
+      const int e = ((qi >> 2) * 4 + ri) * 16 + (qi & 3) * 4;
+      const f32x32& t = cc[e >> 5];
+      return f32x4{t[e & 31], t[(e & 31) + 1], t[(e & 31) + 2], t[(e & 31) + 3]};
+    };
+#endif
+    if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
+      // two-phase residual epilogue (gemm_epilogue.h): 8 quads are loaded together, then added and stored
+      auto resid = [&](auto with_sel) {
+        constexpr bool SEL = decltype(with_sel)::value;
+#pragma unroll
+        for (int ri = 0; ri < NR; ++ri) {
+          const int m = m_of(ri);
+          const int ml = min(m, p.M - 1);
+          const float* gp = (SEL && p.gate_sel[ml]) ? p.gate2 : p.gate;
+#pragma unroll
+          for (int q0 = 0; q0 < NQ; q0 += 8) {
+            ResidIn in[8];
+            f32x4 gt[8], bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int n = n_of(q0 + k);
+              in[k] = resid_load<EPI>(p, ml, n);
+              gt[k] = p.gate ? *(const f32x4*)(gp + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+              bv[k] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (m < p.M) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) resid_apply<EPI>(p, m, n_of(q0 + k), quad(ri, q0 + k) + bv[k], gt[k], in[k]);
+            }
+          }
+        }
+      };
+      if (p.gate_sel) resid(std::true_type{});
+      else resid(std::false_type{});
+    } else {
+#pragma unroll
+      for (int ri = 0; ri < NR; ++ri) {
+        const int m = m_of(ri);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+          const int n = n_of(qi);
+          f32x4 b = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) b = *(const f32x4*)(p.bias + n);
+          gemm_epilogue_quad<EPI>(p, m, n, quad(ri, qi) + b);
+        }
+      }
+    }
+  };
 
 #if MC_GEMM_V2_PERSIST
-#ifndef MC_V2_STAGGER
-#define MC_V2_STAGGER 0
-#endif
-  // (experiment) de-phased start for the residual epilogues: with every CU in its epilogue at once the x read-modify-write
-  // is HBM-bound (134 MB per round of tiles) while the memory system idles during the main loops; four phase groups per
-  // XCD start MC_V2_STAGGER x ~4 us apart
-  if constexpr (EPI == EPI_RESID_GATE && MC_V2_STAGGER > 0) {
-    const int ph = (blockIdx.x >> 3) & 3;
-    for (int i = 0; i < ph * MC_V2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   // one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...: the asm statement is one trip; its last two K tiles fetch
   // the first two of the NEXT output tile, which land in the LDS ring under the epilogue below (tools/gen_gemm_v2.py)
+  bf16_t* const scr = CAN_DEFER && scratch_all ? scratch_all + (size_t)blockIdx.x * V2_SCRATCH_ELEMS : nullptr;
+  const bool defer = CAN_DEFER && scr != nullptr && p.K >= V2_DEFER_MIN_K;
+  bool pend = false;        // a tile's residual update is waiting in the scratch tile
+  int pm0 = 0, pn0 = 0;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  place(tile, m0, n0);
-  const int next_tile = tile + (int)gridDim.x;
-  int nm0 = 0, nn0 = 0;
-  const bool more = next_tile < ntiles;
-  if (more) place(next_tile, nm0, nn0);
-  const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
-  const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
-  const bf16_t* a_next = p.A + (size_t)nm0 * p.lda;
-  const bf16_t* w_next = p.W + (size_t)nn0 * p.ldw;
-  const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
-  const uint32_t a_nrec_n = __builtin_amdgcn_readfirstlane(more ? a_nrec_of(nm0) : 0u);
-  const uint32_t w_nrec_n = __builtin_amdgcn_readfirstlane(more ? w_nrec_of(nn0) : 0u);
-  const int first = __builtin_amdgcn_readfirstlane(tile == (int)blockIdx.x ? 1 : 0);
-  f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;
-  asm volatile(
-#include MC_GEMM_V2_BODY
-      : "={a[0:15]}"(c0), "={a[16:31]}"(c1), "={a[32:47]}"(c2), "={a[48:63]}"(c3), "={a[64:79]}"(c4), "={a[80:95]}"(c5),
-        "={a[96:111]}"(c6), "={a[112:127]}"(c7), "={a[128:143]}"(c8), "={a[144:159]}"(c9), "={a[160:175]}"(c10),
-        "={a[176:191]}"(c11), "={a[192:207]}"(c12), "={a[208:223]}"(c13), "={a[224:239]}"(c14), "={a[240:255]}"(c15)
-      : "s"(a_tile), "s"(w_tile), "s"(lda_b), "s"(ldw_b), "s"(nk), "s"(wv), "s"(lds0), "s"(a_nrec), "s"(w_nrec), "s"(a_next),
-        "s"(w_next), "s"(a_nrec_n), "s"(w_nrec_n), "s"(first)
-      :
-#include MC_GEMM_V2_CLOBBERS
-  );
-#if MC_GEMM_V2_SCHED_H
-  // contract of schedule h (tools/gen_gemm_v2.py, L_queued): the next tile's K tiles 0, 1, fetched by the statement's last
-  // two K tiles, have LANDED before this trip's epilogue issues its first load or store (they are ~1.5 K tiles old here)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    place(tile, m0, n0);
+    const int next_tile = tile + (int)gridDim.x;
+    int nm0 = 0, nn0 = 0;
+    const bool more = next_tile < ntiles;
+    if (more) place(next_tile, nm0, nn0);
+    const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
+    const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
+    const bf16_t* a_next = p.A + (size_t)nm0 * p.lda;
+    const bf16_t* w_next = p.W + (size_t)nn0 * p.ldw;
+    const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
+    const uint32_t a_nrec_n = __builtin_amdgcn_readfirstlane(more ? a_nrec_of(nm0) : 0u);
+    const uint32_t w_nrec_n = __builtin_amdgcn_readfirstlane(more ? w_nrec_of(nn0) : 0u);
+    const int first = __builtin_amdgcn_readfirstlane(tile == (int)blockIdx.x ? 1 : 0);
+    f32x32 c0, c1, c2, c3, c4, c5, c6, c7;
+#if MC_GEMM_V2_DEFER
+    // the deferred tile: its x rows, how many of them are valid, its gate columns
+    const float* d_x = p.X + (size_t)pm0 * p.ldx + pn0;
+    const uint32_t d_ldx_b = (uint32_t)p.ldx * 4u;
+    const uint32_t d_xnrec = __builtin_amdgcn_readfirstlane(pend ? (uint32_t)min(p.M - pm0, TB) * d_ldx_b : 0u);
+    const float* d_gate = p.gate ? p.gate + pn0 : nullptr;
+#if MC_V2_DEFER_ABL & 2     // timing ablation: no deferred work inside the main loop
+    const int d_on = 0;
+#else
+    const int d_on = __builtin_amdgcn_readfirstlane(pend ? 1 : 0);
 #endif
+    asm volatile(
+#include MC_GEMM_V2_BODY
+        : MC_V2_OUTS
+        : "s"(a_tile), "s"(w_tile), "s"(lda_b), "s"(ldw_b), "s"(nk), "s"(wv), "s"(lds0), "s"(a_nrec), "s"(w_nrec), "s"(a_next),
+          "s"(w_next), "s"(a_nrec_n), "s"(w_nrec_n), "s"(first), "s"(scr), "s"(d_x), "s"(d_xnrec), "s"(d_ldx_b), "s"(d_gate),
+          "s"(d_on)
+        :
+#include MC_GEMM_V2_CLOBBERS
+    );
+    pend = false;
+#else
+    asm volatile(
+#include MC_GEMM_V2_BODY
+        : MC_V2_OUTS
+        : "s"(a_tile), "s"(w_tile), "s"(lda_b), "s"(ldw_b), "s"(nk), "s"(wv), "s"(lds0), "s"(a_nrec), "s"(w_nrec), "s"(a_next),
+          "s"(w_next), "s"(a_nrec_n), "s"(w_nrec_n), "s"(first)
+        :
+#include MC_GEMM_V2_CLOBBERS
+    );
+#endif
+#if MC_GEMM_V2_SCHED_H
+    // contract of schedule h (tools/gen_gemm_v2.py, L_queued): the next tile's K tiles 0, 1, fetched by the statement's last
+    // two K tiles, have LANDED before this trip's epilogue issues its first load or store (they are ~1.5 K tiles old here)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef MC_V2_NO_EPI   // (timing ablation, tools/build_gemm_v2_variants.py ...,noepi=1: nothing is written)
+    const f32x32 cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+    if constexpr (LEAN) {
+      lean_epilogue(cc, m0, n0, defer, scr);
+      if (defer) {
+        pend = true;
+        pm0 = m0;
+        pn0 = n0;
+      }
+    } else {
+      generic_epilogue(cc);
+    }
+#else
+    if (p.M < 0) p.X[0] = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0];
+#endif
+  }   // tile loop
+#if !(MC_V2_DEFER_ABL & 1)   // (timing ablation 1: the last tile's update is dropped)
+  if (CAN_DEFER && pend) deferred_tail(pm0, pn0, scr);
+#endif
+  // the last trip's "next tile" fetches (zeros: num_records 0) still write the ring: they must not outlive the workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
   place(blockIdx.x, m0, n0);
   const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
   const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
   const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
-
-  f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;
+  f32x32 c0, c1, c2, c3, c4, c5, c6, c7;
   asm volatile(
 #include MC_GEMM_V2_BODY
-      : "={a[0:15]}"(c0), "={a[16:31]}"(c1), "={a[32:47]}"(c2), "={a[48:63]}"(c3), "={a[64:79]}"(c4), "={a[80:95]}"(c5),
-        "={a[96:111]}"(c6), "={a[112:127]}"(c7), "={a[128:143]}"(c8), "={a[144:159]}"(c9), "={a[160:175]}"(c10),
-        "={a[176:191]}"(c11), "={a[192:207]}"(c12), "={a[208:223]}"(c13), "={a[224:239]}"(c14), "={a[240:255]}"(c15)
+      : MC_V2_OUTS
       : "s"(a_tile), "s"(w_tile), "s"(lda_b), "s"(ldw_b), "s"(nk), "s"(wv), "s"(lds0), "s"(a_nrec), "s"(w_nrec)
       :
 #include MC_GEMM_V2_CLOBBERS
   );
+#ifndef MC_V2_NO_EPI
+  const f32x32 cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+  if constexpr (LEAN) lean_epilogue(cc, m0, n0, false, nullptr);
+  else generic_epilogue(cc);
 #endif
-#ifdef MC_V2_NO_EPI   // timing ablation (tools/build_gemm_v2_variants.py ...,noepi=1): nothing is written
-  if (p.M < 0) p.X[0] = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0] + c8[0] + c9[0] + c10[0] + c11[0] + c12[0] + c13[0] + c14[0] + c15[0];
-#else
-  const f32x16 cc[16] = {c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15};
-#if MC_GEMM_V2_MFMA == 16
-  // ---- lean epilogues (round 4) for the three hot forms.  The generic code below costs ~1400 instructions per tile around
-  // 64-bit address arithmetic, per-lane M guards and scratch reloads that wait for vmcnt(0), i.e. for the NEXT tile's
-  // prefetched K tiles: with it the kernel ran 1137 TF on the QKV shape, with the epilogue compiled out 1523
-  // (profiles/r04/kbench_gemm_v2_noepi.log).  Here: raw buffer accesses relative to the tile origin (rows past M are out of
-  // range and dropped by the hardware), nothing lane-dependent lives across the asm statement.
-  constexpr bool LEAN = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || (MC_V2_LEAN_RESID && EPI == EPI_RESID_GATE));   // (never with gate_sel: see the launcher)
-  if constexpr (LEAN) {
-    {
-      const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-      const int l15 = ln & 15, g4 = ln >> 4;
-      const int wr_ = wv >> 1, wc_ = wv & 1;
-      const uint32_t rows = (uint32_t)min(p.M - m0, TB);
-      // the accumulators STAY in their AGPRs until the quad is needed (an asm read per element): handing the sixteen tuples to
-      // the compiler as values made it copy all 256 into VGPRs first, and with the register file full it serialised the
-      // residual epilogue's loads (two loads, wait, two stores: 32 round trips per wave)
-      auto acc_quad = [&](int mb, int nb) {
-        const f32x16& t = cc[(nb * 8 + mb) >> 2];
-        const int e = ((nb * 8 + mb) & 3) * 4;
-        f32x4 q;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x;
-          asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(t[e + r]));
-          q[r] = x;
-        }
-        return q;
-      };
-      // bias (and gate) quads of this lane: columns n0 + 128 wc + 16 nb + 4 g4 + 0..3
-      const uint32_t voff_n = (uint32_t)(wc_ * 128 + 4 * g4) * 4u;
-      f32x4 bq[8];
-      if (p.bias) {
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias + n0), 0, TB * 4, 0x00020000);
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) bq[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, voff_n + nb * 64, 0, 0));
-      } else {
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) bq[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      // ---- the lane's bf16(acc + bias) values go through a private strip of LDS (16 rows x 128 columns, rows padded to 272
-      // bytes: conflict-free ds_write_b64 / ds_read_b128) and come back ROW-MAJOR: lane -> row lane / 16 (+ 4 i), columns
-      // 8 c16 .. + 7 (c16 = lane % 16).  Every global access of the epilogue is then 16 bytes per lane and whole 128-byte lines per
-      // row -- the MFMA layout's own stores (8 bytes per lane, 16 rows x 32 bytes per instruction) cost ~60 cycles of the
-      // CU's address path EACH: 1264 TF on the QKV shape against 1531 with the stores compiled out
-      // (profiles/r04/kbench_qkv_epi_abl.log).  LDS instructions of one wave execute in order, and the strip belongs to
-      // one wave: no barrier, no wait between a pass's writes and reads.
-      char* strip = smem + V2_RING_BYTES + wv * V2_STRIP_BYTES;
-      const int rr = ln >> 4, c16 = ln & 15;
-      const uint32_t wr_off = (uint32_t)(l15 * 272 + g4 * 8), rd_off = (uint32_t)(rr * 272 + c16 * 16);
-      f32x4 gA, gB;      // residual form: gate of columns 8 c16 .. + 7
-      __amdgpu_buffer_rsrc_t rio;
-      uint32_t vio, row_b;
-      if constexpr (EPI == EPI_RESID_GATE) {
-        gA = gB = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (p.gate) {
-          const float* gp = p.gate + n0 + wc_ * 128 + c16 * 8;
-          gA = *(const f32x4*)gp;
-          gB = *(const f32x4*)(gp + 4);
-        }
-        row_b = (uint32_t)p.ldx * 4u;
-        rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (size_t)m0 * p.ldx + n0), 0, rows * row_b, 0x00020000);
-        vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 4u;
-      } else {
-        row_b = (uint32_t)p.ldc * 2u;
-        rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cb + (size_t)m0 * p.ldc + n0), 0, rows * row_b, 0x00020000);
-        vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 2u;
-      }
-      // (row offsets live in the VGPR offset: the hardware range-checks VGPR + immediate only; a scalar offset would carry
-      // the rows past M through the check)
-      // residual form: the 8 x loads of m block mb + 1 are issued BEFORE m block mb is transposed and applied (two register
-      // sets), pinned there by sched_barrier: the waits in front of the adds are then counted ones
-#ifndef MC_V2_XAHEAD
-#define MC_V2_XAHEAD 1
 #endif
-      constexpr int XA = MC_V2_XAHEAD, XS = XA + 1;     // m blocks loaded ahead, register sets
-      f32x4 xin[XS][4][2];
-      auto load_x = [&](int mb, int set) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
-#if MC_V2_EPI_ABL == 4    // timing ablation: no x loads
-          xin[set][i][0] = xin[set][i][1] = gA;
-#else
-          xin[set][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow, 0, 0));
-          xin[set][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow + 16, 0, 0));
-#endif
-        }
-      };
-      if constexpr (EPI == EPI_RESID_GATE) {
-#pragma unroll
-        for (int b = 0; b < XA; ++b) load_x(b, b);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) {
-        if constexpr (EPI == EPI_RESID_GATE) {
-          if (mb + XA < 8) load_x(mb + XA, (mb + XA) % XS);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
-          f32x4 val = acc_quad(mb, nb) + bq[nb];
-          if constexpr (EPI == EPI_GELU_BF16) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) val[i] = gelu_tanh_fast(bf16_round(val[i]));
-          }
-          *(u32x2*)(strip + wr_off + nb * 32) = u32x2{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
-        }
-        u32x4 rowv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rowv[i] = *(const u32x4*)(strip + rd_off + i * (4 * 272));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
-          if constexpr (EPI == EPI_RESID_GATE) {
-            // x[row][8 c16 .. + 7] += gate * bf16 value (the Linear's output was rounded to bf16 above, like autocast)
-            f32x4 xa = xin[mb % XS][i][0], xb = xin[mb % XS][i][1];
-            const u32x4 w = rowv[i];
-            xa[0] += __uint_as_float(w[0] << 16) * gA[0];
-            xa[1] += __uint_as_float(w[0] & 0xffff0000u) * gA[1];
-            xa[2] += __uint_as_float(w[1] << 16) * gA[2];
-            xa[3] += __uint_as_float(w[1] & 0xffff0000u) * gA[3];
-            xb[0] += __uint_as_float(w[2] << 16) * gB[0];
-            xb[1] += __uint_as_float(w[2] & 0xffff0000u) * gB[1];
-            xb[2] += __uint_as_float(w[3] << 16) * gB[2];
-            xb[3] += __uint_as_float(w[3] & 0xffff0000u) * gB[3];
-#if MC_V2_EPI_ABL == 3    // timing ablation: no x stores
-            asm volatile("" ::"v"(xa), "v"(xb));
-#else
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xa), rio, vrow, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb), rio, vrow + 16, 0, 0);
-#endif
-          } else {
-            __builtin_amdgcn_raw_buffer_store_b128(rowv[i], rio, vrow, 0, 0);
-          }
-        }
-        if constexpr (EPI == EPI_RESID_GATE) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  } else
-#endif
-  {
+}
 
-  // ---- epilogue: a wave's 128 x 128 tile as NQ quads of 4 consecutive n for each of NR rows m of the lane
-  //   16x16x32: accumulator (nb, mb, r) = register (8 nb + mb) * 4 + r = C[m][n], m = .. + 16 mb + lane % 16,
-  //             n = .. + 16 nb + 4 (lane / 16) + r                                  -> rows mb 0..7, quads nb 0..7
-  //   32x32x16: accumulator (nb, mb, r) = register (4 nb + mb) * 16 + r,            m = .. + 32 mb + lane % 32,
-  //             n = .. + 32 nb + 8 (r / 4) + 4 (lane / 32) + r % 4                  -> rows mb 0..3, quads (nb, r / 4) 0..15
-  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const int wr = wv >> 1, wc = wv & 1;
-#if MC_GEMM_V2_MFMA == 16
-  constexpr int NR = 8, NQ = 8;
-  const int mrow = lane & 15, ncol = 4 * (lane >> 4);
-  auto m_of = [&](int ri) { return m0 + wr * 128 + ri * 16 + mrow; };
-  auto n_of = [&](int qi) { return n0 + wc * 128 + qi * 16 + ncol; };
-  auto quad = [&](int ri, int qi) {
-    const f32x16& t = cc[(qi * 8 + ri) >> 2];
-    const int e = ((qi * 8 + ri) & 3) * 4;
-    return f32x4{t[e], t[e + 1], t[e + 2], t[e + 3]};
-  };
-#else
-  constexpr int NR = 4, NQ = 16;
-  const int mrow = lane & 31, ncol = 4 * (lane >> 5);
-  auto m_of = [&](int ri) { return m0 + wr * 128 + ri * 32 + mrow; };
-  auto n_of = [&](int qi) { return n0 + wc * 128 + (qi >> 2) * 32 + 8 * (qi & 3) + ncol; };
-  auto quad = [&](int ri, int qi) {
-    const f32x16& t = cc[(qi >> 2) * 4 + ri];
-    const int e = (qi & 3) * 4;
-    return f32x4{t[e], t[e + 1], t[e + 2], t[e + 3]};
-  };
-#endif
-  if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
-    // two-phase residual epilogue (gemm_epilogue.h): 8 quads are loaded together, then added and stored
-    auto resid = [&](auto with_sel) {
-      constexpr bool SEL = decltype(with_sel)::value;
-#pragma unroll
-      for (int ri = 0; ri < NR; ++ri) {
-        const int m = m_of(ri);
-        const int ml = min(m, p.M - 1);
-        const float* gp = (SEL && p.gate_sel[ml]) ? p.gate2 : p.gate;
-#pragma unroll
-        for (int q0 = 0; q0 < NQ; q0 += 8) {
-          ResidIn in[8];
-          f32x4 gt[8], bv[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int n = n_of(q0 + k);
-            in[k] = resid_load<EPI>(p, ml, n);
-            gt[k] = p.gate ? *(const f32x4*)(gp + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-            bv[k] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-          if (m < p.M) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) resid_apply<EPI>(p, m, n_of(q0 + k), quad(ri, q0 + k) + bv[k], gt[k], in[k]);
-          }
-        }
-      }
-    };
-    if (p.gate_sel) resid(std::true_type{});
-    else resid(std::false_type{});
-  } else {
-#pragma unroll
-    for (int ri = 0; ri < NR; ++ri) {
-      const int m = m_of(ri);
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int qi = 0; qi < NQ; ++qi) {
-        const int n = n_of(qi);
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b = *(const f32x4*)(p.bias + n);
-        gemm_epilogue_quad<EPI>(p, m, n, quad(ri, qi) + b);
-      }
-    }
+// the deferred epilogue's scratch tiles: one per CU, allocated once per device (never inside a stream capture: a launch that
+// finds none while its stream is capturing runs the epilogue in place instead)
+bf16_t* v2_scratch(hipStream_t stream, int n_wg) {
+  static std::atomic<bf16_t*> buf[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  bf16_t* b = buf[dev & 63].load(std::memory_order_acquire);
+  if (b) return b;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+  void* pnew = nullptr;
+  if (hipMalloc(&pnew, (size_t)std::max(n_wg, 512) * V2_SCRATCH_ELEMS * sizeof(bf16_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
   }
-  }   // generic epilogues
-#endif   // MC_V2_NO_EPI
-#if MC_GEMM_V2_PERSIST
-  }   // tile loop
-  // the last trip's "next tile" fetches (zeros: num_records 0) still write the ring: they must not outlive the workgroup
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+  bf16_t* expected = nullptr;
+  if (!buf[dev & 63].compare_exchange_strong(expected, (bf16_t*)pnew, std::memory_order_acq_rel)) {
+    (void)hipFree(pnew);
+    return expected;
+  }
+  return (bf16_t*)pnew;
 }
 
 template <int EPI>
@@ -353,6 +477,7 @@ hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream) {
   static std::atomic<uint64_t> lds_ready{0};
   if (hipError_t e = ensure_dynamic_lds((const void*)gemm_v2_kernel<EPI>, V2_LDS_BYTES, lds_ready); e != hipSuccess) return e;
   int grid = tilesM * tilesN;
+  bf16_t* scratch = nullptr;
 #if MC_GEMM_V2_PERSIST
   static int n_cu = 0;
   if (!n_cu) {
@@ -362,9 +487,13 @@ hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream) {
     if (n_cu <= 0) n_cu = 256;
   }
   if (grid > n_cu) grid = n_cu;
+#if MC_GEMM_V2_DEFER
+  // (a workgroup with one tile gains nothing from deferring; the scratch tile is indexed by blockIdx.x < n_cu)
+  if (EPI == EPI_RESID_GATE && tilesM * tilesN > grid && g_gemm_defer) scratch = v2_scratch(stream, n_cu);
+#endif
 #endif
   hipLaunchKernelGGL((gemm_v2_kernel<EPI>), dim3(grid), dim3(256), V2_LDS_BYTES, stream, p, tilesM, tilesN,
-                     tilesN >= 32 ? 4 : 8);
+                     tilesN >= 32 ? 4 : 8, scratch);
   return hipGetLastError();
 }
 
@@ -372,8 +501,9 @@ hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream) {
 
 bool gemm_bf16_v2_supported(const GemmParams& p) {
   // (the per-row gate selection of Wan2.2 TI2V stays with the 8-wave kernel: the lean residual epilogue has one gate vector)
-  return !p.gate_sel && p.M > 0 && p.N > 0 && (p.N % TB) == 0 && (p.K % 128) == 0 && p.K >= 256 && (p.lda % 8) == 0 && (p.ldw % 8) == 0 &&
-         (size_t)p.M * (size_t)p.lda < (1ull << 31) && (size_t)p.N * (size_t)p.ldw < (1ull << 31);
+  return !p.gate_sel && p.M > 0 && p.N > 0 && (p.N % TB) == 0 && (p.K % 128) == 0 && p.K >= 256 && (p.lda % 8) == 0 &&
+         (p.ldw % 8) == 0 && (size_t)p.M * (size_t)p.lda < (1ull << 31) && (size_t)p.N * (size_t)p.ldw < (1ull << 31) &&
+         (size_t)TB * (size_t)std::max(p.ldx, p.ldc) * 4 < (1ull << 31);
 }
 
 hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream) {

@@ -10,16 +10,33 @@
 
 namespace mc {
 
-// GELU(approximate='tanh'):  0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = k0 (x + k1 x^3).
-// Written with exp2 + rcp (2 transcendentals) instead of tanhf (~30 VALU ops): the FFN-1 epilogue
-// evaluates it 293 M times per layer at 480p.  Relative error of v_exp_f32 / v_rcp_f32 is ~1 ulp,
-// far below the bf16 rounding that follows.
+// GELU(approximate='tanh'):  0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = k0 (x + k1 x^3), evaluated as
+//   x / (1 + 2^(x (C0 + C1 x^2))),  C0 = -2 log2(e) k0,  C1 = C0 k1
+// with exp2 + rcp (2 transcendentals) instead of tanhf (~30 VALU ops): the FFN-1 epilogue evaluates it 293 M times per
+// layer at 480p.  Relative error of v_exp_f32 / v_rcp_f32 is ~1 ulp, far below the bf16 rounding that follows; large |x|
+// saturates cleanly (exp2 -> 0 or inf).  Seven operations per element (mul, fma, mul, exp2, add, rcp, mul); round 3's form
+// spent eleven (the compiler's instruction count for it: 13.7 VALU per element of the FFN-1 epilogue, 8.5 now).  The PAIR
+// form does the same seven operations on two elements with packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 /
+// v_pk_add_f32: IEEE-identical to the scalar ones, so both forms give the same bits) -- no MFMA runs beside an epilogue.
+constexpr float kGeluC0 = -2.885390081777927f * 0.7978845608028654f;
+constexpr float kGeluC1 = kGeluC0 * 0.044715f;
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float u = k0 * (x + k1 * x * x * x);
-  // sigmoid(2u) = 1 / (1 + 2^(-2u log2 e)); large |u| saturates cleanly (exp2 -> 0 or inf)
-  const float e = __builtin_amdgcn_exp2f(-2.885390081777927f * u);
+  const float x2 = x * x;
+  const float t = __builtin_fmaf(x2, kGeluC1, kGeluC0);
+  const float e = __builtin_amdgcn_exp2f(t * x);
   return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ f32x2 gelu_tanh_fast2(f32x2 x) {
+  const f32x2 x2 = x * x;
+  const f32x2 t = __builtin_elementwise_fma(x2, f32x2{kGeluC1, kGeluC1}, f32x2{kGeluC0, kGeluC0});
+  const f32x2 u = t * x;
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + f32x2{1.0f, 1.0f};
+  return x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+// two fp32 -> the two bf16-rounded values as fp32 (what autocast's Linear output holds)
+__device__ __forceinline__ f32x2 bf16_round2(float a, float b) {
+  const uint32_t w = pack_bf16x2(a, b);
+  return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
 }
 
 // val = acc + bias for columns n..n+3 of row m.

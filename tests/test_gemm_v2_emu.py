@@ -94,12 +94,13 @@ def test_gemm_v2_inc_file_is_current():
     gen.ROW = 128 if "MC_GEMM_V2_ROW 128" in cfg else 64
     gen.PERSIST = 1 if "MC_GEMM_V2_PERSIST 1" in cfg else 0
     gen.SCHED = "h" if "MC_GEMM_V2_SCHED_H 1" in cfg else "r3"
+    gen.DEFER = 1 if "MC_GEMM_V2_DEFER 1" in cfg else 0
     inc = os.path.join(ROOT, "magcache_amd", "csrc", "gemm_v2_body.inc")
     try:
         assert open(inc).read() == gen.to_inc(gen.generate()), \
-            "regenerate with: python tools/gen_gemm_v2.py --write --mfma 16 --row 128 --persist 1 --sched h"
+            "regenerate with: python tools/gen_gemm_v2.py --write --mfma 16 --row 128 --persist 1 --sched h --defer 1"
     finally:
-        gen.PERSIST, gen.SCHED = 0, "r3"
+        gen.PERSIST, gen.SCHED, gen.DEFER = 0, "r3", 0
 
 
 # ---------------------------------------------------------------- persistent form (ROW 128): two trips of one workgroup
@@ -167,3 +168,71 @@ def test_gemm_v2_persistent_trips_hand_the_ring_over(dma_late, load_late, sched,
         want = mats[ia][:, :K].astype(np.float64) @ mats[iw][:, :K].astype(np.float64).T
         assert np.isfinite(got).all()
         assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
+
+
+# ---------------------------------------------------------------- schedule h with the deferred residual epilogue
+@pytest.mark.parametrize("dma_late,load_late,rows,with_gate", [(False, False, 256, True), (True, True, 200, True), (True, False, 256, False)])
+def test_gemm_v2_deferred_residual_epilogue(dma_late, load_late, rows, with_gate):
+    """Two trips of one workgroup.  Trip 1 (first = 1, nothing deferred) computes output tile X; the kernel's epilogue --
+    restated here -- leaves bf16(acc) of X row-major in the scratch tile.  Trip 2 (first = 0, deferred on) computes tile Y and,
+    inside its first 8 pairs of K tiles, applies x[m][n] += gate[n] * scratch[m][n] to the `rows` valid rows of X's x tile
+    (fp32 fma; rows past `rows` are out of range of the descriptor: loaded as 0, not stored).  Loads and LDS-DMA complete
+    only at their covering waits in the late modes: a wrong vmcnt count shows as poison or stale data."""
+    gen.MFMA, gen.ROW, gen.PERSIST, gen.SCHED, gen.DEFER = 16, 128, 1, "h", 1
+    try:
+        text = gen.generate()
+    finally:
+        gen.PERSIST, gen.SCHED, gen.DEFER = 0, "r3", 0
+    pairs = {0, 1, 9, 10, 14, 15, 18}
+    for k in range(19, -1, -1):
+        r = IN_BASE + 2 * k
+        text = text.replace(f"%{gen.IN0 + k}", f"s[{r}:{r + 1}]" if k in pairs else f"s{r}")
+    text += "  s_endpgm\n"
+    K = lda = 1280
+    ldx = 320
+    rng = np.random.default_rng(5)
+    mats = [emu.bf16_to_f32(emu.bf16_rne((0.1 * rng.standard_normal((256, lda))).astype(np.float32))) for _ in range(4)]   # Ax Wx Ay Wy
+    bases = [0x1000_0000, 0x2000_0000, 0x3000_0000, 0x4000_0000]
+    SCR, XB, GB = 0x5000_0000, 0x6000_0000, 0x7000_0000
+    x0 = rng.standard_normal((256, ldx)).astype(np.float32)
+    gate = rng.standard_normal(256).astype(np.float32)
+    scratch = np.zeros((256, 256), dtype=np.uint16)
+    xbuf = x0.copy()
+    nrec = 256 * lda * 2
+    lds, prev, outs = None, None, []
+    for trip, (ia, iw, first) in enumerate(((0, 1, 1), (2, 3, 0))):
+        m = emu.Machine(text, n_waves=4, lds_bytes=4 * gen.SUB, dma_late=dma_late, load_late=load_late)
+        if lds is not None:
+            m.lds = lds
+        lds = m.lds
+        for b, x in zip(bases, mats):
+            m.add_buffer(b, emu.bf16_rne(x).astype(np.uint16))
+        m.add_buffer(SCR, scratch.view(np.uint8).reshape(-1))
+        m.add_buffer(XB, xbuf.view(np.uint8).reshape(-1))
+        m.add_buffer(GB, gate.view(np.uint8).reshape(-1))
+        nxt = (bases[2], bases[3], nrec, nrec) if trip == 0 else (0, 0, 0, 0)
+        d_on = 0 if trip == 0 else 1
+        vals = [bases[ia], bases[iw], lda * 2, lda * 2, K // 32, None, 0, nrec, nrec, nxt[0], nxt[1], nxt[2], nxt[3], first,
+                SCR, XB, (rows * ldx * 4) if d_on else 0, ldx * 4, GB if with_gate else 0, d_on]
+        for wi, w in enumerate(m.waves):
+            w.v[:] = np.uint32(0x7FC0DEAD)
+            for k, val in enumerate(vals):
+                r = IN_BASE + 2 * k
+                val = w.wid if val is None else val
+                w.s[r] = np.uint32(val & 0xFFFFFFFF)
+                w.s[r + 1] = np.uint32((val >> 32) & 0xFFFFFFFF)
+        m.run()
+        acc = _read_acc16(m)
+        outs.append(acc)
+        if trip == 0:       # the kernel's epilogue: bf16(acc) row-major into the scratch tile
+            scratch[:] = emu.bf16_rne(acc).astype(np.uint16)
+    for got, (ia, iw) in zip(outs, ((0, 1), (2, 3))):
+        want = mats[ia][:, :K].astype(np.float64) @ mats[iw][:, :K].astype(np.float64).T
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
+    sval = emu.bf16_to_f32(scratch.astype(np.uint32))
+    g = gate if with_gate else np.ones(256, dtype=np.float32)
+    want_x = x0.copy()
+    want_x[:rows, :256] = (x0[:rows, :256].astype(np.float64) + g[None, :].astype(np.float64) * sval[:rows].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(xbuf[rows:], x0[rows:]) and np.array_equal(xbuf[:, 256:], x0[:, 256:])      # nothing outside the tile's valid rows
+    assert np.abs(xbuf[:rows, :256] - want_x[:rows, :256]).max() <= 1e-6 * np.abs(want_x).max()         # one fp32 fma per element

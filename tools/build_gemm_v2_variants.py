@@ -22,6 +22,8 @@ for spec in sys.argv[1:]:
     kv = dict(x.split("=") for x in rest.split(",") if x)
     gen.MFMA, gen.ROW, gen.PERSIST = int(kv.get("mfma", 16)), int(kv.get("row", 64)), int(kv.get("persist", 0))
     gen.SCHED = kv.get("sched", "r3")
+    gen.DEFER = int(kv.get("defer", 0))
+    gen.NCH = int(kv.get("nch", 4))
     for k, val in kv.items():                 # any further generator knob, e.g. H_RD=2
         if k.isupper():
             setattr(gen, k, int(val))
@@ -33,6 +35,8 @@ for spec in sys.argv[1:]:
     open(os.path.join(out, "gemm_v2_config.h"), "w").write(gen.config_h())
     obj = os.path.join(out, "gemm_bf16_v2.hip.o")
     extra = ["-DMC_V2_NO_EPI"] if kv.get("noepi") else []
+    if kv.get("deferabl"):
+        extra.append("-DMC_V2_DEFER_ABL=" + kv["deferabl"])
     if kv.get("xahead"):
         extra.append("-DMC_V2_XAHEAD=" + kv["xahead"])
     if kv.get("stagger"):

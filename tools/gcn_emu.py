@@ -713,7 +713,9 @@ class Machine:
         """raw-buffer LDS-DMA: buffer_load_dwordx4 voff, s[srd:srd+3], soff offen offset:imm lds
         global address = base + voff + soff + imm, range-checked as a whole against num_records (out of range reads 0);
         LDS address = M0 + imm + lane * 16 (profiles/r03/lds_dma_probe.log)"""
-        assert ins.mods.get("lds") and ins.mods.get("offen"), "only the LDS-DMA form is modelled"
+        if not ins.mods.get("lds"):
+            return self._buffer_load_vgpr(w, ins, o)
+        assert ins.mods.get("offen"), "only the offen form is modelled"
         if self.check and w.issued - w.m0_written - 1 < 1:
             raise HazardError(f"line {ins.line}: LDS-DMA right after an M0 write")
         self._haz_read(w, ins, o[0], "mem")
@@ -738,6 +740,56 @@ class Machine:
         else:
             fin()
             w.vm_q.append(None)
+
+    def _buffer_addr(self, w, ins, voff, srd_op, soff):
+        """raw buffer, offen: (global addresses [64], in-range mask) for a 16-byte access; the whole offset is range-checked"""
+        srd = srd_op[2]
+        base = int(w.s[srd]) | ((int(w.s[srd + 1]) & 0xFFFF) << 32)
+        nrec = int(w.s[srd + 2])
+        off = self.rd(w, voff).astype(np.int64) + int(self.rds(w, soff)) + ins.mods.get("offset", 0)
+        return base + off, (off >= 0) & (off + 16 <= nrec)
+
+    def _buffer_load_vgpr(self, w, ins, o):
+        """buffer_load_dwordx4 v[d:d+3], voff, s[srd:srd+3], soff offen [offset:imm] [sc1]: out of range reads 0"""
+        assert ins.mods.get("offen")
+        dst = o[0]
+        self._haz_read(w, ins, o[1], "mem")
+        addr, ok = self._buffer_addr(w, ins, o[1], o[2], o[3])
+
+        def fin():
+            val = np.zeros((64, 4), dtype=np.uint32)
+            for l in range(64):
+                if ok[l]:
+                    arr, o_ = self._find(int(addr[l]), 16)
+                    val[l] = arr[o_:o_ + 16].view(np.uint32)
+            for i in range(4):
+                self.wr(w, dst, val[:, i], i)
+        if self.load_late:
+            for i in range(4):
+                self.wr(w, dst, np.full(64, POISON, dtype=np.uint32), i)
+            w.vm_q.append(fin)
+        else:
+            fin()
+            w.vm_q.append(None)
+        self._haz_write(w, ins, dst, "mem")
+
+    def i_buffer_store_dwordx4(self, w, ins, o):
+        """buffer_store_dwordx4 v[d:d+3], voff, s[srd:srd+3], soff offen [offset:imm]: out of range is dropped"""
+        assert ins.mods.get("offen")
+        self._haz_read(w, ins, o[0], "mem")
+        self._haz_read(w, ins, o[1], "mem")
+        addr, ok = self._buffer_addr(w, ins, o[1], o[2], o[3])
+        data = np.stack([self.rd(w, o[0], i) for i in range(4)], axis=1).astype(np.uint32).view(np.uint8).reshape(64, 16)
+        for l in range(64):
+            if ok[l]:
+                arr, o_ = self._find(int(addr[l]), 16)
+                arr[o_:o_ + 16] = data[l]
+        w.vm_q.append(None)
+
+    def i_s_cmp_eq_u64(self, w, ins, o):
+        def r64(op):
+            return (int(self.rds(w, op, 0)) | (int(self.rds(w, op, 1)) << 32)) if op[0] == "reg" else int(self.rds(w, op))
+        w.scc = r64(o[0]) == r64(o[1])
 
     def i_global_load_dwordx4(self, w, ins, o):
         self._haz_read(w, ins, o[1], "mem")

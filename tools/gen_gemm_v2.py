@@ -40,8 +40,18 @@ S_T = 44
 S_ASRD2, S_WSRD2 = 52, 56    # (persistent form) descriptors of the workgroup's NEXT output tile
 S_DCUR2, S_FIRST = 60, 61
 S_LAST = 62
+# schedule "h" with the DEFERRED residual epilogue (DEFER = 1): the previous output tile's x += gate * bf16(acc + bias) runs inside
+# this tile's main loop, from a bf16 copy of that tile in a scratch buffer
+S_DSCR, S_DX = 64, 68        # buffer descriptors: the workgroup's scratch tile (256 x 256 bf16), the x rows of the deferred tile
+S_DGATE, S_DON, S_DSOFF, S_D4LDX, S_DCNT, S_DT = 72, 74, 75, 76, 77, 78
+S_LAST_D = 79
 N_INPUTS = 9                 # + 5 in the persistent form: next A / W tile pointers, their num_records, first-trip flag
-IN0 = 16                     # the asm statement's operands 0..15 are the accumulator outputs
+                             # + 6 with DEFER: scratch tile, x tile origin, its num_records, ldx in bytes, gate pointer, on / off
+IN0 = 8                      # the asm statement's operands 0..7 are the accumulator outputs (eight 32-register AGPR tuples)
+V_DG = 180                   # DEFER: gate of this lane's 8 columns
+V_DVS, V_DVX, V_DVX2 = 188, 189, 190      # lane offsets: scratch rows, x rows being loaded, x rows being stored
+V_DD = 192                   # 4 chunks x (4 scratch + 8 x) registers = v192..v239
+V_DT = 240                   # two temporaries
 
 V_FR = 0                     # fragment buffers: [p][A | W][8 fragments] x 4 registers = v0..v127
 V_BA, V_BW = 128, 132        # fragment read bases: [operand][k-step 0 | 1 (32x32x16 only)][slots 0-1 | slots 2-3]
@@ -80,6 +90,8 @@ ROW = 64                     # bytes of a row in the LDS ring.  64: ring of four
                              # Built and emulator-validated at the end of round 3, NOT yet measured (no GPU minutes left).
 
 
+DEFER = 0                    # (SCHED "h") 1: the stream also carries the deferred residual epilogue (see emit_pair_h)
+NCH = 4                      # chunks of the deferred epilogue per pair of K tiles (32 / NCH pairs carry them)
 SCHED = "r3"                 # (ROW 128) schedule of a K tile:
                              # "r3" (round 3): the whole tile kt+2 is fetched during the second k-step of tile kt behind ONE
                              #   vmcnt(0) + barrier per k-step: measured 1089-1127 TF on the QKV shape, the waves parked 32 % of
@@ -409,7 +421,24 @@ ABL = 0                      # schedule "h" timing ablations (results WRONG by c
                              # 8 no s_waitcnt in the loop
 
 
-def emit_tile_h(e, b, nxt=False):
+class VmQ:
+    """the wave's VMEM operations in issue order (retired in order): s_waitcnt vmcnt(N) for "the last operation tagged T has
+    retired" is N = the number of operations issued after it"""
+
+    def __init__(self, init):
+        self.q = list(init)
+
+    def issue(self, tag):
+        self.q.append(tag)
+
+    def need(self, tag):
+        idx = max(i for i, t in enumerate(self.q) if t == tag)
+        n = len(self.q) - 1 - idx
+        assert n <= 63, (tag, n)
+        return n
+
+
+def emit_tile_h(e, b, nxt=False, vq=None, fillers=None):
     """SCHED "h": K tile kt = 2 trip + b in ring slot b; fragment buffer 0 = k-step 0, buffer 1 = k-step 1.
     gaps   0..14   reads of W (kt, k-step 1)                                  | MFMAs 0..63 on buffer 0
     gap    18/19   lgkmcnt(0), barrier: every wave is done with the W rows of slot b
@@ -421,50 +450,65 @@ def emit_tile_h(e, b, nxt=False):
     gap  104/105   vmcnt(16), barrier: the A rows of tile kt+1 have landed
     gaps 106..120  reads of A (kt+1, k-step 0)
     In-order retirement per wave, issue order W0..7 A0..7 per tile: at gap 67 this tile's 12 pieces and the previous tile's
-    8 A pieces may be in flight (20), at gap 104 only this tile's 16."""
+    8 A pieces may be in flight (20), at gap 104 only this tile's 16 -- the counts come out of the VmQ model (vq: tags 'W<k>'
+    / 'A<k>' = pieces of the pair's K tile k; a pair starts from the previous pair's W1 x 8, A1 x 8).
+    fillers: wave-private instructions of the deferred residual epilogue, drawn in order into the gaps that hold no LDS read,
+    LDS-DMA piece, wait or barrier (at most two per gap, one of them a memory operation): ("v", text) VALU / SALU,
+    ("m", text, tag) a load or store, ("w", tag) wait for the loads tagged so."""
     e.c(f"---- K tile body {b} (schedule h)")
-    plan = {}
+    plan, busy = {}, set()
+    vq = vq or VmQ(["W1"] * 8 + ["A1"] * 8 + (["W2"] * 8 + ["A2"] * 8 if b else []))
+    fillers = fillers if fillers is not None else []
 
-    def at(g, fn, kind=0):
+    def at(g, fn, kind=0, occupies=True):
         if not (ABL & kind):
             plan.setdefault(g, []).append(fn)
+            if occupies:
+                busy.add(g)
 
     def m0_of(op, j):
         return lambda: e.i(f"s_add_u32 m0, {s(S_LDSW)}, {b * 65536 + (0 if op == 'A' else 32768) + j * 1024}")
 
     def dma_of(op, j):
         src, srd = (V_S128, S_ASRD2 if nxt else S_ASRD) if op == "A" else (V_S128 + 8, S_WSRD2 if nxt else S_WSRD)
-        return lambda: e.i(f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(S_DCUR2 if nxt else S_DCUR)} offen lds")
+
+        def fn():
+            e.i(f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(S_DCUR2 if nxt else S_DCUR)} offen lds")
+            vq.issue(f"{op}{b + 2}")
+        return fn
 
     def read_of(p, op, blk, slot, ks):
         return lambda: frag_read128(e, p, op, blk, slot, ks)
+
+    def wait_of(tag):
+        return lambda: e.i(f"s_waitcnt vmcnt({vq.need(tag)})")
 
     for i in range(8):
         at(2 * i, read_of(1, "W", i, b, 1), 1)
     at(18, lambda: e.i("s_waitcnt lgkmcnt(0)"), 8)
     at(19, lambda: e.i("s_barrier"), 4)
     for i in range(8):
-        at(20 + 3 * i, m0_of("W", i), 2)
+        at(20 + 3 * i, m0_of("W", i), 2, occupies=False)
         at(21 + 3 * i, dma_of("W", i), 2)
         at(23 + 3 * i, read_of(1, "A", i, b, 1), 1)
     at(50, lambda: e.i("s_waitcnt lgkmcnt(0)"), 8)
     at(51, lambda: e.i("s_barrier"), 4)
     for i in range(4):
-        at(52 + 3 * i, m0_of("A", i), 2)
+        at(52 + 3 * i, m0_of("A", i), 2, occupies=False)
         at(53 + 3 * i, dma_of("A", i), 2)
-    at(67, lambda: e.i("s_waitcnt vmcnt(20)"), 8)
+    at(67, wait_of(f"W{b + 1}"), 8)
     at(68, lambda: e.i("s_barrier"), 4)
     for i in range(8):
         at(69 + 2 * i, read_of(0, "W", i, 1 - b, 0), 1)
     for i in range(4):
-        at(85 + 3 * i, m0_of("A", 4 + i), 2)
+        at(85 + 3 * i, m0_of("A", 4 + i), 2, occupies=False)
         at(86 + 3 * i, dma_of("A", 4 + i), 2)
-    at(104, lambda: e.i("s_waitcnt vmcnt(16)"), 8)
+    at(104, wait_of(f"A{b + 1}"), 8)
     at(105, lambda: e.i("s_barrier"), 4)
     for i in range(8):
         at(106 + 2 * i, read_of(0, "A", i, 1 - b, 0), 1)
     cur = S_DCUR2 if nxt else S_DCUR
-    at(122, lambda: e.i(f"s_add_u32 {s(cur)}, {s(cur)}, 128"))
+    at(122, lambda: e.i(f"s_add_u32 {s(cur)}, {s(cur)}, 128"), occupies=False)
     g = 0
     for ks in range(2):
         for nb in range(8):
@@ -472,9 +516,57 @@ def emit_tile_h(e, b, nxt=False):
                 e.i(f"v_mfma_f32_16x16x32_bf16 {a(acc(nb, mb), 4)}, {v(frag(ks, 'W', nb), 4)}, {v(frag(ks, 'A', mb), 4)}, {a(acc(nb, mb), 4)}")
                 for fn in plan.get(g, []):
                     fn()
+                if g not in busy and g >= 20:       # (the first gaps carry the k-step-1 reads the MFMAs 64.. wait for)
+                    took, mem = 0, 0
+                    while fillers and took < 2:
+                        it = fillers[0]
+                        if it[0] == "m":
+                            if mem:
+                                break
+                            mem = 1
+                            e.i(it[1])
+                            vq.issue(it[2])
+                        elif it[0] == "w":
+                            e.i(f"s_waitcnt vmcnt({vq.need(it[1])})")
+                        else:
+                            e.i(it[1])
+                        fillers.pop(0)
+                        took += 1
                 g += 1
+    assert not fillers, f"{len(fillers)} deferred instructions did not fit into the tile"
     if not (ABL & 8):
         e.i("s_waitcnt lgkmcnt(0)")
+
+
+def deferred_fillers():
+    """the deferred residual epilogue of ONE pair of K tiles: 4 chunks (4 rows x 128 columns of this wave's quarter of the
+    previous output tile each): (tile 0 of the pair) the chunk's bf16 row from the scratch tile and its 8 x values per lane;
+    (tile 1) x += gate * value, stores.  Loads ~130 MFMA gaps ahead of their use."""
+    stage_a, stage_b = [], []
+    for k in range(NCH):
+        d = V_DD + 12 * k
+        stage_a += [("m", f"buffer_load_dwordx4 {v(d, 4)}, {v(V_DVS)}, {s(S_DSCR, 4)}, {s(S_DSOFF)} offen sc1", f"L{k}"),
+                    ("v", f"s_add_u32 {s(S_DSOFF)}, {s(S_DSOFF)}, 2048"),
+                    ("m", f"buffer_load_dwordx4 {v(d + 4, 4)}, {v(V_DVX)}, {s(S_DX, 4)}, 0 offen", f"L{k}"),
+                    ("m", f"buffer_load_dwordx4 {v(d + 8, 4)}, {v(V_DVX)}, {s(S_DX, 4)}, 0 offen offset:16", f"L{k}"),
+                    ("v", f"v_add_u32 {v(V_DVX)}, {s(S_D4LDX)}, {v(V_DVX)}")]
+        stage_b.append(("w", f"L{k}"))
+        for j in range(8):
+            t = V_DT + (j & 1)
+            w = d + j // 2
+            stage_b.append(("v", f"v_and_b32 {v(t)}, 0xffff0000, {v(w)}" if j & 1 else f"v_lshlrev_b32 {v(t)}, 16, {v(w)}"))
+            stage_b.append(("v", f"v_fma_f32 {v(d + 4 + j)}, {v(t)}, {v(V_DG + j)}, {v(d + 4 + j)}"))
+        stage_b += [("m", f"buffer_store_dwordx4 {v(d + 4, 4)}, {v(V_DVX2)}, {s(S_DX, 4)}, 0 offen", "S"),
+                    ("m", f"buffer_store_dwordx4 {v(d + 8, 4)}, {v(V_DVX2)}, {s(S_DX, 4)}, 0 offen offset:16", "S"),
+                    ("v", f"v_add_u32 {v(V_DVX2)}, {s(S_D4LDX)}, {v(V_DVX2)}")]
+    return stage_a, stage_b
+
+
+def emit_pair_h(e, nxt=False, deferred=False):
+    vq = VmQ(["W1"] * 8 + ["A1"] * 8)
+    fa, fb = deferred_fillers() if deferred else ([], [])
+    emit_tile_h(e, 0, nxt, vq, fa)
+    emit_tile_h(e, 1, nxt, vq, fb)
 
 
 def emit_prologue_h(e):
@@ -504,6 +596,49 @@ def emit_prologue_h(e):
         frag_read128(e, 0, "A", blk, 0, 0)
     e.i("s_waitcnt lgkmcnt(0)")
     e.i(f"s_lshr_b32 {s(S_IT)}, {s(S_NK)}, 2")                          # nk counts 32-k steps: trips of the 2-tile loop
+    if DEFER:
+        emit_deferred_setup(e)
+
+
+def emit_deferred_setup(e):
+    """descriptors, lane offsets and gate values of the deferred residual epilogue (inputs IN0 + 14 .. 19)"""
+    e.c("---- deferred residual epilogue of the previous output tile: set-up")
+    e.i(f"s_mov_b32 {s(S_DON)}, %{IN0 + 19}")
+    e.i(f"s_mov_b64 {s(S_DSCR, 2)}, %{IN0 + 14}")
+    e.i(f"s_and_b32 {s(S_DSCR + 1)}, {s(S_DSCR + 1)}, 0xffff")
+    e.i(f"s_mov_b32 {s(S_DSCR + 2)}, 131072")
+    e.i(f"s_mov_b32 {s(S_DSCR + 3)}, 0x00020000")
+    e.i(f"s_mov_b64 {s(S_DX, 2)}, %{IN0 + 15}")
+    e.i(f"s_and_b32 {s(S_DX + 1)}, {s(S_DX + 1)}, 0xffff")
+    e.i(f"s_mov_b32 {s(S_DX + 2)}, %{IN0 + 16}")
+    e.i(f"s_mov_b32 {s(S_DX + 3)}, 0x00020000")
+    e.i(f"s_mov_b32 {s(S_DT)}, %{IN0 + 17}")                            # ldx in bytes
+    e.i(f"s_lshl_b32 {s(S_D4LDX)}, {s(S_DT)}, 2")
+    e.i(f"s_mov_b64 {s(S_DGATE, 2)}, %{IN0 + 18}")
+    e.i(f"s_mov_b32 {s(S_DSOFF)}, 0")
+    t0, t1, t2 = V_DT, V_DT + 1, V_DT + 2
+    # lane -> row rr = lane / 16 of a chunk, columns 8 (lane % 16) .. + 7 of the wave's 128; wave (wr, wc) = (wv / 2, wv % 2)
+    e.i(f"v_lshrrev_b32 {v(t0)}, 4, {v(V_LANE)}")                       # rr
+    e.i(f"v_and_b32 {v(t1)}, 15, {v(V_LANE)}")                          # c16
+    e.i(f"s_lshr_b32 {s(S_DT + 1)}, {s(S_WV)}, 1")
+    e.i(f"s_lshl_b32 {s(S_DT + 1)}, {s(S_DT + 1)}, 7")                  # 128 wr
+    e.i(f"v_add_u32 {v(t0)}, {s(S_DT + 1)}, {v(t0)}")                   # tile row of the lane in chunk 0
+    e.i(f"s_and_b32 {s(S_DT + 1)}, {s(S_WV)}, 1")
+    e.i(f"s_lshl_b32 {s(S_DT + 1)}, {s(S_DT + 1)}, 7")                  # 128 wc
+    e.i(f"v_lshl_add_u32 {v(t1)}, {v(t1)}, 3, {s(S_DT + 1)}")           # tile column 128 wc + 8 c16
+    e.i(f"v_lshlrev_b32 {v(t2)}, 9, {v(t0)}")                           # scratch: row * 512 bytes
+    e.i(f"v_lshl_add_u32 {v(V_DVS)}, {v(t1)}, 1, {v(t2)}")              # + column * 2
+    e.i(f"v_mul_lo_u32 {v(t2)}, {v(t0)}, {s(S_DT)}")                    # x: row * ldx bytes
+    e.i(f"v_lshl_add_u32 {v(V_DVX)}, {v(t1)}, 2, {v(t2)}")              # + column * 4
+    e.i(f"v_mov_b32 {v(V_DVX2)}, {v(V_DVX)}")
+    for j in range(8):
+        e.i(f"v_mov_b32 {v(V_DG + j)}, 1.0")
+    e.i(f"s_cmp_eq_u64 {s(S_DGATE, 2)}, 0")
+    e.i("s_cbranch_scc1 L_nogate")
+    e.i(f"v_lshlrev_b32 {v(t2)}, 2, {v(t1)}")                           # gate: column * 4 bytes
+    e.i(f"global_load_dwordx4 {v(V_DG, 4)}, {v(t2)}, {s(S_DGATE, 2)}")
+    e.i(f"global_load_dwordx4 {v(V_DG + 4, 4)}, {v(t2)}, {s(S_DGATE, 2)} offset:16")
+    e.label("L_nogate")
 
 
 def generate():
@@ -512,16 +647,26 @@ def generate():
         e = E()
         emit_prologue_h(e)
         e.i(f"s_mov_b32 {s(S_DCUR2)}, 0")
+        if DEFER:
+            # 8 pairs of K tiles carry the 32 chunks of the previous output tile's residual epilogue (the kernel turns the
+            # deferred form on only for K >= 9 pairs)
+            e.i(f"s_cmp_eq_u32 {s(S_DON)}, 0")
+            e.i("s_cbranch_scc1 L_loop")
+            e.i(f"s_mov_b32 {s(S_DCNT)}, {32 // NCH}")
+            e.label("L_loop_d")
+            emit_pair_h(e, deferred=True)
+            e.i(f"s_sub_u32 {s(S_IT)}, {s(S_IT)}, 1")
+            e.i(f"s_sub_u32 {s(S_DCNT)}, {s(S_DCNT)}, 1")
+            e.i(f"s_cmp_lg_u32 {s(S_DCNT)}, 0")
+            e.i("s_cbranch_scc1 L_loop_d")
         e.label("L_loop")
         e.i(f"s_cmp_eq_u32 {s(S_IT)}, 1")
         e.i("s_cbranch_scc1 L_lasttrip")
-        for b in range(2):
-            emit_tile_h(e, b)
+        emit_pair_h(e)
         e.i(f"s_sub_u32 {s(S_IT)}, {s(S_IT)}, 1")
         e.i("s_branch L_loop")
         e.label("L_lasttrip")
-        for b in range(2):
-            emit_tile_h(e, b, nxt=True)
+        emit_pair_h(e, nxt=True)
         # the next tile's K tiles 0, 1 stay in flight under the epilogue (the caller drains them behind its last tile)
         e.i("s_nop 15")
         e.i("s_nop 15")
@@ -583,13 +728,15 @@ def to_inc(text):
 
 def config_h():
     return ("// GENERATED by tools/gen_gemm_v2.py\n#define MC_GEMM_V2_MFMA %d\n#define MC_GEMM_V2_ROW %d\n#define MC_GEMM_V2_PERSIST %d\n"
-            "#define MC_GEMM_V2_SCHED_H %d\n" % (MFMA, ROW, PERSIST, 1 if SCHED == "h" else 0))
+            "#define MC_GEMM_V2_SCHED_H %d\n#define MC_GEMM_V2_DEFER %d\n#define MC_GEMM_V2_DEFER_PAIRS %d\n"
+            % (MFMA, ROW, PERSIST, 1 if SCHED == "h" else 0, DEFER, 32 // NCH))
 
 
 def clobbers():
     # v0..v191: fragments, bases, offsets, temporaries (the highest register any layout uses is v179); v192..v255 stay with
     # the compiler (the persistent kernel needs a few for SGPR spills across the statement)
-    regs = [f"v{i}" for i in range(192)] + [f"s{i}" for i in range(20, S_LAST + 1)] + ["vcc", "scc", "m0", "memory"]
+    nv, ns = (244, S_LAST_D) if DEFER else (192, S_LAST)
+    regs = [f"v{i}" for i in range(nv)] + [f"s{i}" for i in range(20, ns + 1)] + ["vcc", "scc", "m0", "memory"]
     out, line = ["// GENERATED by tools/gen_gemm_v2.py: registers owned by the asm block (the AGPRs are its outputs)"], ""
     for r in regs:
         tok = f'"{r}", '
@@ -602,7 +749,7 @@ def clobbers():
 
 
 def main():
-    global MFMA, ROW, PERSIST, SCHED
+    global MFMA, ROW, PERSIST, SCHED, DEFER, NCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--asm")
@@ -610,8 +757,12 @@ def main():
     ap.add_argument("--row", type=int, default=ROW)
     ap.add_argument("--persist", type=int, default=PERSIST)
     ap.add_argument("--sched", default=SCHED)
+    ap.add_argument("--defer", type=int, default=DEFER)
+    ap.add_argument("--nch", type=int, default=NCH)
     args = ap.parse_args()
+    NCH = args.nch
     SCHED = args.sched
+    DEFER = args.defer
     MFMA = args.mfma
     ROW = args.row
     PERSIST = args.persist
