@@ -69,6 +69,11 @@ typedef struct {
                            fly; a speed / quality option (~3 % relative error per GEMM), never the default.
                            2: the same Linears on MX block-scaled fp8 (one E8M0 scale per 32 input features of every
                            token and of every output channel, v_mfma_scale_f32_16x16x128_f8f6f4; mc_op_gemm_mxfp8) */
+  int no_context_cache; /* 1: do not reserve the text-context cache (the per-block cross-attention K|V of two prompts:
+                           2 x layers x text_len x 2 dim bf16 = 0.19 GB at 1.3B, 0.84 GB at 14B); mc_set_context /
+                           mc_use_context then fail with MC_ESTATE and every forward takes its context argument */
+  int no_token_timesteps; /* 1: do not reserve the second modulation set and the per-token selector of
+                           mc_set_token_timesteps (Wan2.2 TI2V); the call then fails with MC_ESTATE */
 } mc_config;
 
 const char* mc_last_error(void);

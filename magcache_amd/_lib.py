@@ -24,7 +24,8 @@ class McConfig(C.Structure):
                                        "text_dim", "text_len", "latent_f", "latent_h", "latent_w")] + \
                [("eps", C.c_float)] + \
                [(n, C.c_int) for n in ("sp_rank", "sp_size", "n_branches", "calibration", "clip_dim", "vace_layers",
-                                         "vace_stride", "vace_in_dim", "fp8_linear")]
+                                         "vace_stride", "vace_in_dim", "fp8_linear", "no_context_cache",
+                                         "no_token_timesteps")]
 
 
 class MagCacheHipError(RuntimeError):

@@ -235,6 +235,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (c.vace_layers < 0 || (c.vace_layers > 0 && (c.vace_stride <= 0 || c.vace_in_dim <= 0 ||
                                                    (c.vace_layers - 1) * c.vace_stride >= c.num_layers)))
     return fail(MC_EINVAL, "bad VACE geometry: %d blocks, stride %d, in_dim %d", c.vace_layers, c.vace_stride, c.vace_in_dim);
+  if ((c.no_context_cache | c.no_token_timesteps) & ~1) return fail(MC_EINVAL, "no_context_cache / no_token_timesteps must be 0 or 1");
   if (c.fp8_linear < 0 || c.fp8_linear > 2) return fail(MC_EINVAL, "fp8_linear must be 0, 1 (per-row scales) or 2 (MX block scales)");
   if (c.fp8_linear && ((c.dim % 256) || (c.ffn_dim % 256) || c.dim < 512 || c.ffn_dim < 512))
     return fail(MC_EINVAL, "fp8_linear needs dim and ffn_dim to be multiples of 256 and >= 512");
@@ -418,12 +419,14 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   add_buf(e, cur, "ctx", (size_t)e->ctx_rows * d * 2);
   add_buf(e, cur, "ckv", (size_t)e->ctx_rows * 2 * d * 2);
   add_buf(e, cur, "ctx_cache", (size_t)2 * e->ctx_rows * d * 2);                              // [2 slots][ctx_rows][d]
-  add_buf(e, cur, "ckv_cache", (size_t)2 * (e->NL + e->NV) * e->ctx_rows * 2 * d * 2);        // [2][layers][ctx_rows][2d]
+  if (!c.no_context_cache)      // (0.84 GB at 14B that a caller who passes its context every forward never uses)
+    add_buf(e, cur, "ckv_cache", (size_t)2 * (e->NL + e->NV) * e->ctx_rows * 2 * d * 2);      // [2][layers][ctx_rows][2d]
   // two sets of everything that depends on t: set 0 for the (maximum) timestep, set 1 for the second value per-token
   // timesteps may carry (Wan2.2 TI2V: the conditioning frame's tokens have t = 0)
-  add_buf(e, cur, "temb", (size_t)2 * (c.freq_dim + 2 * d + 6 * d) * 4);  // 2 x (sinus | h1 | e | e0)
-  add_buf(e, cur, "emod", (size_t)2 * (e->NL + e->NV) * 6 * d * 4);
-  add_buf(e, cur, "tok_sel", (size_t)Lp + 256);
+  const size_t tsets = c.no_token_timesteps ? 1 : 2;
+  add_buf(e, cur, "temb", tsets * (c.freq_dim + 2 * d + 6 * d) * 4);  // sets x (sinus | h1 | e | e0)
+  add_buf(e, cur, "emod", tsets * (e->NL + e->NV) * 6 * d * 4);
+  add_buf(e, cur, "tok_sel", c.no_token_timesteps ? 256 : (size_t)Lp + 256);
   add_buf(e, cur, "tok_t2", 64);
   if (c.fp8_linear) {
     add_buf(e, cur, "aq", Lp * std::max(d, ffn));            // e4m3 activations of the current fp8 GEMM
@@ -1150,6 +1153,7 @@ mc_status mc_set_context(mc_engine* e, int slot, const void* context_dev, mc_dty
   mc_status st = check_ready(e);
   if (st != MC_OK) return st;
   if (slot < 0 || slot > 1) return fail(MC_EINVAL, "context slot %d out of range (0, 1)", slot);
+  if (e->cfg.no_context_cache) return fail(MC_ESTATE, "the engine was created with no_context_cache: pass the context to every forward");
   if (!context_dev) return fail(MC_EINVAL, "null context");
   const int d = e->d;
   bf16_t* ctx = e->buf<bf16_t>("ctx_cache") + (size_t)slot * e->ctx_rows * d;
@@ -1169,6 +1173,7 @@ mc_status mc_set_context(mc_engine* e, int slot, const void* context_dev, mc_dty
 mc_status mc_use_context(mc_engine* e, int slot) {
   if (!e) return fail(MC_EINVAL, "null engine");
   if (slot < -1 || slot > 1) return fail(MC_EINVAL, "context slot %d out of range (-1, 0, 1)", slot);
+  if (slot >= 0 && e->cfg.no_context_cache) return fail(MC_ESTATE, "the engine was created with no_context_cache");
   if (slot >= 0 && !e->ctx_valid[slot]) return fail(MC_ESTATE, "context slot %d was never set (mc_set_context)", slot);
   e->ctx_active = slot;
   return MC_OK;
@@ -1177,6 +1182,7 @@ mc_status mc_use_context(mc_engine* e, int slot) {
 mc_status mc_set_token_timesteps(mc_engine* e, const float* t_tokens_dev, mc_stream) {
   if (!e) return fail(MC_EINVAL, "null engine");
   if (t_tokens_dev && e->NV > 0) return fail(MC_EINVAL, "per-token timesteps are not defined for the VACE model");
+  if (t_tokens_dev && e->cfg.no_token_timesteps) return fail(MC_ESTATE, "the engine was created with no_token_timesteps");
   e->tok_t = t_tokens_dev;
   return MC_OK;
 }

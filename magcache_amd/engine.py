@@ -112,7 +112,10 @@ class Engine:
                      sp_rank=sp_rank, sp_size=sp_size, n_branches=n_branches, calibration=int(calibration),
                      clip_dim=cfg.get("clip_dim", 0), vace_layers=vace_geometry(cfg)[0], vace_stride=vace_geometry(cfg)[1],
                      vace_in_dim=cfg.get("vace_in_dim", 0) if vace_geometry(cfg)[0] else 0,
-                     fp8_linear=int(cfg.get("fp8_linear", 0) or 0))
+                     fp8_linear=int(cfg.get("fp8_linear", 0) or 0),
+                     no_context_cache=int(bool(cfg.get("no_context_cache", 0))),
+                     no_token_timesteps=int(bool(cfg.get("no_token_timesteps", 0))))
+        self.context_cache = not cfg.get("no_context_cache", 0)
         self.sp_rank, self.sp_size, self.n_branches = sp_rank, sp_size, n_branches
         self.vace_layers, self.vace_stride = vace_geometry(cfg)
         h = C.c_void_p()

@@ -212,7 +212,7 @@ class WanModelHIP:
         elif hasattr(self.engine, "set_token_timesteps"):
             self.engine.set_token_timesteps(None)
         t = t if not torch.is_tensor(t) else t.to(self.device)
-        if hasattr(self.engine, "set_context"):
+        if hasattr(self.engine, "set_context") and getattr(self.engine, "context_cache", True):
             self._cached_context(context[0])
             ctx = None
         else:

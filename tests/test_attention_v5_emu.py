@@ -252,3 +252,29 @@ def test_v5_two_deep_ring_variant_is_also_right():
 def test_v5_inc_file_is_current():
     inc = os.path.join(ROOT, "magcache_amd", "csrc", "attention_v5_body.inc")
     assert open(inc).read() == gen.to_inc(gen.generate()), "regenerate with: python tools/gen_attention_v5.py --write"
+
+
+@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("spike_row,target", [(100, 122.0), (200, 125.0), (330, 126.5)])
+def test_v5_lazy_reference_spike_between_2p120_and_2p128_with_large_values(spike_row, target, mfma):
+    """one key whose score exceeds everything before it by 2^120 .. 2^128 (log2 units ~124-126 for query row 5), in
+    a tile AWAY from the last one, with |V| ~ 50: the exponentials of that tile are finite but the row sum passes the 2^120
+    vote threshold only after P has been formed -- correctness rests on the reference move (or the vote + restart) happening
+    before those P words are multiplied into O.  Whatever path the workgroup takes, every output must be finite and match the
+    fp64 softmax."""
+    pb = Problem(448, 1, 2, 1, 1.0, 7, False)
+    nh, head = pb.n_heads, pb.head
+    q5 = pb.qkv[5, head * 128:(head + 1) * 128]
+    gain = target / (float(q5.astype(np.float64) @ q5.astype(np.float64)) / np.sqrt(128.0) * 1.4426950408889634)
+    pb.qkv[spike_row, nh * 128 + head * 128:nh * 128 + (head + 1) * 128] = bf16_round(gain * q5)
+    pb.qkv[:, 2 * nh * 128:] = bf16_round(50.0 * pb.qkv[:, 2 * nh * 128:])                     # large values
+    pb.qkv_bits = emu.bf16_rne(pb.qkv).astype(np.uint16)
+    k = pb.qkv[spike_row, nh * 128 + head * 128:nh * 128 + (head + 1) * 128].astype(np.float64)
+    s_log2 = float(q5.astype(np.float64) @ k) / np.sqrt(128.0) * 1.4426950408889634
+    assert 118.0 < s_log2 < 128.0, s_log2                                                       # the case this test is about
+    out_bits, _, m = launch(pb, dma_late=True, load_late=True, cfg={"mfma": mfma})
+    got = emu.bf16_to_f32(out_bits[:, head * 128:(head + 1) * 128].astype(np.uint32))
+    want, _ = pb.reference([0])
+    assert np.isfinite(got).all()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 8e-3
+    assert np.abs(got[5] - want[5]).max() <= 2e-2 * np.abs(want[5]).max()                       # the row with the spike

@@ -708,3 +708,47 @@ def test_text_context_cache_equals_uncached_forward():
         assert torch.equal(m([lat], t=tt, context=[c1], seq_len=L)[0], want1)
     c0.mul_(2.0)                                                      # in-place edit bumps the version: recomputed
     assert not torch.equal(m([lat], t=tt, context=[c0], seq_len=L)[0], want0)
+    # MAGCACHE_COMPARE_CONDITIONING=1: a write that bypasses the version counter is seen through the checksum
+    # the key carries -- without it the stale cached K|V are reused, which is the documented limit
+    os.environ["MAGCACHE_COMPARE_CONDITIONING"] = "1"
+    try:
+        m2 = type("WanModelHIPCtxCmp", (M.WanModelHIP,), {})(cfg, grid, device=DEV, calibration=False)
+        m2.load_state_dict(oracle.state_dict())
+        cc = c1.clone()
+        a = m2([lat], t=tt, context=[cc], seq_len=L)[0].clone()
+        assert torch.equal(a, want1)
+        cc.data.copy_(cc.data * 3.0)                                   # same object, same version, new content
+        b = m2([lat], t=tt, context=[cc], seq_len=L)[0]
+        assert not torch.equal(b, want1)
+    finally:
+        del os.environ["MAGCACHE_COMPARE_CONDITIONING"]
+
+
+def test_engine_without_context_cache_and_token_timesteps():
+    """mc_config.no_context_cache / no_token_timesteps: the text-context cache and the second modulation set
+    are not carved out of the workspace; the calls that need them fail with MC_ESTATE; a forward that is handed its context
+    gives the bits of the default engine."""
+    cfg = W.tiny_config(num_layers=2, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64)
+    grid = (2, 16, 16)
+    oracle = W.init_synthetic_(W.WanModel(**cfg), seed=2, std=0.05)
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(16, *grid, generator=g).to(DEV)
+    c0 = torch.randn(21, cfg["text_dim"], generator=g).to(DEV)
+    e = Engine(cfg, grid, device=DEV, n_branches=2, calibration=False)
+    e.load_weights(oracle.state_dict())
+    want = e.forward(lat, 500.0, c0).clone()
+    lean = Engine(dict(cfg, no_context_cache=1, no_token_timesteps=1), grid, device=DEV, n_branches=2, calibration=False)
+    lean.load_weights(oracle.state_dict())
+    assert lean.ws.numel() < e.ws.numel()
+    assert torch.equal(lean.forward(lat, 500.0, c0), want)
+    with pytest.raises(_lib.MagCacheHipError) as ei:
+        lean.set_context(0, c0)
+    assert ei.value.status == _lib.MC_ESTATE
+    with pytest.raises(_lib.MagCacheHipError) as ei:
+        lean.set_token_timesteps(torch.zeros(lean.seq_len, device=DEV))
+    assert ei.value.status == _lib.MC_ESTATE
+    # the shim notices and passes the context every forward
+    m = type("WanModelHIPNoCtxCache", (M.WanModelHIP,), {})(dict(cfg, no_context_cache=1), grid, device=DEV, calibration=False)
+    m.load_state_dict(oracle.state_dict())
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    assert torch.equal(m([lat], t=torch.tensor([500.0], device=DEV), context=[c0], seq_len=L)[0], want)

@@ -711,6 +711,16 @@ def emit_rescale_routine(E, par, n_ret, lazy=False):
             E.i("s_nop 0")
             E.i(f"v_floor_f32 {v(d)}, {v(d)}")
             E.i(f"v_max_f32 {v(d)}, 0, {v(d)}")
+        if not E.pipe:
+            # Two-phase lazy loop (the pipelined one rescales the packed P words BEFORE they meet V): this tile's P has
+            # already been multiplied into O.  A row sum that jumped past 2^96 in one tile means P up to 2^96+ times |V| went
+            # into fp32 accumulators -- O may hold inf although every row sum is finite again after the move.  Such a row
+            # gets an infinite row sum: the vote at the end fails and the workgroup starts over in the exact loop.
+            # (tests/test_attention_v5_emu.py, spike between 2^120 and 2^128 with |V| ~ 50: ADVICE r03.)
+            E.i(f"v_mov_b32 {v(M.V_T + 1)}, 0x7f800000")
+            for qb in range(M.NQB):
+                E.i(f"v_cmp_lt_f32 vcc, 0x42c00000, {v(M.V_D + qb)}")          # 96 < d
+                E.i(f"v_cndmask_b32 {v(M.V_L + 2 * qb)}, {v(M.V_L + 2 * qb)}, {v(M.V_T + 1)}, vcc")
         for qb in range(M.NQB):
             d, al = M.V_D + qb, M.V_ALPHA + qb
             E.i(f"v_add_f32 {v(M.V_M + qb)}, {v(M.V_M + qb)}, {v(d)}")
