@@ -88,7 +88,9 @@ def kernel_rooflines(cfg, device):
     t = ev_time(lambda: H.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, heads, Lp, SEQ, 1, 128 ** -0.5), 5)
     fl = 4.0 * SEQ * SEQ * d
     traffic, traffic_src = pmc_traffic("attn_fwd_v5_kernel")
-    res["attention"] = dict(bound="mfma", achieved=fl / t / 1e12, peak=2500.0, unit="TFLOP/s",
+    # (back-to-back launches of the self-attention kernel: the chip runs them at its power limit, ~7 % slower than between
+    # the engine's other kernels; the line's roofline object carries the LIVE figure of the timed region)
+    res["attention_back_to_back"] = dict(bound="mfma", achieved=fl / t / 1e12, peak=2500.0, unit="TFLOP/s",
                             frac=fl / t / 2.5e15, traffic=traffic, traffic_source=f"committed PMC pass, not this run: {traffic_src}",
                             ms=t * 1e3, shape=f"L={SEQ} heads={heads} hd=128")
     # cross-attention: the same kernel family on 512 text keys (q = the projected tokens, k|v = the cached context rows)
@@ -500,7 +502,7 @@ def bench_main():
         line.update(extra)
         if world == 1 and not args.no_kernels:
             k = kernel_rooflines(cfg, device)
-            line["roofline"] = {kk: k["attention"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+            line["roofline"] = {kk: k["attention_back_to_back"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic",
                                                                   "traffic_source")}
             if attn_live and attn_live[1] > 0:
                 # the dominant kernel's average launch duration inside the timed (no-cache) region: algorithmic

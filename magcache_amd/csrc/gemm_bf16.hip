@@ -221,16 +221,21 @@ hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stre
 // Kernel choice.  g_gemm_kernel: 0 = by shape, 1 = always the 128x128 kernel, 2 = the 256x256
 // kernel wherever it is supported (mc_set_option("gemm_kernel", v); used by the parity tests and A/B benchmarks);
 // 3 = the 4-wave variant tools/kernels_ab/gemm_bf16_w128.hip, linked only into the A/B library (-DMC_AB_KERNELS).
-// By shape: estimated throughput = (fraction of the tile slots the grid fills, over its whole number of waves) x the
-// kernel's per-tile rate.  The 256x256 kernel runs one workgroup per CU (256 slots) and is ~1.3x faster per tile; the
-// 128x128 kernel runs two per CU (512 slots) and has 4x the tiles, so it wins when M*N is small (measured on the
-// FLUX / sequence-parallel shapes with tools/gemm_smallm_ab.py: e.g. M=1024 N=9216: 858 vs 660 TF for 256^2,
-// M=512 N=9216: 490 vs 566 TF).  K < 1024: the 256^2 kernel's prologue/epilogue dominate, keep the small one.
+// By shape (round 4, remeasured with gemm_v2 as the 256^2 kernel: tools/gemm_smallm_v2_ab.py, profiles/r04/
+// gemm_smallm_v2_ab.log): time in units of one 256^2 tile's K loop.  A 256^2 kernel needs ceil(tiles256 / 256) of them
+// (one workgroup per CU).  A 128^2 workgroup alone on a CU needs ~0.62 of that, two co-resident ones ~1.45 x 0.62 each
+// pair; a CU gets n = ceil(tiles128 / 256) of them.  Examples (us, 256^2 vs 128^2): M=1536 N=9216 K=3072 71 vs 74;
+// M=1536 N=12288 GELU 124 vs 145; M=8192 N=3072 residual 139 vs 177; M=1024 N=3072 K=12288 188 vs 122; M=512 N=9216 53 vs
+// 50.  K < 1024: the 256^2 kernels' prologue / epilogue dominate, keep the small one.
 int g_gemm_kernel = 0;
 
-static double fill_efficiency(long tiles, long slots) {
-  const long waves = (tiles + slots - 1) / slots;
-  return (double)tiles / (double)(waves * slots);
+static bool prefer_256(const GemmParams& p) {
+  const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
+  const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const double t256 = (double)((tiles256 + 255) / 256);
+  const long n = (tiles128 + 255) / 256;
+  const double t128 = 0.62 * (1.45 * (double)(n / 2) + (double)(n % 2));
+  return t256 <= t128;
 }
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
@@ -240,9 +245,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
     if (g_gemm_kernel == 2) {
       big = true;
     } else if (p.K >= 1024) {
-      const long tiles_big = (long)((p.M + 255) / 256) * (p.N / 256);
-      const long tiles_small = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-      big = 1.3 * fill_efficiency(tiles_big, 256) >= fill_efficiency(tiles_small, 512);
+      big = prefer_256(p);
     }
   }
   // generation 2 (4 waves x 128 x 128, generated stream, round 4: schedule "h" + row-major epilogues) takes the three hot

@@ -235,7 +235,9 @@ def test_v5_pipelined_body_read_placement_options(cfg):
 
 @pytest.mark.parametrize("cfg", [{"mfma": 32, "lazy": 1, "pipe": 0}, {"mfma": 32, "lazy": 0, "hoist": 0},
                                  {"mfma": 32, "barrier_every": 1}, {"mfma": 16, "lazy": 1, "barrier_every": 1},
-                                 {"mfma": 32, "pipe": 0, "kread_from": 12, "kread_to": 31}, {"mfma": 32, "exp_gap": 1, "pipe": 0}])
+                                 {"mfma": 32, "pipe": 0, "kread_from": 12, "kread_to": 31}, {"mfma": 32, "exp_gap": 1, "pipe": 0},
+                                 # round 3's fixed-cost paths (Q by per-lane global loads, O by 8-byte stores, final wait)
+                                 {"q_dma": 0, "epi_lds": 0, "final_wait": 1}, {"early_dma": 1}, {"mfma": 16, "q_dma": 1, "epi_lds": 1}])
 def test_v5_generator_option_matrix(cfg):
     # every option the notes quote a measurement for still generates a stream that passes the hazard checker and is right
     rel, got, want, _ = run_block(130, dma_late=True, load_late=True, seed=13, cfg=cfg)
@@ -278,3 +280,13 @@ def test_v5_lazy_reference_spike_between_2p120_and_2p128_with_large_values(spike
     assert np.isfinite(got).all()
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 8e-3
     assert np.abs(got[5] - want[5]).max() <= 2e-2 * np.abs(want[5]).max()                       # the row with the spike
+
+
+def test_v5_row_major_epilogue_and_q_images_keep_the_bits():
+    # the LDS-transposed epilogue and the LDS-DMA'd Q images change how bytes travel, not one bit of the result
+    pb = Problem(200, 1, 2, 1, 1.0, 21, False)
+    new, _, _ = launch(pb, dma_late=True, load_late=True)
+    old, _, _ = launch(pb, dma_late=True, load_late=True, cfg={"q_dma": 0, "epi_lds": 0, "final_wait": 1})
+    assert np.array_equal(new, old)
+    # columns of the other head are untouched by the whole-row stores
+    assert not new[:, :128].any()

@@ -27,7 +27,7 @@ for spec in sys.argv[1:]:
     except AssertionError as e:
         print(f"variant {name}: schedule infeasible ({e})")
         continue
-    for fn, content in (("attention_v5_body.inc", gen.to_inc(text)), ("attention_v5_clobbers.inc", gen.clobbers()),
+    for fn, content in (("attention_v5_body.inc", gen.to_inc(text)), ("attention_v5_clobbers.inc", gen.clobbers(text)),
                         ("attention_v5_config.h", gen.config_h(cfg))):
         open(os.path.join(out, fn), "w").write(content)
     obj = os.path.join(out, "attention_v5.hip.o")

@@ -670,6 +670,27 @@ class Machine:
             put()
             w.lgkm_q.append(None)
 
+    def i_ds_write_b64(self, w, ins, o):
+        """ds_write_b64 vaddr, vdata[2] [offset]: same completion model as ds_write_b32"""
+        self._haz_read(w, ins, o[0], "mem")
+        self._haz_read(w, ins, o[1], "mem")
+        addr = self.rd(w, o[0]).astype(np.int64) + ins.mods.get("offset", 0)
+        if (addr % 8).any():
+            raise RuntimeError(f"line {ins.line}: misaligned ds_write_b64")
+        data = np.stack([self.rd(w, o[1], 0), self.rd(w, o[1], 1)], axis=1).copy().view(np.uint8).reshape(64, 8)
+
+        def put():
+            for l in range(64):
+                a = int(addr[l])
+                if a + 8 > self.lds.size:
+                    raise RuntimeError(f"LDS write out of range {a}")
+                self.lds[a:a + 8] = data[l]
+        if self.load_late:
+            w.lgkm_q.append(put)
+        else:
+            put()
+            w.lgkm_q.append(None)
+
     def i_ds_read_b64_tr_b16(self, w, ins, o):
         self._haz_read(w, ins, o[1], "mem")
         addr = self.rd(w, o[1]).astype(np.int64) + ins.mods.get("offset", 0)
@@ -835,6 +856,14 @@ class Machine:
         self._haz_read(w, ins, o[1], "mem")
         addr = self._gaddr(w, o[0], o[2], ins)
         self.gstore(addr, self.rd(w, o[1], 0).copy().view(np.uint8).reshape(64, 4))
+        w.vm_q.append(None)
+
+    def i_global_store_dwordx4(self, w, ins, o):
+        self._haz_read(w, ins, o[0], "mem")
+        self._haz_read(w, ins, o[1], "mem")
+        addr = self._gaddr(w, o[0], o[2], ins)
+        data = np.stack([self.rd(w, o[1], i) for i in range(4)], axis=1).copy().view(np.uint8).reshape(64, 16)
+        self.gstore(addr, data)
         w.vm_q.append(None)
 
     def i_global_store_dwordx2(self, w, ins, o):

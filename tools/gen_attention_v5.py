@@ -88,6 +88,22 @@ DEFAULT_CFG = {
     "exp_lat": 3,            # ... between an exponential and the first instruction that reads it
     "skew": 2,               # pairs between an exponential and the instructions that consume it
     "abl": "",               # TIMING ABLATIONS (wrong results): comma list of exp add cvt max lds dma bar -- drops those
+    # ---- the per-workgroup fixed cost (round 4: 12.4 us of the 20.7 us a 512-key cross-attention workgroup lives,
+    #      profiles/r04/kbench_attn_keys_sweep.log)
+    "early_dma": 0,          # (measured: +1 % on 512 keys, nothing on 32 760 -- off) the tiles the loop expects in flight (K(2), V(0), ...) are issued WITH K(0), K(1), in front of the
+                             # Q loads, instead of behind the prologue's second barrier (V(0) was still on its way when the
+                             # first PV product needed it)
+    "epi_lds": 1,            # O^T leaves through LDS: each wave transposes its 64 x 128 result in a 64 x 272-byte strip of the
+                             # (dead) rings and writes whole 256-byte rows with 16-byte stores, 16 stores instead of 32 8-byte
+                             # stores that each touch 32 rows (~60 cycles of the CU's address path each, the same wall the GEMM
+                             # epilogue hit: profiles/r04/NOTES.md)
+    "q_dma": 1,              # the 256 query rows reach LDS as four 64-row tile images by LDS-DMA (the K machinery: 1 KiB pieces
+                             # of whole rows, K's swizzle) in the V ring, which is idle until the prologue's second barrier,
+                             # and each wave reads the fragments of ITS 64 rows with 16 ds_read_b128; before, 16
+                             # global_load_dwordx4 per wave each touched 32 rows (32 bytes of every 256-byte row per
+                             # instruction): 14.5 us of a 512-key launch (kbench_attn_fixed_cost_abl.log).  Needs nst >= 4.
+    "final_wait": 0,         # s_waitcnt vmcnt(0) behind the last store (the wave ends right after the asm statement; stores
+                             # in flight at s_endpgm complete on their own)
 }
 
 A_O, A_Q, A_K = 0, 128, 192
@@ -107,6 +123,7 @@ S_LSEO, S_LSEI = 84, 86                              # log-sum-exp out / in row 
 S_ONES = 57                  # bf16 1.0 | 1.0
 S_SAFE, S_LTHR, S_BIG = 58, 59, 60   # lazy reference: 1 = second pass in the exact loop; 2^lthr; 2^120
 VOTE_OFF_BYTES = 256         # LDS behind the rings: one flag word per wave
+S_QSRD = 48                  # (prologue only, over the temporaries S_T+1..S_T+4) buffer descriptor of the workgroup's 256 query rows
 S_LAST = 91
 N_INPUTS = 22
 
@@ -1156,19 +1173,57 @@ def emit_prologue(E):
     E.comment("---- K(0), K(1) on their way; Q rows -> registers")
     dma_tile_now(E, "K", 0)
     dma_tile_now(E, "K", 1)
-    # query row of the lane: wv * 64 + QROWS * qb + ql;  bytes inside the row: 16 * group (the lane's 8 d of a d-step)
+    early = bool(cfg["early_dma"]) and nst >= 2 + ah     # their slots must not be the ones K(0), K(1) are read from
+    if early:
+        for i in range(ah):                # the tiles "iterations -ahead .. -1" would have issued, in their order
+            dma_tile_now(E, "K", (2 + i) % nst)
+            dma_tile_now(E, "V", i % nst)
     qrows = 64 // M.NQB
-    E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 6")
-    for qb in range(M.NQB):
-        E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(M.V_QL)}")
-        if qb:
-            E.i(f"v_add_u32 {v(t0)}, {qrows * qb}, {v(t0)}")
-        E.i(f"v_mul_lo_u32 {v(M.V_QOFF + qb)}, {v(t0)}, {s(S_LDQ)}")
-        E.i(f"v_lshl_add_u32 {v(M.V_QOFF + qb)}, {v(M.V_G)}, 4, {v(M.V_QOFF + qb)}")
     dstep = 32 if big else 64               # bytes of one d-step in a row
-    for qb in range(M.NQB):
-        for ds in range(M.NDS):
-            E.i(f"global_load_dwordx4 {v((qb * M.NDS + ds) * 4, 4)}, {v(M.V_QOFF + qb)}, {s(S_Q, 2)} offset:{ds * dstep}")
+    fixed_abl = str(cfg["abl"]).split("+")     # timing ablations of the per-workgroup fixed cost: qload, qscale, ostore
+    q_dma = bool(cfg["q_dma"]) and nst >= 4 and "qload" not in fixed_abl and not early     # (early_dma fills V slots 0, 1)
+    v_srcq, v_qa = 64, 68                   # temporaries in S buffer 1 (first written by the loop)
+    if q_dma:
+        E.comment("---- Q block -> four tile images in the V ring (LDS-DMA, K's swizzle)")
+        E.i(f"s_mov_b32 {s(S_QSRD)}, {s(S_Q)}")
+        E.i(f"s_and_b32 {s(S_QSRD + 1)}, {s(S_Q + 1)}, 0xffff")
+        E.i(f"s_mul_i32 {s(S_T)}, {s(S_LDQ)}, 255")
+        E.i(f"s_add_u32 {s(S_QSRD + 2)}, {s(S_T)}, 256")                  # bytes reachable: 255 rows + 128 d
+        E.i(f"s_mov_b32 {s(S_QSRD + 3)}, 0x00020000")
+        E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 4")
+        for j in range(4):                  # piece j of this wave: rows 16 wv + 4 j + (lane >> 4) of a tile, as for K
+            E.i(f"v_add_u32 {v(t0)}, {4 * j}, {v(g4)}")                   # row & 15
+            E.i(f"v_add_u32 {v(t1)}, {s(S_T)}, {v(t0)}")                  # row
+            E.i(f"v_mul_lo_u32 {v(t2)}, {v(t1)}, {s(S_LDQ)}")
+            E.i(f"v_xor_b32 {v(t0)}, {v(t0)}, {v(M.V_L15)}")              # chunk
+            E.i(f"v_lshl_add_u32 {v(v_srcq + j)}, {v(t0)}, 4, {v(t2)}")
+            if j:
+                E.i(f"v_subrev_u32 {v(v_srcq + j)}, {1024 * j}, {v(v_srcq + j)}")
+        E.i(f"s_lshl_b32 {s(S_RET)}, {s(S_LDQ)}, 6")                      # 64 rows (S_RET, S_VSLOT: set by the loop later)
+        E.i(f"s_mov_b32 {s(S_VSLOT)}, 0")
+        for w in range(4):
+            E.i(f"s_add_u32 m0, {s(S_LDSW)}, {(nst + w) * TILE}")
+            E.i("s_nop 0")
+            for j in range(4):
+                E.i(f"buffer_load_dwordx4 {v(v_srcq + j)}, {s(S_QSRD, 4)}, {s(S_VSLOT)} offen offset:{1024 * j} lds")
+            if w < 3:
+                E.i(f"s_add_u32 {s(S_VSLOT)}, {s(S_VSLOT)}, {s(S_RET)}")
+    else:
+        # query row of the lane: wv * 64 + QROWS * qb + ql;  bytes inside the row: 16 * group (the lane's 8 d of a d-step)
+        E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 6")
+        for qb in range(M.NQB):
+            E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(M.V_QL)}")
+            if qb:
+                E.i(f"v_add_u32 {v(t0)}, {qrows * qb}, {v(t0)}")
+            E.i(f"v_mul_lo_u32 {v(M.V_QOFF + qb)}, {v(t0)}, {s(S_LDQ)}")
+            E.i(f"v_lshl_add_u32 {v(M.V_QOFF + qb)}, {v(M.V_G)}, 4, {v(M.V_QOFF + qb)}")
+        for qb in range(M.NQB):
+            for ds in range(M.NDS):
+                if "qload" in fixed_abl:
+                    for k in range(4):
+                        E.i(f"v_mov_b32 {v((qb * M.NDS + ds) * 4 + k)}, 0")
+                    continue
+                E.i(f"global_load_dwordx4 {v((qb * M.NDS + ds) * 4, 4)}, {v(M.V_QOFF + qb)}, {s(S_Q, 2)} offset:{ds * dstep}")
     E.comment("---- O = 0, l = 0, m = 0, c_init = 0")
     for r in range(128):
         E.i(f"v_accvgpr_write_b32 {a(A_O + r)}, 0")
@@ -1179,8 +1234,23 @@ def emit_prologue(E):
     for qb in range(M.NQB):
         E.i(f"v_mov_b32 {v(M.V_M + qb)}, 0")
     E.i("s_waitcnt vmcnt(0)")
+    if q_dma:
+        E.i("s_barrier")                   # every wave's pieces of the four Q images (and of K(0), K(1)) have landed
+        E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 14")                        # this wave's image: slot wv of the V ring
+        E.i(f"s_add_u32 {s(S_T)}, {s(S_T)}, {nst * TILE}")
+        for ds in range(M.NDS):
+            E.i(f"v_add_u32 {v(v_qa + ds)}, {s(S_T)}, {v(M.V_KOFF + ds)}")
+        kbs = 8192 if big else 4096
+        tq = None
+        for qb in range(M.NQB):
+            for ds in range(M.NDS):
+                tq = E.ds(f"ds_read_b128 {v((qb * M.NDS + ds) * 4, 4)}, {v(v_qa + ds)} offset:{qb * kbs}")
+                if (qb * M.NDS + ds) % 8 == 7:
+                    E.wait_lds(tq)         # (lgkmcnt holds 15)
     E.comment("---- Q * scale*log2(e), rounded to bf16 again, into AGPRs")
     for r in range(64):
+        if "qscale" in fixed_abl:
+            continue
         lo, hi = M.V_T + 4, M.V_T + 5
         E.i(f"v_lshlrev_b32 {v(lo)}, 16, {v(r)}")
         E.i(f"v_and_b32 {v(hi)}, 0xffff0000, {v(r)}")
@@ -1188,7 +1258,8 @@ def emit_prologue(E):
         E.i(f"v_mul_f32 {v(hi)}, {s(S_C)}, {v(hi)}")
         E.i(f"v_cvt_pk_bf16_f32 {v(lo)}, {v(lo)}, {v(hi)}")
         E.i(f"v_accvgpr_write_b32 {a(A_Q + r)}, {v(lo)}")
-    E.i("s_barrier")
+    if not q_dma:
+        E.i("s_barrier")
     E.comment("---- S(0) = K(0) Q^T into buffer 0, then the fragments of K(1)")
     tk = None
     for ds in range(M.NDS):
@@ -1206,9 +1277,10 @@ def emit_prologue(E):
             tk = kfrag_read(E, kb, ds, 1)
     E.wait_lds(tk)
     E.i("s_barrier")                       # every wave has read K(0) and K(1): their slots may be refilled
-    for i in range(ah):                    # the tiles "iterations -ahead .. -1" would have issued, in their order
-        dma_tile_now(E, "K", (2 + i) % nst)
-        dma_tile_now(E, "V", i % nst)
+    if not early:
+        for i in range(ah):                # the tiles "iterations -ahead .. -1" would have issued, in their order
+            dma_tile_now(E, "K", (2 + i) % nst)
+            dma_tile_now(E, "V", i % nst)
     E.i("s_nop 7")
     # one-tile shards with padding keys: mask tile 0 before the first reference is taken
     E.i(f"s_cmp_gt_u32 {s(S_TPS)}, 1")
@@ -1223,11 +1295,17 @@ def emit_prologue(E):
     E.label("L_pro_done")
 
 
+STRIP_ROW = 272              # bytes of one row of a wave's O strip in LDS: 256 + 16 (bank spread of the 8-byte writes)
+STRIP = 64 * STRIP_ROW       # one wave's strip
+
+
 def emit_epilogue(E):
     """O / l -> bf16 -> global; optional log-sum-exp out (two-phase attention, first launch) and merge with the result of
-    an earlier launch over other keys (lse_in: O holds that launch's normalised result) -- the epilogue of attention_v3.hip"""
-    M = E.M
+    an earlier launch over other keys (lse_in: O holds that launch's normalised result) -- the epilogue of attention_v3.hip.
+    cfg epi_lds: the bf16 result goes through a per-wave LDS strip and leaves as whole rows (see DEFAULT_CFG)."""
+    M, cfg = E.M, E.cfg
     big = M.mfma == 32
+    via_lds = bool(cfg["epi_lds"]) and 4 * STRIP <= 2 * cfg["nst"] * TILE    # the four strips live in the rings
     E.comment("---- O / l -> bf16 -> global")
     E.i("s_nop 15")
     t0 = M.V_T
@@ -1235,6 +1313,16 @@ def emit_epilogue(E):
     lrow = [M.V_D + qb for qb in range(M.NQB)]           # byte offset of the lane's row in the lse arrays
     lse = [M.V_MX + qb for qb in range(M.NQB)]
     ca = [M.V_M + qb for qb in range(M.NQB)]             # weight of the earlier launch's result (merge)
+    soff = [M.V_RM + qb for qb in range(M.NQB)]          # LDS address of the lane's row in the strip (+ 8 * group)
+    v_rb, v_go = M.V_RM + 4, M.V_RM + 5                  # read-back: LDS address / global byte offset of the lane's 16 bytes
+    if via_lds:
+        # no LDS-DMA may land in a ring slot (tiles past the end of the key sequence are issued, and read zeros) and no
+        # wave may still be reading V fragments when the strips are written
+        E.i("s_waitcnt vmcnt(0)")
+        E.i("s_barrier")
+        E.i(f"s_mov_b32 {s(S_T + 1)}, {STRIP}")
+        E.i(f"s_mul_i32 {s(S_T + 1)}, {s(S_T + 1)}, {s(S_WV)}")
+        E.i(f"s_add_u32 {s(S_T + 1)}, {s(S_T + 1)}, {s(S_LDS)}")          # this wave's strip
     E.i(f"s_lshl_b32 {s(S_T)}, {s(S_WV)}, 6")
     for qb in range(M.NQB):
         E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(M.V_QL)}")
@@ -1243,6 +1331,23 @@ def emit_epilogue(E):
         E.i(f"v_lshlrev_b32 {v(lrow[qb])}, 2, {v(t0)}")
         E.i(f"v_mul_lo_u32 {v(M.V_QOFF + qb)}, {v(t0)}, {s(S_LDO)}")
         E.i(f"v_lshl_add_u32 {v(M.V_QOFF + qb)}, {v(M.V_G)}, 3, {v(M.V_QOFF + qb)}")   # 4 d = 8 bytes per lane group
+        if via_lds:
+            # row in the wave's strip = ql + qrows * qb;  address = strip + row * 272 + 8 * group
+            E.i(f"v_add_u32 {v(t0)}, {qrows * qb}, {v(M.V_QL)}")
+            E.i(f"v_lshlrev_b32 {v(t0 + 1)}, 8, {v(t0)}")
+            E.i(f"v_lshl_add_u32 {v(t0 + 1)}, {v(t0)}, 4, {v(t0 + 1)}")
+            E.i(f"v_lshl_add_u32 {v(t0 + 1)}, {v(M.V_G)}, 3, {v(t0 + 1)}")
+            E.i(f"v_add_u32 {v(soff[qb])}, {s(S_T + 1)}, {v(t0 + 1)}")
+    if via_lds:
+        # read-back: lane -> row 4 it + (lane >> 4), 16-byte chunk lane & 15
+        E.i(f"v_lshrrev_b32 {v(t0)}, 4, {v(M.V_LANE)}")
+        E.i(f"v_lshlrev_b32 {v(t0 + 1)}, 8, {v(t0)}")
+        E.i(f"v_lshl_add_u32 {v(t0 + 1)}, {v(t0)}, 4, {v(t0 + 1)}")
+        E.i(f"v_lshl_add_u32 {v(t0 + 1)}, {v(M.V_L15)}, 4, {v(t0 + 1)}")
+        E.i(f"v_add_u32 {v(v_rb)}, {s(S_T + 1)}, {v(t0 + 1)}")
+        E.i(f"v_add_u32 {v(t0)}, {s(S_T)}, {v(t0)}")                      # 64 wv + (lane >> 4)
+        E.i(f"v_mul_lo_u32 {v(v_go)}, {v(t0)}, {s(S_LDO)}")
+        E.i(f"v_lshl_add_u32 {v(v_go)}, {v(M.V_L15)}, 4, {v(v_go)}")
     for qb in range(M.NQB):
         l = M.V_L + 2 * qb
         E.i(f"v_add_f32 {v(l)}, {v(l)}, {v(l + 1)}")
@@ -1307,18 +1412,38 @@ def emit_epilogue(E):
                     E.i(f"v_cvt_pk_bf16_f32 {v(x)}, {v(x)}, {v(x + 1)}")
                     E.i(f"v_cvt_pk_bf16_f32 {v(x + 1)}, {v(x + 2)}, {v(x + 3)}")
                     off = db * 64 + g * 16 if big else db * 32
-                    E.i(f"global_store_dwordx2 {v(M.V_QOFF + qb)}, {v(x, 2)}, {s(S_O, 2)} offset:{off}")
-                    E.i("s_nop 1")
+                    if via_lds:
+                        E.i(f"ds_write_b64 {v(soff[qb])}, {v(x, 2)} offset:{off}")
+                    else:
+                        E.i(f"global_store_dwordx2 {v(M.V_QOFF + qb)}, {v(x, 2)}, {s(S_O, 2)} offset:{off}")
+                        E.i("s_nop 1")
         if merge:
-            E.i("s_branch L_epi_lse")
-    E.label("L_epi_lse")
+            E.i("s_branch L_epi_rows")
+    E.label("L_epi_rows")
+    if via_lds:
+        # the strip belongs to this wave alone: its own writes complete, then 16 x (4 whole rows -> global)
+        E.i("s_waitcnt lgkmcnt(0)")
+        E.lds_done = E.lds_issued
+        E.i(f"s_lshl_b32 {s(S_T + 2)}, {s(S_LDO)}, 2")                     # 4 rows
+        tk = {}
+        for it in range(8):
+            tk[it] = E.ds(f"ds_read_b128 {v(4 * it, 4)}, {v(v_rb)} offset:{it * 4 * STRIP_ROW}")
+        for it in range(16):
+            if it + 8 < 16:
+                tk[it + 8] = E.ds(f"ds_read_b128 {v(4 * (it + 8), 4)}, {v(v_rb)} offset:{(it + 8) * 4 * STRIP_ROW}")
+            E.wait_lds(tk[it])
+            if "ostore" not in str(cfg["abl"]).split("+"):
+                E.i(f"global_store_dwordx4 {v(v_go)}, {v(4 * it, 4)}, {s(S_O, 2)}")
+            if it < 15:
+                E.i(f"v_add_u32 {v(v_go)}, {s(S_T + 2)}, {v(v_go)}")
     E.i(f"s_or_b32 {s(S_T)}, {s(S_LSEO)}, {s(S_LSEO + 1)}")
     E.i(f"s_cmp_eq_u32 {s(S_T)}, 0")
     E.i("s_cbranch_scc1 L_epi_done")
     for qb in range(M.NQB):                              # every lane that holds a part of the row writes the same value
         E.i(f"global_store_dword {v(lrow[qb])}, {v(lse[qb])}, {s(S_LSEO, 2)}")
     E.label("L_epi_done")
-    E.i("s_waitcnt vmcnt(0)")
+    if cfg["final_wait"]:
+        E.i("s_waitcnt vmcnt(0)")
 
 
 def emit_masktops(E):
@@ -1512,8 +1637,20 @@ def to_inc(text):
     return "\n".join(out) + "\n"
 
 
-def clobbers():
-    regs = [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(20, S_LAST + 1)]
+def sgprs_used(text):
+    """SGPRs the stream names (singly or inside a range)"""
+    used = {int(m.group(1)) for m in re.finditer(r"\bs(\d+)\b", text)}
+    for m in re.finditer(r"\bs\[(\d+):(\d+)\]", text):
+        used.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return used
+
+
+def clobbers(text=None):
+    """registers owned by the asm block: every VGPR / AGPR, and the SGPRs of s20..S_LAST the stream actually names (the
+    persistent wrapper keeps its loop state in the ones that are left)"""
+    used = sgprs_used(text if text is not None else generate())
+    assert all(20 <= r <= S_LAST for r in used), sorted(r for r in used if not 20 <= r <= S_LAST)
+    regs = [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in sorted(used)]
     regs += ["vcc", "scc", "m0", "memory"]
     out, line = ["// GENERATED by tools/gen_attention_v5.py: registers owned by the asm block"], ""
     for r in regs:
@@ -1557,7 +1694,7 @@ def main():
     if outdir:
         os.makedirs(outdir, exist_ok=True)
         open(os.path.join(outdir, "attention_v5_body.inc"), "w").write(to_inc(text))
-        open(os.path.join(outdir, "attention_v5_clobbers.inc"), "w").write(clobbers())
+        open(os.path.join(outdir, "attention_v5_clobbers.inc"), "w").write(clobbers(text))
         open(os.path.join(outdir, "attention_v5_config.h"), "w").write(config_h(cfg))
     n = sum(1 for l in text.splitlines() if l.startswith("  ") and not l.strip().startswith(";"))
     print(f"{n} instructions", file=sys.stderr)

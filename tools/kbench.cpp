@@ -301,6 +301,31 @@ static void bench_attn(const char* name, int Lq_pad, int H, int valid, float q_a
   CK(hipFree(O)); CK(hipFree(Oref)); CK(hipFree(dcount));
 }
 
+// Short-key sweep (cross-attention shapes): 32768 query rows against `keys` keys -- time per launch as a function of the
+// key count separates the per-workgroup fixed cost (prologue, Q load, epilogue) from the per-tile cost.
+static void bench_attn_keys(int Lq_pad, int H, int rounds, int launches) {
+  const int D = H * 128;
+  uint16_t *Q, *K, *V, *O;
+  CK(hipMalloc(&Q, (size_t)Lq_pad * D * 2));
+  CK(hipMalloc(&K, (size_t)4096 * D * 2));
+  CK(hipMalloc(&V, (size_t)4096 * D * 2));
+  CK(hipMalloc(&O, (size_t)Lq_pad * D * 2));
+  fill_bf16<<<2048, 256>>>(Q, (size_t)Lq_pad * D, 11, 1.0f * g_amp);
+  fill_bf16<<<2048, 256>>>(K, (size_t)4096 * D, 12, 1.0f * g_amp);
+  fill_bf16<<<2048, 256>>>(V, (size_t)4096 * D, 13, 1.0f * g_amp);
+  CK(hipDeviceSynchronize());
+  const float scale = 1.0f / std::sqrt(128.0f);
+  for (int keys : {64, 128, 256, 512, 1024, 2048, 4096}) {
+    auto launch = [&](int l) {
+      MCL(g_libs[l], g_libs[l].attn(Q, D, K, D, 0, V, D, 0, O, D, Lq_pad, H, keys, keys, 1, scale, nullptr));
+    };
+    char what[64];
+    snprintf(what, sizeof(what), "attn_k%d", keys);
+    measure(what, 4.0 * (double)Lq_pad * keys * D, "TF", 1e-12, rounds, launches, launch);
+  }
+  CK(hipFree(Q)); CK(hipFree(K)); CK(hipFree(V)); CK(hipFree(O));
+}
+
 // ------------------------------------------------------------------------------------- calibration statistics
 static void bench_calib(int M, int D, int rounds, int launches) {
   float *r, *rp, *stats;
@@ -328,7 +353,7 @@ static void bench_calib(int M, int D, int rounds, int launches) {
 
 int main(int argc, char** argv) {
   if (argc < 5) {
-    fprintf(stderr, "usage: kbench.bin <gemm|attn|calib|all> <rounds> <launches> libA.so [libB.so ...]\n");
+    fprintf(stderr, "usage: kbench.bin <gemm|attn|attn_keys|calib|all> <rounds> <launches> libA.so [libB.so ...]\n");
     return 2;
   }
   if (getenv("KBENCH_AMP")) g_amp = (float)atof(getenv("KBENCH_AMP"));
@@ -375,6 +400,7 @@ int main(int argc, char** argv) {
     bench_attn("self480p_q6", 32768, 12, 32760, 6.0f, rounds, std::max(1, launches / 4));
   }
   if (what == "attn_strided" || what == "all") bench_attn("self480p_qkv", 32768, 12, 32760, 1.0f, rounds, std::max(1, launches / 4), true);
+  if (what == "attn_keys") bench_attn_keys(32768, 12, rounds, launches);
   if (what == "attn1") bench_attn("self480p", 32768, 12, 32760, 1.0f, rounds, launches);          // one shape (PMC passes)
   if (what == "gemm1") bench_gemm("qkv", M, 4608, 1536, 0, rounds, launches);
   if (what == "calib" || what == "all") bench_calib(32760, 1536, rounds, launches * 2);
