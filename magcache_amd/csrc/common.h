@@ -29,7 +29,10 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // 48..63 carried a wrong low result of the rotation's v_pk_fma_f32 -- only while the other stream's 128x128 GEMM was
 // resident; the one-stream result matched an fp64 restatement, the two-stream one did not; the same kernel compiled
 // with -packed-fp32-ops: 0 differences in 360 replays.  The scalar forms cost nothing here (latency-bound kernels).
-#if defined(__HIP_DEVICE_COMPILE__)
+// (MC_PK_EXPERIMENT, tools/build_pk_experiment.py: 1 = packed instructions back in, to reproduce the fault; 2 = the same
+// plus agent-scope acquire / release and cache-bypassing loads in the head-norm kernel -- the round-4 experiment that
+// rules memory visibility in or out)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MC_PK_EXPERIMENT)
 #define MC_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
 #else
 #define MC_NO_PK_F32

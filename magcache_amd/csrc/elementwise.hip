@@ -145,6 +145,9 @@ MC_NO_PK_F32 __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t*
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   float cc = 1.f, sn = 0.f;
+#if defined(MC_PK_EXPERIMENT) && MC_PK_EXPERIMENT == 2
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   if (cs) {
     const f32x2 t = *(const f32x2*)(cs + (size_t)(cs_row0 + row) * 128 + 2 * lane);
     cc = t[0];
@@ -157,7 +160,11 @@ MC_NO_PK_F32 __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t*
     f32x2 wv = {1.f, 1.f};
     if (w) wv = *(const f32x2*)(w + 2 * lane);
     for (int h = 0; h < n_heads; ++h) {
+#if defined(MC_PK_EXPERIMENT) && MC_PK_EXPERIMENT == 2
+      const uint32_t b = __hip_atomic_load(xr + h * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
       const uint32_t b = xr[h * 64];
+#endif
       float re = __uint_as_float(b << 16), im = __uint_as_float(b & 0xffff0000u);
       if (w) {
         // upstream RMSNorm (diffusers / hyvideo): norm in fp32, cast to the activation dtype, then * weight
@@ -173,6 +180,9 @@ MC_NO_PK_F32 __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t*
       xr[h * 64] = pack_bf16x2(r2, i2);
     }
   }
+#if defined(MC_PK_EXPERIMENT) && MC_PK_EXPERIMENT == 2
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
 }
 
 __global__ __launch_bounds__(256) void gemv_bf16w_kernel(const bf16_t* __restrict__ Wt, const float* __restrict__ x,
