@@ -285,7 +285,7 @@ def bench_main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernels", action="store_true")
     ap.add_argument("--no_nocache", action="store_true", help="skip the second (cache off) timed region")
-    ap.add_argument("--fp8_linear", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2),
+    ap.add_argument("--fp8_linear", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2, 3),
                     help="OPTIONAL precision mode, never the headline: QKV / FFN Linears on an fp8 e4m3 MFMA path "
                          "(1: per-row / per-channel scales, 2: MX block scales)")
     ap.add_argument("--layout", choices=("auto", "sp", "cfg2sp"), default="auto",
@@ -479,7 +479,7 @@ def bench_main():
             "value": args.steps / t_mc, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": t_mc / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": (f"bf16 + {'MX block-scaled ' if args.fp8_linear == 2 else ''}fp8(e4m3) QKV/FFN Linears (reduced precision: NOT the headline)"
+            "dtype": (f"bf16 + {'MX block-scaled ' if args.fp8_linear >= 2 else ''}fp8(e4m3) {'all six' if args.fp8_linear == 3 else 'QKV/FFN'} Linears (reduced precision: NOT the headline)"
                       if args.fp8_linear else "bf16"),
             "data": "synthetic",
             "config": {"workload": "Wan2.1-T2V-1.3B 832x480 81 frames: latent 16x21x60x104, 32760 tokens, "

@@ -68,7 +68,11 @@ typedef struct {
                            path: weights quantised per output channel at mc_set_weight, activations per token on the
                            fly; a speed / quality option (~3 % relative error per GEMM), never the default.
                            2: the same Linears on MX block-scaled fp8 (one E8M0 scale per 32 input features of every
-                           token and of every output channel, v_mfma_scale_f32_16x16x128_f8f6f4; mc_op_gemm_mxfp8) */
+                           token and of every output channel, v_mfma_scale_f32_16x16x128_f8f6f4; mc_op_gemm_mxfp8).
+                           3: as 2, and the three dim x dim Linears of every block as well (self-attention O,
+                           cross-attention Q and O).  With 1..3 the LayerNorm + modulate kernel writes the e4m3 operand
+                           of the GEMM it feeds directly, and with 2 / 3 the GELU epilogue of FFN-1 writes FFN-2's
+                           (mc_set_option("fp8_fused_quant", 0) restores the separate quantise passes: same bits) */
   int no_context_cache; /* 1: do not reserve the text-context cache (the per-block cross-attention K|V of two prompts:
                            2 x layers x text_len x 2 dim bf16 = 0.19 GB at 1.3B, 0.84 GB at 14B); mc_set_context /
                            mc_use_context then fail with MC_ESTATE and every forward takes its context argument */

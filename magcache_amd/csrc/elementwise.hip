@@ -16,7 +16,19 @@ namespace {
 
 // ------------------------------------------------------------------ LayerNorm (+ modulate / affine)
 // one wave per row; lane holds NV float4 (row element e = i*256 + lane*4 + j)
-template <int NV>
+// QM (fp8 Linear modes of the engine): 0 = bf16 / fp32 rows out; 1 = the row leaves as OCP e4m3 with one scale per row;
+// 2 = as e4m3 with one E8M0 scale per 32 elements (MX).  Both quantise the bf16-ROUNDED row exactly as
+// quantize_rows_fp8_kernel / quantize_rows_mx_kernel would from the bf16 row this kernel otherwise writes: the same bits
+// without the 2-byte row ever reaching memory (round 4: drops one pass over the activations per fp8 GEMM).
+struct LnQuantOut {
+  uint8_t* q;       // [M, ldq] e4m3
+  long ldq;
+  float* scale;     // QM 1: [M]
+  uint8_t* mx;      // QM 2: block-major E8M0, mx[kb * mx_rows + perm(row)] (gemm_mxfp8.hip)
+  long mx_rows;
+};
+
+template <int NV, int QM>
 MC_NO_PK_F32 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, long ldx,
                                                           const bf16_t* __restrict__ x0, long ldx0,
                                                           const float* __restrict__ sc,
@@ -25,7 +37,7 @@ MC_NO_PK_F32 __global__ __launch_bounds__(256) void ln_modulate_kernel(const flo
                                                           float* __restrict__ out_f32, long ldof, int M, int D,
                                                           const float* __restrict__ sc2,
                                                           const float* __restrict__ sh2,
-                                                          const uint8_t* __restrict__ sel) {
+                                                          const uint8_t* __restrict__ sel, LnQuantOut qo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -73,11 +85,54 @@ MC_NO_PK_F32 __global__ __launch_bounds__(256) void ln_modulate_kernel(const flo
       const float n = (v[i][j] - mean) * rstd;
       y[j] = (mode == 0) ? n * (1.0f + a[j]) + b[j] : n * a[j] + b[j];
     }
-    if (out_f32) {
+    if constexpr (QM != 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = bf16_round(y[j]);   // what the bf16 row would hold
+    } else if (out_f32) {
       *(f32x4*)(out_f32 + (size_t)row * ldof + e) = y;
     } else {
       u32x2 w = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
       *(u32x2*)(out + (size_t)row * ldo + e) = w;
+    }
+  }
+  if constexpr (QM == 1) {   // one scale per row: max|row| / 448
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float sc1 = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc1;
+    if (lane == 0) qo.scale[row] = sc1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, 0, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w, true);
+      *(int*)(qo.q + (size_t)row * qo.ldq + i * 256 + lane * 4) = w;
+    }
+  }
+  if constexpr (QM == 2) {   // MX: the 32-element block of (i, lane / 8) sits in 8 neighbouring lanes
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float amax = fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+      amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+      int ex = -127;
+      if (amax > 0.f) {   // e = ceil(log2(amax / 448)), as quantize_rows_mx_kernel
+        int fx;
+        const float f = frexpf(amax * (1.0f / 448.0f), &fx);
+        ex = (f == 0.5f) ? fx - 1 : fx;
+        ex = max(-127, min(127, ex));
+      }
+      const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
+      int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, 0, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w, true);
+      *(int*)(qo.q + (size_t)row * qo.ldq + i * 256 + lane * 4) = w;
+      if ((lane & 7) == 0)
+        qo.mx[(size_t)(i * 8 + (lane >> 3)) * qo.mx_rows + ((row & ~63) | ((row & 15) << 2) | ((row >> 4) & 3))] =
+            (uint8_t)(ex + 127);
     }
   }
 }
@@ -484,16 +539,16 @@ inline int grid_for(long total, int block, int cap = 2048) {
 
 }  // namespace
 
-hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long ldx0, const float* sc,
-                              const float* sh, int mode, float eps, bf16_t* out, long ldo, float* out_f32,
-                              long ldof, int M, int D, hipStream_t stream, const float* sc2, const float* sh2,
-                              const uint8_t* sel) {
+template <int QM>
+static hipError_t launch_ln_t(const float* x, long ldx, const bf16_t* x0, long ldx0, const float* sc, const float* sh,
+                              int mode, float eps, bf16_t* out, long ldo, float* out_f32, long ldof, int M, int D,
+                              hipStream_t stream, const float* sc2, const float* sh2, const uint8_t* sel, LnQuantOut qo) {
   if (M <= 0 || D <= 0 || (D % 256) != 0 || (sel && (!sc2 || !sh2))) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
 #define MC_LN_CASE(NV)                                                                                      \
   case NV:                                                                                                  \
-    hipLaunchKernelGGL((ln_modulate_kernel<NV>), grid, block, 0, stream, x, ldx, x0, ldx0, sc, sh, mode, eps, out, \
-                       ldo, out_f32, ldof, M, D, sc2, sh2, sel);                                                           \
+    hipLaunchKernelGGL((ln_modulate_kernel<NV, QM>), grid, block, 0, stream, x, ldx, x0, ldx0, sc, sh, mode, eps, out, \
+                       ldo, out_f32, ldof, M, D, sc2, sh2, sel, qo);                                                   \
     break;
   switch (D / 256) {
     MC_LN_CASE(1)
@@ -509,6 +564,26 @@ hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long l
   }
 #undef MC_LN_CASE
   return hipGetLastError();
+}
+
+hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long ldx0, const float* sc,
+                              const float* sh, int mode, float eps, bf16_t* out, long ldo, float* out_f32,
+                              long ldof, int M, int D, hipStream_t stream, const float* sc2, const float* sh2,
+                              const uint8_t* sel) {
+  return launch_ln_t<0>(x, ldx, x0, ldx0, sc, sh, mode, eps, out, ldo, out_f32, ldof, M, D, stream, sc2, sh2, sel,
+                        LnQuantOut{nullptr, 0, nullptr, nullptr, 0});
+}
+
+hipError_t launch_ln_modulate_fp8(const float* x, long ldx, const float* sc, const float* sh, int mode, float eps,
+                                  uint8_t* q, long ldq, float* row_scale, uint8_t* mx, long mx_rows, int M, int D,
+                                  hipStream_t stream, const float* sc2, const float* sh2, const uint8_t* sel) {
+  if (!q || (ldq % 4) != 0 || (!row_scale && !mx)) return hipErrorInvalidValue;
+  const LnQuantOut qo{q, ldq, row_scale, mx, mx_rows};
+  if (mx) {
+    if ((D % 32) != 0 || (ldq % 16) != 0 || (mx_rows % 64) != 0 || mx_rows < ((M + 63) / 64) * 64) return hipErrorInvalidValue;
+    return launch_ln_t<2>(x, ldx, nullptr, 0, sc, sh, mode, eps, nullptr, 0, nullptr, 0, M, D, stream, sc2, sh2, sel, qo);
+  }
+  return launch_ln_t<1>(x, ldx, nullptr, 0, sc, sh, mode, eps, nullptr, 0, nullptr, 0, M, D, stream, sc2, sh2, sel, qo);
 }
 
 hipError_t launch_rmsnorm_rope(bf16_t* x, long ldx, const float* w, float eps, const float* cs, int cs_row0,

@@ -64,7 +64,9 @@ struct Layer {
   // fp8_linear: e4m3 copies of the three large Linears + per-output-channel scales
   uint8_t *q_wqkv = nullptr, *q_w1 = nullptr, *q_w2 = nullptr;
   float *s_wqkv = nullptr, *s_w1 = nullptr, *s_w2 = nullptr;
-  uint8_t *m_wqkv = nullptr, *m_w1 = nullptr, *m_w2 = nullptr;   // fp8_linear == 2: MX block scales [K/32][N]
+  uint8_t *m_wqkv = nullptr, *m_w1 = nullptr, *m_w2 = nullptr;   // fp8_linear >= 2: MX block scales [K/32][N]
+  // fp8_linear == 3: the d x d Linears too (self-attention O, cross-attention Q and O), MX
+  uint8_t *q_wo = nullptr, *q_wcq = nullptr, *q_wco = nullptr, *m_wo = nullptr, *m_wcq = nullptr, *m_wco = nullptr;
 };
 
 struct Buf {
@@ -212,6 +214,9 @@ mc_status set_error_v(mc_status s, const char* fmt, va_list ap) {
 }
 }  // namespace mc
 
+// mc_set_option("fp8_fused_quant", 0|1): 1 (default) = with fp8_linear the LayerNorm + modulate kernel (and, MX, the GELU
+// epilogue of FFN-1) write the e4m3 operand of the next GEMM directly; 0 = round 3's separate quantise passes (same bits).
+static int g_fp8_fused_quant = 1;
 extern int g_mmdit_two_streams;   // mmdit_engine.cpp: mc_set_option("mmdit_two_streams", v)
 
 extern "C" {
@@ -236,7 +241,8 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
                                                    (c.vace_layers - 1) * c.vace_stride >= c.num_layers)))
     return fail(MC_EINVAL, "bad VACE geometry: %d blocks, stride %d, in_dim %d", c.vace_layers, c.vace_stride, c.vace_in_dim);
   if ((c.no_context_cache | c.no_token_timesteps) & ~1) return fail(MC_EINVAL, "no_context_cache / no_token_timesteps must be 0 or 1");
-  if (c.fp8_linear < 0 || c.fp8_linear > 2) return fail(MC_EINVAL, "fp8_linear must be 0, 1 (per-row scales) or 2 (MX block scales)");
+  if (c.fp8_linear < 0 || c.fp8_linear > 3)
+    return fail(MC_EINVAL, "fp8_linear must be 0, 1 (per-row scales), 2 (MX block scales: QKV, FFN-1, FFN-2) or 3 (MX, the d x d Linears too)");
   if (c.fp8_linear && ((c.dim % 256) || (c.ffn_dim % 256) || c.dim < 512 || c.ffn_dim < 512))
     return fail(MC_EINVAL, "fp8_linear needs dim and ffn_dim to be multiples of 256 and >= 512");
   if (c.vace_layers > 0 && c.sp_size > 1 && (c.vace_layers - 1) * c.vace_stride == c.num_layers - 1)
@@ -317,7 +323,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
       s1.q8 = l.q_w1; s1.q8_scale = l.s_w1; s1.q8_k = d;
       Slot& s2 = e->slots[p + "ffn.2.weight"];
       s2.q8 = l.q_w2; s2.q8_scale = l.s_w2; s2.q8_k = ffn;
-      if (c.fp8_linear == 2) {   // MX: one E8M0 byte per (output channel, 32 input features), block-major
+      if (c.fp8_linear >= 2) {   // MX: one E8M0 byte per (output channel, 32 input features), block-major
         ALLOC(l.m_wqkv, (d / 32) * 3 * d); ALLOC(l.m_w1, (d / 32) * ffn); ALLOC(l.m_w2, (ffn / 32) * d);
         for (int j = 0; j < 3; ++j) {
           Slot& sl = e->slots[p + qkv_names[j]];
@@ -325,6 +331,16 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
         }
         s1.mx = l.m_w1; s1.mx_rows = ffn;
         s2.mx = l.m_w2; s2.mx_rows = d;
+      }
+      if (c.fp8_linear == 3) {
+        const struct { const char* name; uint8_t** q; uint8_t** m; } dd[3] = {
+            {"self_attn.o.weight", &l.q_wo, &l.m_wo}, {"cross_attn.q.weight", &l.q_wcq, &l.m_wcq},
+            {"cross_attn.o.weight", &l.q_wco, &l.m_wco}};
+        for (const auto& w : dd) {
+          ALLOC(*w.q, d * d); ALLOC(*w.m, (d / 32) * d);
+          Slot& sl = e->slots[p + w.name];
+          sl.q8 = *w.q; sl.q8_scale = nullptr; sl.q8_k = d; sl.mx = *w.m; sl.mx_rows = d;
+        }
       }
     }
     if (c.clip_dim > 0) {
@@ -431,7 +447,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (c.fp8_linear) {
     add_buf(e, cur, "aq", Lp * std::max(d, ffn));            // e4m3 activations of the current fp8 GEMM
     add_buf(e, cur, "a_scale", Lp * 4);                      // their per-token scales
-    if (c.fp8_linear == 2) add_buf(e, cur, "a_mx", (std::max(d, ffn) / 32) * Lp);   // MX: per (token, 32 k) block scales
+    if (c.fp8_linear >= 2) add_buf(e, cur, "a_mx", (std::max(d, ffn) / 32) * Lp);   // MX: per (token, 32 k) block scales
   }
   if (e->NV > 0) {
     add_buf(e, cur, "xc", Lp * d * 4);                       // VACE control stream c (fp32 like x)
@@ -735,21 +751,41 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
 // computed here (one pass over the bf16 rows), the weights were quantised per output channel at load time.
 // fp8_linear == 2 (wm != null): MX block scales instead -- activations per (token, 32 k), weights per (channel, 32 k),
 // multiplied inside the matrix core (gemm_mxfp8.hip).
+// A == nullptr: the producer already left the quantised rows (and their scales) in "aq" / "a_mx" / "a_scale"
+// (ln_for_gemm below) or in aq_pre / amx_pre (the GELU epilogue of the MX FFN-1 GEMM, which writes into "h").
 static mc_status gemm_fp8_rows(mc_engine* e, const bf16_t* A, long lda, int M, int K, const uint8_t* Wq, const float* ws,
-                               const uint8_t* wm, mc::GemmParams p, int epi, hipStream_t s) {
-  uint8_t* aq = e->buf<uint8_t>("aq");
+                               const uint8_t* wm, mc::GemmParams p, int epi, hipStream_t s, uint8_t* aq_pre = nullptr,
+                               uint8_t* amx_pre = nullptr) {
+  uint8_t* aq = aq_pre ? aq_pre : e->buf<uint8_t>("aq");
   p.A = (const bf16_t*)aq; p.lda = K; p.W = (const bf16_t*)Wq; p.ldw = K; p.K = K;
   if (wm) {
-    uint8_t* am = e->buf<uint8_t>("a_mx");
-    HIP_TRY(mc::launch_quantize_rows_mx(A, nullptr, lda, M, K, aq, K, am, (long)e->Lp, s));
+    uint8_t* am = amx_pre ? amx_pre : e->buf<uint8_t>("a_mx");
+    if (A) HIP_TRY(mc::launch_quantize_rows_mx(A, nullptr, lda, M, K, aq, K, am, (long)e->Lp, s));
     p.a_mx = am; p.mx_rows_a = (long)e->Lp; p.w_mx = wm; p.mx_rows_w = p.N;
     HIP_TRY(mc::launch_gemm_mxfp8(p, epi, s));
     return MC_OK;
   }
   float* as = e->buf<float>("a_scale");
-  HIP_TRY(mc::launch_quantize_rows_fp8(A, nullptr, lda, M, K, aq, K, as, s));
+  if (A) HIP_TRY(mc::launch_quantize_rows_fp8(A, nullptr, lda, M, K, aq, K, as, s));
   p.a_scale = as; p.w_scale = ws;
   HIP_TRY(mc::launch_gemm_fp8(p, epi, s));
+  return MC_OK;
+}
+
+// LayerNorm + modulate whose consumer is an fp8 GEMM: with fp8_fused_quant the row goes straight to "aq" (+ scales) and
+// the function returns true; otherwise the bf16 row goes to "xn" as ever and the GEMM wrapper quantises it.
+static mc_status ln_for_gemm(mc_engine* e, bool fp8_consumer, bool mx, const float* x, const float* sc, const float* sh,
+                             int mode, const float* sc2, const float* sh2, const uint8_t* sel, hipStream_t s, bool* fused) {
+  const int d = e->d, Lp = e->Lp;
+  *fused = fp8_consumer && g_fp8_fused_quant;
+  if (*fused) {
+    HIP_TRY(mc::launch_ln_modulate_fp8(x, d, sc, sh, mode, e->cfg.eps, e->buf<uint8_t>("aq"), d,
+                                       mx ? nullptr : e->buf<float>("a_scale"), mx ? e->buf<uint8_t>("a_mx") : nullptr,
+                                       (long)Lp, Lp, d, s, sc2, sh2, sel));
+  } else {
+    HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, sc, sh, mode, e->cfg.eps, e->buf<bf16_t>("xn"), d, nullptr, 0, Lp, d,
+                                   s, sc2, sh2, sel));
+  }
   return MC_OK;
 }
 
@@ -767,13 +803,17 @@ static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float*
   bf16_t* qkv = e->buf<bf16_t>("qkv");
   const float* em2 = second_set(e, em);
   const uint8_t* sel = tok_sel(e);
-  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + d, em, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s,
-                                 em2 ? em2 + d : nullptr, em2, sel));
+  bool fused = false;
+  {
+    mc_status st = ln_for_gemm(e, e->P == 1 && l.q_wqkv, l.m_wqkv != nullptr, x, em + d, em, 0, em2 ? em2 + d : nullptr, em2,
+                               sel, s, &fused);
+    if (st != MC_OK) return st;
+  }
   if (e->P == 1) {
     mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
     if (l.q_wqkv) {
-      mc_status st = gemm_fp8_rows(e, xn, d, Lp, d, l.q_wqkv, l.s_wqkv, l.m_wqkv, p, mc::EPI_BF16, s);
+      mc_status st = gemm_fp8_rows(e, fused ? nullptr : xn, d, Lp, d, l.q_wqkv, l.s_wqkv, l.m_wqkv, p, mc::EPI_BF16, s);
       if (st != MC_OK) return st;
     } else {
       HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
@@ -876,16 +916,30 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     mc::GemmParams p = gp(ao, d, l.wo, d, l.bo, Lp, d, d);
     p.X = x; p.ldx = d; p.gate = em + 2 * d;
     if (em2) { p.gate2 = em2 + 2 * d; p.gate_sel = sel; }
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_RESID_GATE, s));
+    if (l.q_wo) {
+      mc_status st = gemm_fp8_rows(e, ao, d, Lp, d, l.q_wo, nullptr, l.m_wo, p, mc::EPI_RESID_GATE, s);
+      if (st != MC_OK) return st;
+    } else {
+      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_RESID_GATE, s));
+    }
   }
   // ---- cross attention: x = x + o(attn(norm_q(q(norm3(x))), norm_k(k(ctx)), v(ctx)))
-  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, l.n3w, l.n3b, 1, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s));
+  bool fused_cq = false;
+  {
+    mc_status st = ln_for_gemm(e, l.q_wcq != nullptr, true, x, l.n3w, l.n3b, 1, nullptr, nullptr, nullptr, s, &fused_cq);
+    if (st != MC_OK) return st;
+  }
   bf16_t* cq = qkv;  // the self-attention q/k/v are dead now
   bf16_t* ckv = e->buf<bf16_t>("ckv");
   {
     mc::GemmParams p = gp(xn, d, l.wcq, d, l.bcq, Lp, d, d);
     p.Cb = cq; p.ldc = d;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    if (l.q_wcq) {
+      mc_status st = gemm_fp8_rows(e, fused_cq ? nullptr : xn, d, Lp, d, l.q_wcq, nullptr, l.m_wcq, p, mc::EPI_BF16, s);
+      if (st != MC_OK) return st;
+    } else {
+      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    }
     HIP_TRY(mc::launch_rmsnorm_rope(cq, d, l.cnq, e->cfg.eps, nullptr, 0, Lp, d, s));
     if (e->ctx_active >= 0) {
       // constant over a video for this context: computed once by mc_set_context
@@ -917,17 +971,33 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     }
     mc::GemmParams o = gp(ao, d, l.wco, d, l.bco, Lp, d, d);
     o.X = x; o.ldx = d; o.gate = nullptr;
-    HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+    if (l.q_wco) {
+      mc_status st = gemm_fp8_rows(e, ao, d, Lp, d, l.q_wco, nullptr, l.m_wco, o, mc::EPI_RESID_GATE, s);
+      if (st != MC_OK) return st;
+    } else {
+      HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+    }
   }
   // ---- FFN: x = x + ffn(LN(x)*(1+e[4])+e[3]) * e[5]
-  HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, em + 4 * d, em + 3 * d, 0, e->cfg.eps, xn, d, nullptr, 0, Lp, d, s,
-                                 em2 ? em2 + 4 * d : nullptr, em2 ? em2 + 3 * d : nullptr, sel));
+  bool fused_ffn = false;
+  {
+    mc_status st = ln_for_gemm(e, l.q_w1 != nullptr, l.m_w1 != nullptr, x, em + 4 * d, em + 3 * d, 0,
+                               em2 ? em2 + 4 * d : nullptr, em2 ? em2 + 3 * d : nullptr, sel, s, &fused_ffn);
+    if (st != MC_OK) return st;
+  }
   bf16_t* h = e->buf<bf16_t>("h");
   {
     mc::GemmParams p = gp(xn, d, l.w1, d, l.b1, Lp, ffn, d);
     p.Cb = h; p.ldc = ffn;
+    // MX with fused quantisers: FFN-1's GELU epilogue writes the e4m3 rows + block scales FFN-2 reads (both inside "h":
+    // Lp * ffn bytes, then ffn / 32 * Lp scale bytes), the bf16 hidden tensor never exists
+    const bool h_fp8 = l.m_w1 && l.m_w2 && g_fp8_fused_quant;
+    uint8_t* hq = (uint8_t*)h;
+    uint8_t* hmx = hq + (size_t)Lp * ffn;
     if (l.q_w1) {
-      mc_status st = gemm_fp8_rows(e, xn, d, Lp, d, l.q_w1, l.s_w1, l.m_w1, p, mc::EPI_GELU_BF16, s);
+      if (h_fp8) { p.Cq = hq; p.ldcq = ffn; p.c_mx = hmx; p.mx_rows_c = Lp; }
+      mc_status st = gemm_fp8_rows(e, fused_ffn ? nullptr : xn, d, Lp, d, l.q_w1, l.s_w1, l.m_w1, p,
+                                   h_fp8 ? mc::EPI_GELU_MXFP8 : mc::EPI_GELU_BF16, s);
       if (st != MC_OK) return st;
     } else {
       HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
@@ -937,6 +1007,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     if (em2) { q.gate2 = em2 + 5 * d; q.gate_sel = sel; }
     const bool f8 = l.q_w2 != nullptr;
     auto ffn2 = [&](int epi) -> mc_status {
+      if (f8 && h_fp8) return gemm_fp8_rows(e, nullptr, ffn, Lp, ffn, l.q_w2, l.s_w2, l.m_w2, q, epi, s, hq, hmx);
       if (f8) return gemm_fp8_rows(e, h, ffn, Lp, ffn, l.q_w2, l.s_w2, l.m_w2, q, epi, s);
       HIP_TRY(mc::launch_gemm_bf16(q, epi, s));
       return MC_OK;
@@ -1390,6 +1461,9 @@ mc_status mc_set_option(const char* key, int value) {
   } else if (k == "gemm_defer") {
     if (value != 0 && value != 1) return fail(MC_EINVAL, "gemm_defer must be 0 (residual epilogues in place) or 1 (deferred into the next tile's main loop)");
     mc::g_gemm_defer = value;
+  } else if (k == "fp8_fused_quant") {
+    if (value != 0 && value != 1) return fail(MC_EINVAL, "fp8_fused_quant must be 0 (separate quantise passes) or 1 (fused into the producers)");
+    g_fp8_fused_quant = value;
   } else if (k == "attn_kernel") {
 #ifndef MC_AB_KERNELS
     if (value != 0 && value != 3 && value != 5)

@@ -299,12 +299,51 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_kernel(GemmParams p, int tiles
       if (m >= p.M) continue;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
+        if constexpr (EPI == EPI_GELU_MXFP8) {
+          // The 32 columns n0 + wc*64 + nh*32 .. +31 of row m are ONE MX block of the next GEMM's A operand: 8 values in
+          // this lane (nb = 0, 1), the rest in the lanes kgrp' != kgrp with the same l15 (lane ^ 16, ^ 32).  Values as
+          // the bf16 epilogue would store them; e = ceil(log2(amax / 448)) and the bytes as quantize_rows_mx_kernel.
+          const int nblk0 = n0 + wc * 64 + nh * 32;
+          float y[8];
+          float amax = 0.f;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int n = nblk0 + nb * 16 + 4 * kgrp;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b = *(const f32x4*)(p.bias + n);
+            const f32x4 val = acc[mh][mb][nh][nb] + b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              y[4 * nb + i] = bf16_round(gelu_tanh_fast(bf16_round(val[i])));
+              amax = fmaxf(amax, fabsf(y[4 * nb + i]));
+            }
+          }
+          amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+          amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+          int ex = -127;
+          if (amax > 0.f) {
+            int fx;
+            const float f = frexpf(amax * (1.0f / 448.0f), &fx);
+            ex = (f == 0.5f) ? fx - 1 : fx;
+            ex = max(-127, min(127, ex));
+          }
+          const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * nb] * inv, y[4 * nb + 1] * inv, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * nb + 2] * inv, y[4 * nb + 3] * inv, w, true);
+            *(int*)(p.Cq + (size_t)m * p.ldcq + nblk0 + nb * 16 + 4 * kgrp) = w;
+          }
+          if (kgrp == 0)
+            p.c_mx[(size_t)(nblk0 >> 5) * p.mx_rows_c + ((m & ~63) | ((m & 15) << 2) | ((m >> 4) & 3))] = (uint8_t)(ex + 127);
+          continue;
+        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           const int n = n0 + wc * 64 + nh * 32 + nb * 16 + 4 * kgrp;
           f32x4 b = {0.f, 0.f, 0.f, 0.f};
           if (p.bias) b = *(const f32x4*)(p.bias + n);
-          gemm_epilogue_quad<EPI>(p, m, n, acc[mh][mb][nh][nb] + b);
+          if constexpr (EPI != EPI_GELU_MXFP8) gemm_epilogue_quad<EPI>(p, m, n, acc[mh][mb][nh][nb] + b);
         }
       }
     }
@@ -394,6 +433,10 @@ hipError_t launch_gemm_mxfp8(const GemmParams& p, int epi, hipStream_t stream) {
     case EPI_RESID_GATE: return launch_mx_t<EPI_RESID_GATE>(p, stream);
     case EPI_RESID_CAPTURE: return launch_mx_t<EPI_RESID_CAPTURE>(p, stream);
     case EPI_F32: return launch_mx_t<EPI_F32>(p, stream);
+    case EPI_GELU_MXFP8:
+      if (!p.Cq || !p.c_mx || (p.ldcq % 16) != 0 || (p.mx_rows_c % 64) != 0 || p.mx_rows_c < (long)((p.M + TB - 1) / TB) * TB)
+        return hipErrorInvalidValue;
+      return launch_mx_t<EPI_GELU_MXFP8>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }

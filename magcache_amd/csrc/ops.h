@@ -19,6 +19,8 @@ enum GemmEpi {
   EPI_F32 = 5,           // X = acc + bias (fp32 store)
   EPI_GELU_ERF_BF16 = 6, // Cb = bf16(gelu_erf(bf16(acc + bias)))   (128x128 kernel only)
   EPI_SILU_BF16 = 7,     // Cb = bf16(silu(bf16(acc + bias)))       (128x128 kernel only; HunyuanVideo token refiner)
+  EPI_GELU_MXFP8 = 8,    // as 1, then MX-quantised in the epilogue: Cq = e4m3 bytes, c_mx = E8M0 block scales -- the A
+                         // operand of the next MX GEMM, the bits launch_quantize_rows_mx would make of Cb (gemm_mxfp8 only)
 };
 
 struct GemmParams {
@@ -43,6 +45,9 @@ struct GemmParams {
   // block-major: scale of (row, k block kb of 32) at [kb * mx_rows + row]
   const uint8_t* a_mx; long mx_rows_a;
   const uint8_t* w_mx; long mx_rows_w;
+  // EPI_GELU_MXFP8: e4m3 output rows (ldcq bytes) and their block scales, c_mx[(n / 32) * mx_rows_c + perm(m)]
+  uint8_t* Cq; long ldcq;
+  uint8_t* c_mx; long mx_rows_c;
 };
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
@@ -108,6 +113,14 @@ hipError_t launch_ln_modulate(const float* x, long ldx, const bf16_t* x0, long l
                               const float* sh, int mode, float eps, bf16_t* out, long ldo, float* out_f32,
                               long ldof, int M, int D, hipStream_t stream, const float* sc2 = nullptr,
                               const float* sh2 = nullptr, const uint8_t* sel = nullptr);
+// The same row, quantised for an fp8 GEMM instead of stored as bf16: e4m3 bytes q[m, :] relative to one scale per row
+// (row_scale != null; launch_quantize_rows_fp8's arithmetic) or to one E8M0 scale per 32 elements (mx != null;
+// launch_quantize_rows_mx's arithmetic and scale layout) -- bit-identical to quantising the bf16 row launch_ln_modulate
+// writes, without that row's round trip through memory.
+hipError_t launch_ln_modulate_fp8(const float* x, long ldx, const float* sc, const float* sh, int mode, float eps,
+                                  uint8_t* q, long ldq, float* row_scale, uint8_t* mx, long mx_rows, int M, int D,
+                                  hipStream_t stream, const float* sc2 = nullptr, const float* sh2 = nullptr,
+                                  const uint8_t* sel = nullptr);
 // Wan2.2 TI2V per-token timesteps (at most two distinct values per forward): t2[0] = max, t2[1] = min of t[0, n_all);
 // sel[i] = 1 where t[row0 + i] == min and min != max (rows >= n_rows: 0); t2[2] = number of tokens that are neither
 hipError_t launch_token_t_prepare(const float* t, int n_all, int row0, int n_rows, int n_rows_pad, float* t2, uint8_t* sel,

@@ -208,7 +208,8 @@ def test_wan21_vace_forward_and_magcache_run_vs_reference_golden(golden_dir):
 def test_fp8_linear_option_forward_vs_oracle():
     """fp8_linear (BASELINE.json config 4's "fp8 MFMA weight path"): QKV, FFN-1 and FFN-2 of every block run on an e4m3
     MFMA kernel -- 1: per-channel weight scales and per-token activation scales (gemm_fp8_big.hip), 2: MX block scales,
-    one E8M0 per 32 input features of every token / channel, multiplied inside the matrix core (gemm_mxfp8.hip).
+    one E8M0 per 32 input features of every token / channel, multiplied inside the matrix core (gemm_mxfp8.hip), 3: MX
+    for the self-attention O and the cross-attention Q / O Linears as well.
     Tolerance: fp8 e4m3 carries 3 mantissa bits (2^-4 relative per element), so the forward is held to 8e-2 relative L2
     of the fp32 oracle -- and it must differ measurably from the bf16 engine (the option really switches kernels)."""
     cfg = W.tiny_config(num_layers=2, num_heads=4, ffn_dim=1024, text_len=64, text_dim=128, freq_dim=64)
@@ -222,20 +223,31 @@ def test_fp8_linear_option_forward_vs_oracle():
     oracle.set_fp32_attention(True)
     ref_32 = oracle.forward([lat], t, [ctx], L, autocast=False)[0]
     outs = {}
-    for fp8 in (0, 1, 2):
+    lib = _lib.load()
+    for fp8 in (0, 1, 2, 3):
         cls = type(f"WanHIPfp8_{fp8}", (M.WanModelHIP,), {})
         m = cls(dict(cfg, fp8_linear=fp8), grid, device=DEV, calibration=False)
         m.load_state_dict(oracle.state_dict())
-        outs[fp8] = m([lat.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L)[0]
-    e16, e8, emx = (rel_l2(outs[k], ref_32) for k in (0, 1, 2))
-    assert e16 < 2e-2 and e8 < 8e-2 and emx < 8e-2, (e16, e8, emx)
+        outs[fp8] = m([lat.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L)[0].clone()
+        if fp8:
+            # the quantisers fused into LayerNorm + modulate (1..3) and into FFN-1's GELU epilogue (2, 3) make the SAME
+            # bytes as round 3's separate passes over the bf16 rows: the whole forward is bit-identical
+            _lib.check(lib.mc_set_option(b"fp8_fused_quant", 0))
+            try:
+                unfused = m([lat.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L)[0]
+            finally:
+                _lib.check(lib.mc_set_option(b"fp8_fused_quant", 1))
+            assert torch.equal(unfused, outs[fp8]), f"fp8_linear={fp8}: fused quantisers changed bits"
+    e16, e8, emx, emx6 = (rel_l2(outs[k], ref_32) for k in (0, 1, 2, 3))
+    assert e16 < 2e-2 and e8 < 8e-2 and emx < 8e-2 and emx6 < 8e-2, (e16, e8, emx, emx6)
     assert rel_l2(outs[1], outs[0]) > 2e-3 and rel_l2(outs[2], outs[0]) > 2e-3 and rel_l2(outs[2], outs[1]) > 1e-4
-    for k in (1, 2):
+    assert rel_l2(outs[3], outs[2]) > 1e-4          # 3 really moves the d x d Linears to the MX kernel
+    for k in (1, 2, 3):
         assert MR.psnr(outs[k].cpu().numpy(), ref_32.numpy(), data_range=float(ref_32.abs().max())) > 25.0
     with pytest.raises(_lib.MagCacheHipError):       # shapes the fp8 kernels cannot tile
         Engine(dict(W.tiny_config(), fp8_linear=True), grid, device=DEV)
     with pytest.raises(_lib.MagCacheHipError):
-        Engine(dict(cfg, fp8_linear=3), grid, device=DEV)
+        Engine(dict(cfg, fp8_linear=4), grid, device=DEV)
 
 
 @pytest.mark.parametrize("solver", ["unipc", "dpm++"])

@@ -189,7 +189,7 @@ def test_wan14_one_block_720p_length():
     check(res)
 
 
-@pytest.mark.parametrize("fp8,layers", [(2, 1), (2, 4), (1, 4)])
+@pytest.mark.parametrize("fp8,layers", [(2, 1), (2, 4), (1, 4), (3, 4)])
 def test_wan14b_widths_full_length_fp8_linears(fp8, layers):
     """BASELINE.json config 5's "fp8 MFMA weight path" AT SIZE: Wan 14B widths (d 5120, 40 heads,
     ffn 13 824) x L = 75 600 tokens with the QKV / FFN Linears on the e4m3 MFMA kernels (2: MX block scales, gemm_mxfp8.hip;
@@ -202,9 +202,13 @@ def test_wan14b_widths_full_length_fp8_linears(fp8, layers):
     cfg = dict(WAN_T2V_14B, num_layers=layers, fp8_linear=fp8)
     res = run_wan_layers(cfg, (21, 90, 160), seed=5, q_scale=4.0, ctx_valid=512,
                          tag=f"wan14B_{layers}block_L75600_qx4_fp8_linear{fp8}", capture_exact=False)
+    # fp8_linear = 3 (the d x d Linears on MX too: the attention branches then enter the residual stream through an e4m3
+    # product): measured 4.2e-2 at every layer, 43.3 dB -- 2.4x the error of mode 2 for 2 % of forward time on these
+    # synthetic weights (profiles/r04/NOTES.md); its bar is 2x ITS measurement
+    bar, db = (8.5e-2, 37.0) if fp8 == 3 else (3.5e-2, 45.0)
     for r in res["layers"]:
-        assert r["e_hip"] <= 3.5e-2, r
-    assert res["out_e_hip"] <= 3.5e-2 and res["out_psnr_hip_db"] >= 45.0, {k: v for k, v in res.items() if k != "layers"}
+        assert r["e_hip"] <= bar, r
+    assert res["out_e_hip"] <= bar and res["out_psnr_hip_db"] >= db, {k: v for k, v in res.items() if k != "layers"}
     # and the mode really differs from the bf16 engine's error level (the option switches kernels)
     assert res["out_e_hip"] > 1.5 * res["out_e_ac"], res
 

@@ -15,8 +15,8 @@ from magcache_amd.engine import MC_MODE_FULL, MC_MODE_SKIP, WAN_T2V_14B, synthet
 import argparse  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--fp8_linear", type=int, default=0, choices=(0, 1, 2),
-                help="OPTIONAL reduced-precision mode (BASELINE.json config 5's fp8 MFMA weight path): 1 per-row scales, 2 MX")
+ap.add_argument("--fp8_linear", type=int, default=0, choices=(0, 1, 2, 3),
+                help="OPTIONAL reduced-precision mode (BASELINE.json config 5's fp8 MFMA weight path): 1 per-row scales, 2 MX, 3 MX incl. the d x d Linears")
 args = ap.parse_args()
 DEV = "cuda:0"
 grid = (21, 90, 160)
