@@ -82,20 +82,34 @@ typedef struct {
 
 const char* mc_last_error(void);
 const char* mc_version(void);
-/* Process-wide tuning knobs (no reference counterpart; results are identical for every setting up
- * to fp32 summation order): "gemm_kernel" 0 = chosen by shape, 1 = 128x128-tile kernel, 2 = 256x256
- * counted-vmcnt kernel wherever it applies; "attn_kernel" 0 = default dispatch (attention_v5.hip: 4 waves x 64 query
- * rows, one wave per SIMD, hand-scheduled 16x16x32 MFMA stream, for single-shard calls; attention_v3.hip: 8 waves x 32
- * rows, for the sequence-parallel forms), 3 = attention_v3 everywhere, 5 = as 0; "mmdit_two_streams": the
- * text stream of an MM-DiT double block (FLUX / HunyuanVideo) runs on a second HIP stream next to the image stream
- * between a fork and a join event.  OPT-IN (default 0 = off): round 2 traced a run-to-run difference of this overlap to
- * packed-fp32 VALU instructions executing beside another stream's MFMA waves on one CU and removed them from the
- * kernels involved (bit-identical since: 300-replay determinism test, 4000-forward soak; FLUX.1-dev 512x512: +11 %),
- * but the root cause is not understood, so a caller has to ask for it: 1 = on, -1 = by shape (on when the text half
- * is at least 1/16 of the image half and the engine is not sequence parallel); values 2..6 are the diagnostic splits
- * of tests/two_stream_bisect.py (which pair of kernels overlaps).  Used by the
- * parity tests and the A/B micro-benchmarks (tools/build_ab_lib.py builds a library that also answers to the
- * retired kernel generations under tools/kernels_ab/). */
+/* Process-wide tuning knobs (no reference counterpart; results are identical for every setting up to fp32 summation
+ * order, bit-identical where noted).
+ *   "gemm_kernel"   0 = chosen by shape (default): gemm_bf16_v2.hip -- 256x256 tile, 4 waves x (128 x 128), one wave per
+ *                   SIMD, generated instruction stream, persistent over output tiles -- for the bf16 / GELU / gated-residual
+ *                   epilogues of shapes with K >= 1024 whose tile count suits 256-tiles; the 8-wave 256x256 kernel
+ *                   (gemm_bf16_big.hip) for the per-token-gate, residual-capture, embed and fp32 epilogues; the 128x128
+ *                   kernel for everything else.  1 = the 128x128 kernel everywhere, 2 = the 8-wave 256x256 kernel wherever
+ *                   it applies, 4 = gemm_bf16_v2 wherever it applies.  All three give the same bits.
+ *   "gemm_defer"    0 (default) = gemm_bf16_v2 applies a gated-residual epilogue in place; 1 = deferred into the next
+ *                   output tile's main loop (built, bit-identical, measured 1.5-4 % slower: DESIGN 3.2).
+ *   "attn_kernel"   0 = default dispatch = 5: attention_v5.hip (4 waves x 64 query rows, one wave per SIMD, generated
+ *                   32x32x16 MFMA stream with the lazy softmax reference and the pipelined finish) for EVERY form of the
+ *                   call -- one or several key shards, a shard left out, log-sum-exp out and the merge with an earlier
+ *                   launch (the sequence-parallel forms) -- whose K / V span fits 32-bit byte offsets; attention_v3.hip
+ *                   (8 waves x 32 rows) otherwise.  3 = attention_v3 everywhere.
+ *   "fp8_fused_quant"  1 (default) = with mc_config.fp8_linear the LayerNorm + modulate kernel (and, MX modes, the GELU
+ *                   epilogue of FFN-1) write the e4m3 operand of the next GEMM; 0 = separate quantise passes.  Same bits.
+ *   "mmdit_two_streams"  the text stream of an MM-DiT double block (FLUX / HunyuanVideo) runs on a second HIP stream next
+ *                   to the image stream between a fork and a join event.  OPT-IN (default 0 = off): 1 = on, -1 = by shape
+ *                   (on when the text half is at least 1/16 of the image half and the engine is not sequence parallel);
+ *                   2..6 = the diagnostic splits of tests/two_stream_bisect.py.  Round 2 traced a run-to-run difference
+ *                   of this overlap to packed-fp32 VALU instructions of one kernel executing beside the other stream's
+ *                   MFMA waves on one CU and removed them from the kernels involved (bit-identical since: 300-replay
+ *                   test, 4000-forward soak; FLUX.1-dev 512x512: +11 %); round 4 showed that agent-scope acquire /
+ *                   release and cache-bypassing loads do not change the fault (it is an ALU result, not visibility:
+ *                   profiles/r04/NOTES.md 4).  The cause below that is not known, so a caller has to ask for the overlap.
+ * Used by the parity tests and the A/B micro-benchmarks (tools/build_ab_lib.py builds a library that also answers to the
+ * retired kernel generations under tools/kernels_ab/ as gemm_kernel 3 / attn_kernel 1, 2, 4). */
 mc_status mc_set_option(const char* key, int value);
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -30,11 +30,11 @@ def rel_l2(a, b):
 
 @pytest.fixture(params=[1, 2, 4, 0], ids=["gemm-128", "gemm-256", "gemm-256-v2", "gemm-by-shape"])
 def kernel_variant(request):
-    """Every GEMM test (and the attention tests, whose inputs come out of GEMMs in the engine) runs with the 128x128
-    kernel forced, with the 256x256 counted-vmcnt kernel forced wherever the shape allows, with the generation-2
-    256x256 kernel (4 waves, generated stream, gemm_bf16_v2.hip) forced wherever ITS shape rules allow, and with the
-    shipped by-shape dispatch.  One attention kernel is shipped (attention_v3.hip); the retired generations are A/B tooling
-    (tools/kernels_ab/, tools/build_ab_lib.py)."""
+    """Every GEMM test runs with the 128x128 kernel forced, with the 8-wave 256x256 counted-vmcnt kernel
+    (gemm_bf16_big.hip) forced wherever the shape allows, with the 4-wave 256x256 kernel (generated stream,
+    gemm_bf16_v2.hip) forced wherever ITS shape and epilogue rules allow, and with the shipped by-shape dispatch (which
+    picks gemm_bf16_v2 for the bf16 / GELU / gated-residual epilogues of large shapes since round 4).  Retired kernel
+    generations are A/B tooling only (tools/kernels_ab/, tools/build_ab_lib.py)."""
     lib = _lib.load()
     _lib.check(lib.mc_set_option(b"gemm_kernel", request.param))
     yield request.param
@@ -43,8 +43,10 @@ def kernel_variant(request):
 
 @pytest.fixture(params=[3, 5], ids=["attn-8x32", "attn-4x64"])
 def attn_variant(request):
-    """The attention tests run on attention_v3.hip (8 waves x 32 rows) and on attention_v5.hip (4 waves x 64 rows, one
-    wave per SIMD, hand-scheduled; it takes the single-shard calls and leaves the others to v3)."""
+    """The attention tests run on both shipped kernels: attention_v5.hip (4 waves x 64 rows, one wave per SIMD, generated
+    32x32x16 stream -- the default for EVERY form of the call: key shards, a shard left out, log-sum-exp out / merge) and
+    attention_v3.hip (8 waves x 32 rows: the fallback for K / V spans beyond 32-bit byte offsets, forced here by
+    attn_kernel = 3)."""
     lib = _lib.load()
     _lib.check(lib.mc_set_option(b"attn_kernel", request.param))
     yield request.param
