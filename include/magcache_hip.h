@@ -90,8 +90,9 @@ const char* mc_version(void);
  *                   (gemm_bf16_big.hip) for the per-token-gate, residual-capture, embed and fp32 epilogues; the 128x128
  *                   kernel for everything else.  1 = the 128x128 kernel everywhere, 2 = the 8-wave 256x256 kernel wherever
  *                   it applies, 4 = gemm_bf16_v2 wherever it applies.  All three give the same bits.
- *   "gemm_defer"    0 (default) = gemm_bf16_v2 applies a gated-residual epilogue in place; 1 = deferred into the next
- *                   output tile's main loop (built, bit-identical, measured 1.5-4 % slower: DESIGN 3.2).
+ *   "gemm_defer"    no effect in the shipped library.  (A/B libraries whose gemm_bf16_v2 stream was generated with
+ *                   tools/gen_gemm_v2.py --defer 1 apply a gated-residual epilogue inside the next output tile's main
+ *                   loop -- bit-identical, measured 1.5-4 % slower, DESIGN 3.2 -- and 0 switches that off at run time.)
  *   "attn_kernel"   0 = default dispatch = 5: attention_v5.hip (4 waves x 64 query rows, one wave per SIMD, generated
  *                   32x32x16 MFMA stream with the lazy softmax reference and the pipelined finish) for EVERY form of the
  *                   call -- one or several key shards, a shard left out, log-sum-exp out and the merge with an earlier

@@ -14,9 +14,12 @@
 //     bf16, TRANSPOSED through a private 4 KiB strip of LDS and leave row-major -- every global access is 16 bytes per
 //     lane and whole 128-byte lines per row.  (The MFMA layout's own 8-byte stores cost ~60 cycles of the CU's address path
 //     each: 1264 vs 1531 TF with the stores compiled out.)
-//   * the gated residual epilogue is DEFERRED: the tile's bf16 values go to a per-workgroup scratch tile (L2-resident,
-//     128 KiB), and x += gate * value runs INSIDE the next output tile's main loop (asm, 32 chunks over 8 pairs of K
-//     tiles, loads ~130 MFMA gaps ahead of their use); only the workgroup's last tile pays for it in the open.
+//   * the gated residual epilogue runs IN PLACE behind the tile's main loop (x loaded two strips ahead).  A DEFERRED form
+//     exists as a generator option (gen_gemm_v2.py --defer 1, MC_GEMM_V2_DEFER): the tile's bf16 values go to a per-workgroup
+//     scratch tile (L2-resident, 128 KiB) and x += gate * value runs INSIDE the next output tile's main loop (asm, 32 chunks
+//     over 8 pairs of K tiles, loads ~130 MFMA gaps ahead of their use).  It is emulator-validated and bit-identical on the
+//     GPU, and 1.5-4 % SLOWER (the CU's memory path is the shared bound), so the shipped stream is generated WITHOUT it;
+//     in a library built with it, mc_set_option("gemm_defer", 0) switches it off at run time.
 #pragma clang diagnostic ignored "-Winline-asm"
 #include "common.h"
 #include <algorithm>
@@ -49,7 +52,7 @@
 
 namespace mc {
 
-int g_gemm_defer = 1;   // mc_set_option("gemm_defer", 0): residual epilogues in place (A/B, debugging)
+int g_gemm_defer = 1;   // only read when the stream was generated with --defer 1: mc_set_option("gemm_defer", 0) = epilogues in place
 
 namespace {
 

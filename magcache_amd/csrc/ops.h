@@ -57,7 +57,7 @@ hipError_t launch_gemm_bf16_w128(const GemmParams& p, int epi, hipStream_t strea
 bool gemm_bf16_big_supported(const GemmParams& p);
 hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream);     // 256x256 tiles, 4 waves, generated stream
 bool gemm_bf16_v2_supported(const GemmParams& p);
-extern int g_gemm_defer;   // 1 (default): gemm_bf16_v2 runs a tile's gated-residual epilogue inside the next tile's main loop
+extern int g_gemm_defer;   // (libraries whose gemm_v2 stream was generated with --defer 1 only; the shipped one is not) 0: epilogues in place
 extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported (3: A/B library only), 4: generation 2 where supported
 // fp8 (e4m3) operands, 256x256 tiles, v_mfma_f32_32x32x64_f8f6f4; K (fp8 elements) a multiple of 256
 hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);
