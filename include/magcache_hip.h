@@ -109,8 +109,8 @@ const char* mc_version(void);
  *                   test, 4000-forward soak; FLUX.1-dev 512x512: +11 %); round 4 showed that agent-scope acquire /
  *                   release and cache-bypassing loads do not change the fault (it is an ALU result, not visibility:
  *                   profiles/r04/NOTES.md 4).  The cause below that is not known, so a caller has to ask for the overlap.
- * Used by the parity tests and the A/B micro-benchmarks (tools/build_ab_lib.py builds a library that also answers to the
- * retired kernel generations under tools/kernels_ab/ as gemm_kernel 3 / attn_kernel 1, 2, 4). */
+ * Used by the parity tests and the A/B micro-benchmarks (tools/kbench.cpp loads several builds of this library side by side:
+ * tools/build_v5_variants.py, build_gemm_v2_variants.py). */
 mc_status mc_set_option(const char* key, int value);
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

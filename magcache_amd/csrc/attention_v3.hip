@@ -1,15 +1,15 @@
 // Flash-style non-causal attention for gfx950, head_dim 128 -- 8 waves, software pipelined.
 //
 // Contract: upstream wan/modules/attention.py flash_attention(q,k,v,k_lens) (reference call site
-// MagCache4Wan2.1/magcache_generate.py:297-298).  The two earlier generations of this kernel (8 waves unpipelined,
-// 4 waves x 64 rows) live in tools/kernels_ab/ and are linked only into the A/B library of tools/build_ab_lib.py.
+// MagCache4Wan2.1/magcache_generate.py:297-298).  (The two earlier generations of this kernel -- 8 waves unpipelined,
+// compiler-scheduled 4 waves x 64 rows -- left the tree in round 4; git history has them under tools/kernels_ab/.)
 //
 // Why this shape (measured with tools/ubench_issue.cpp on MI355X): ONE wave issues at most one
 // v_mfma_f32_32x32x16_bf16 per ~35 cycles and hides only ~4 other instructions behind it, each
 // further VALU instruction costs ~4.5 cycles (v_exp_f32 ~10).  TWO waves on a SIMD sustain one MFMA
 // per ~17.5 cycles and twice the VALU issue rate.  Attention needs ~7 non-MFMA instructions per MFMA
 // (exp2, fma, row sums, bf16 packing, row maxima, K / V^T fragment reads), so a 4-wave kernel
-// (tools/kernels_ab/attention_v2.hip) is issue-bound at one wave per SIMD; here every SIMD runs two waves of 32 query
+// (round 1's attention_v2, retired) is issue-bound at one wave per SIMD; here every SIMD runs two waves of 32 query
 // rows each (256 VGPRs per wave, all MFMAs in VGPR form -- no AGPR copies, no asm MFMAs), and each
 // wave runs the same software pipeline:
 //
@@ -522,8 +522,7 @@ hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream) {
 
 // mc_set_option("attn_kernel", v): 0 = default dispatch = 5; 3 = this kernel everywhere; 5 = attention_v5.hip (4 waves x 64
 // rows, hand-scheduled) wherever it applies -- every form of the call whose K / V span fits 32-bit byte offsets -- and
-// this kernel otherwise.  The A/B library (tools/build_ab_lib.py, -DMC_AB_KERNELS) also links
-// tools/kernels_ab/attention{,_v2,_v4}.hip as 1 / 2 / 4.
+// this kernel otherwise.
 int g_attn_kernel = 0;
 constexpr int kDefaultAttnKernel = 5;   // attention_v5 where it applies (profiles/r03: +13 % over v3), v3 otherwise
 
@@ -531,11 +530,6 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
   const bool two_phase = p.skip_shard_p1 != 0 || p.lse_out || p.lse_in;
   if (two_phase && (p.skip_shard_p1 < 0 || p.skip_shard_p1 > p.n_shards || (p.skip_shard_p1 && p.n_shards < 2)))
     return hipErrorInvalidValue;
-#ifdef MC_AB_KERNELS
-  if (!two_phase && g_attn_kernel == 1) return launch_attention_v1(p, stream);
-  if (!two_phase && g_attn_kernel == 2) return launch_attention_v2(p, stream);
-  if (!two_phase && g_attn_kernel == 4) return launch_attention_v4(p, stream);
-#endif
   const int kernel = g_attn_kernel ? g_attn_kernel : kDefaultAttnKernel;
   if (kernel == 5 && attention_v5_supports(p)) return launch_attention_v5(p, stream);
   return launch_attention_v3(p, stream);

@@ -1450,12 +1450,7 @@ mc_status mc_set_option(const char* key, int value) {
   if (!key) return fail(MC_EINVAL, "null key");
   const std::string k(key);
   if (k == "gemm_kernel") {
-#ifdef MC_AB_KERNELS
-    const int gemm_max = 3;
-#else
-    const int gemm_max = 2;
-#endif
-    if ((value < 0 || value > gemm_max) && value != 4)
+    if ((value < 0 || value > 2) && value != 4)
       return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 4 (256x256, 4 waves, generated stream)");
     mc::g_gemm_kernel = value;
   } else if (k == "gemm_defer") {
@@ -1465,11 +1460,8 @@ mc_status mc_set_option(const char* key, int value) {
     if (value != 0 && value != 1) return fail(MC_EINVAL, "fp8_fused_quant must be 0 (separate quantise passes) or 1 (fused into the producers)");
     g_fp8_fused_quant = value;
   } else if (k == "attn_kernel") {
-#ifndef MC_AB_KERNELS
     if (value != 0 && value != 3 && value != 5)
       return fail(MC_EINVAL, "attn_kernel must be 0 (default), 3 (8 waves x 32 rows) or 5 (4 waves x 64 rows, hand-scheduled)");
-#endif
-    if (value < 0 || value > 5) return fail(MC_EINVAL, "attn_kernel must be 0..5");
     mc::g_attn_kernel = value;
   } else if (k == "mmdit_two_streams") {
     if (value < -1 || value > 6) return fail(MC_EINVAL, "mmdit_two_streams must be -1 (by shape), 0, 1 or a diagnostic mode 2..6");

@@ -219,8 +219,8 @@ hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stre
 }
 
 // Kernel choice.  g_gemm_kernel: 0 = by shape, 1 = always the 128x128 kernel, 2 = the 256x256
-// kernel wherever it is supported (mc_set_option("gemm_kernel", v); used by the parity tests and A/B benchmarks);
-// 3 = the 4-wave variant tools/kernels_ab/gemm_bf16_w128.hip, linked only into the A/B library (-DMC_AB_KERNELS).
+// kernel wherever it is supported, 4 = gemm_bf16_v2 wherever it is (mc_set_option("gemm_kernel", v); used by the parity
+// tests and A/B benchmarks).
 // By shape (round 4, remeasured with gemm_v2 as the 256^2 kernel: tools/gemm_smallm_v2_ab.py, profiles/r04/
 // gemm_smallm_v2_ab.log): time in units of one 256^2 tile's K loop.  A 256^2 kernel needs ceil(tiles256 / 256) of them
 // (one workgroup per CU).  A 128^2 workgroup alone on a CU needs ~0.62 of that, two co-resident ones ~1.45 x 0.62 each
@@ -257,11 +257,6 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
       ((g_gemm_kernel == 0 && big && v2_epi) ||
        (g_gemm_kernel == 4 && (v2_epi || epi == EPI_RESID_CAPTURE || epi == EPI_F32))))
     return launch_gemm_bf16_v2(p, epi, stream);
-#ifdef MC_AB_KERNELS
-  if (g_gemm_kernel == 3 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
-      gemm_bf16_big_supported(p))
-    return launch_gemm_bf16_w128(p, epi, stream);   // the 4-wave 128x128-wave-tile variant: explicit request only
-#endif
   return big ? launch_gemm_bf16_big(p, epi, stream) : launch_gemm_bf16_small(p, epi, stream);
 }
 

@@ -12,7 +12,7 @@
 // every SIMD sustains 2095 TFLOP/s with 16x16x32 and 1296 TFLOP/s with 32x32x16 on random operands
 // (tools/ubench_mfma_power.cpp, profiles/r02/ubench_mfma_power.log) -- a 32x32x16 moves 8 KB of accumulator per
 // 16 K MACs through the register file, a 16x16x32 2 KB per 8 K MACs.  Round 1's kernel was the same pipeline on
-// 32x32x16 (kept as tools/kernels_ab/gemm_bf16_big_32x32.hip for A/B) and stopped at ~1.2 PFLOP/s in its main loop.
+// 32x32x16 (retired in round 4; git history has it as tools/kernels_ab/gemm_bf16_big_32x32.hip) and stopped at ~1.2 PFLOP/s in its main loop.
 //
 // Geometry
 //   * workgroup = 8 waves (2 along M x 4 along N), one 256x256 output tile, 1 workgroup per CU

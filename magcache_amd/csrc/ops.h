@@ -53,12 +53,11 @@ struct GemmParams {
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
 hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stream);  // 128x128 tiles
 hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);    // 256x256 tiles, 8 waves
-hipError_t launch_gemm_bf16_w128(const GemmParams& p, int epi, hipStream_t stream);   // tools/kernels_ab (A/B library only)
 bool gemm_bf16_big_supported(const GemmParams& p);
 hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream);     // 256x256 tiles, 4 waves, generated stream
 bool gemm_bf16_v2_supported(const GemmParams& p);
 extern int g_gemm_defer;   // (libraries whose gemm_v2 stream was generated with --defer 1 only; the shipped one is not) 0: epilogues in place
-extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported (3: A/B library only), 4: generation 2 where supported
+extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported, 4: generation 2 where supported
 // fp8 (e4m3) operands, 256x256 tiles, v_mfma_f32_32x32x64_f8f6f4; K (fp8 elements) a multiple of 256
 hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);
 bool gemm_fp8_supported(const GemmParams& p);
@@ -98,10 +97,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream);     // pic
 hipError_t launch_attention_v5(const AttnParams& p, hipStream_t stream);  // 4 waves x 64 rows, one wave per SIMD, hand-scheduled (round 3)
 bool attention_v5_supports(const AttnParams& p);                          // K / V span within 32-bit byte offsets
 hipError_t launch_attention_v3(const AttnParams& p, hipStream_t stream);  // 8 waves x 32 rows, pipelined, 32x32x16 MFMA (round 1)
-hipError_t launch_attention_v4(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab: the v3 pipeline on 16x16x32 (A/B library only)
-hipError_t launch_attention_v1(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)
-hipError_t launch_attention_v2(const AttnParams& p, hipStream_t stream);  // tools/kernels_ab (A/B library only)
-extern int g_attn_kernel;  // 0: by support (see launch_attention), 3: attention_v3.hip, 5: attention_v5.hip where it applies (1, 2, 4: A/B library only)
+extern int g_attn_kernel;  // 0: by support (see launch_attention), 3: attention_v3.hip, 5: attention_v5.hip where it applies
 
 // ---------------------------------------------------------------- token-wise ops (elementwise.hip)
 // out[m,:] = bf16( LN(x[m,:]) * a + b ),  a = 1+scale (modulate) or weight (affine)

@@ -33,8 +33,7 @@ def kernel_variant(request):
     """Every GEMM test runs with the 128x128 kernel forced, with the 8-wave 256x256 counted-vmcnt kernel
     (gemm_bf16_big.hip) forced wherever the shape allows, with the 4-wave 256x256 kernel (generated stream,
     gemm_bf16_v2.hip) forced wherever ITS shape and epilogue rules allow, and with the shipped by-shape dispatch (which
-    picks gemm_bf16_v2 for the bf16 / GELU / gated-residual epilogues of large shapes since round 4).  Retired kernel
-    generations are A/B tooling only (tools/kernels_ab/, tools/build_ab_lib.py)."""
+    picks gemm_bf16_v2 for the bf16 / GELU / gated-residual epilogues of large shapes since round 4)."""
     lib = _lib.load()
     _lib.check(lib.mc_set_option(b"gemm_kernel", request.param))
     yield request.param

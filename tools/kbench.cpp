@@ -4,7 +4,7 @@
 //      what: gemm | attn | calib | all
 //
 // Every library given on the command line is dlopen'ed privately (RTLD_LOCAL), so build variants of
-// libmagcache_hip.so (tools/build_variants.py, tools/build_ab_lib.py) are measured INTERLEAVED IN ONE PROCESS on the same
+// libmagcache_hip.so (tools/build_variants.py, tools/build_v5_variants.py, tools/build_gemm_v2_variants.py) are measured INTERLEAVED IN ONE PROCESS on the same
 // buffers: per shape a 1 s warm-up (sustained-power regime), then <rounds> rounds of <launches> back-to-back launches
 // per library, hipEvent-timed; median and minimum per library are printed (CDNA4 guide, methodology rules 24/25: a
 // within-probe interleaved A/B on random data).  Results of libB.. are compared bit for bit with libA, and libA is
