@@ -46,6 +46,9 @@
 #ifndef MC_V2_DEFER_ABL
 #define MC_V2_DEFER_ABL 0
 #endif
+#ifndef MC_V2_RESID_SPLIT
+#define MC_V2_RESID_SPLIT 1   // residual epilogue: a lane's two x quads are 256 bytes apart (whole lines per instruction) instead of adjacent
+#endif
 #ifndef MC_V2_XAHEAD
 #define MC_V2_XAHEAD 1     // residual form, not deferred: m blocks of x loaded ahead (2, 3, 5 measured: no faster)
 #endif
@@ -145,6 +148,18 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       rio = __builtin_amdgcn_make_buffer_rsrc((void*)scr, 0, TB * TB * 2, 0x00020000);
       vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 2u;
     } else if (EPI == EPI_RESID_GATE) {
+#if MC_V2_RESID_SPLIT
+      // lane -> columns 4 c16 .. + 3 and 64 + 4 c16 .. + 3 of the wave's 128: every x load / store instruction then covers 256
+      // CONTIGUOUS bytes of a row (two whole 128-byte lines), instead of 16 bytes out of every 32 over all four lines
+      if (p.gate) {
+        const float* gp = p.gate + tn0 + wc_ * 128 + c16 * 4;
+        gA = *(const f32x4*)gp;
+        gB = *(const f32x4*)(gp + 64);
+      }
+      row_b = (uint32_t)p.ldx * 4u;
+      rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (size_t)tm0 * p.ldx + tn0), 0, rows * row_b, 0x00020000);
+      vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 4) * 4u;
+#else
       if (p.gate) {
         const float* gp = p.gate + tn0 + wc_ * 128 + c16 * 8;
         gA = *(const f32x4*)gp;
@@ -153,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       row_b = (uint32_t)p.ldx * 4u;
       rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (size_t)tm0 * p.ldx + tn0), 0, rows * row_b, 0x00020000);
       vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 4u;
+#endif
     } else {
       row_b = (uint32_t)p.ldc * 2u;
       rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cb + (size_t)tm0 * p.ldc + tn0), 0, rows * row_b, 0x00020000);
@@ -162,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     // dropped.)  Residual form here: the 8 x loads of m block mb + XA are issued BEFORE m block mb is transposed and
     // applied, pinned by sched_barrier -- hipcc otherwise sinks every load to its use (one round trip per pair of loads).
     constexpr int XA = MC_V2_XAHEAD, XS = XA + 1;
+    constexpr uint32_t X2_OFF = MC_V2_RESID_SPLIT ? 256u : 16u;   // byte distance of the lane's second quad of x
     f32x4 xin[XS][4][2];
     auto load_x = [&](int mb, int set) {
 #pragma unroll
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
         xin[set][i][0] = xin[set][i][1] = gA;
 #else
         xin[set][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow, 0, 0));
-        xin[set][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow + 16, 0, 0));
+        xin[set][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow + X2_OFF, 0, 0));
 #endif
       }
     };
@@ -197,7 +214,15 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       }
       u32x4 rowv[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rowv[i] = *(const u32x4*)(strip + rd_off + i * (4 * 272));
+      for (int i = 0; i < 4; ++i) {
+        if (MC_V2_RESID_SPLIT && resid_here) {   // bf16 columns 4 c16 .. + 3 | 64 + 4 c16 .. + 3 of the row
+          const u32x2 lo = *(const u32x2*)(strip + rr * 272 + c16 * 8 + i * (4 * 272));
+          const u32x2 hi = *(const u32x2*)(strip + rr * 272 + 128 + c16 * 8 + i * (4 * 272));
+          rowv[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        } else {
+          rowv[i] = *(const u32x4*)(strip + rd_off + i * (4 * 272));
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
           asm volatile("" ::"v"(xa), "v"(xb));
 #else
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xa), rio, vrow, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb), rio, vrow + 16, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb), rio, vrow + X2_OFF, 0, 0);
 #endif
         } else {
 #if MC_V2_EPI_ABL == 1

@@ -41,6 +41,8 @@ for spec in sys.argv[1:]:
         extra.append("-DMC_V2_XAHEAD=" + kv["xahead"])
     if kv.get("stagger"):
         extra.append("-DMC_V2_STAGGER=" + kv["stagger"])
+    if kv.get("residsplit") is not None:
+        extra.append("-DMC_V2_RESID_SPLIT=" + kv["residsplit"])
     if kv.get("epiabl"):
         extra.append("-DMC_V2_EPI_ABL=" + kv["epiabl"])
     defs = extra + [f'-DMC_GEMM_V2_BODY="{out}/gemm_v2_body.inc"', f'-DMC_GEMM_V2_CLOBBERS="{out}/gemm_v2_clobbers.inc"',

@@ -3,7 +3,9 @@
 cd $GRAFT_REPO_ROOT; out=gpurun_out/$1; mkdir -p $out; shift
 cp magcache_amd/libmagcache_hip.so /tmp/shipped.so
 for n in "$@"; do
-  if [ "$n" = shipped ]; then cp /tmp/shipped.so magcache_amd/libmagcache_hip.so; else cp build_variants/v5_$n/libmagcache_hip.so magcache_amd/libmagcache_hip.so; fi
+  if [ "$n" = shipped ]; then cp /tmp/shipped.so magcache_amd/libmagcache_hip.so
+  elif [ -d build_variants/$n ]; then cp build_variants/$n/libmagcache_hip.so magcache_amd/libmagcache_hip.so
+  else cp build_variants/v5_$n/libmagcache_hip.so magcache_amd/libmagcache_hip.so; fi
   timeout 600 python bench.py --steps 20 --warmup 5 --no_cpu_baseline > $out/bench_$n.log 2>&1
   python3 - $out/bench_$n.log $n <<'PY'
 import json,sys
