@@ -29,6 +29,11 @@ Two MFMA shapes (cfg "mfma"):
    16: v_mfma_f32_16x16x32_bf16, wave = 4 query blocks x 16 rows, 64 MFMAs per phase -- the same fragment reads, VALU
        work and registers, less power per FLOP (tools/ubench_mfma_issue2.cpp: 2030 vs 1800 TFLOP/s on random operands at
        the power limit): faster back to back (power-limited), slower inside the engine (profiles/r03/NOTES.md 4, 5).
+Outside the loop (round 4, cfg q_dma / epi_lds; profiles/r04/NOTES.md 2): the workgroup's 256 query rows arrive as four
+64-row tile images by LDS-DMA (K's swizzle, K's pieces) in the V ring, which is idle until the prologue's second barrier,
+and every wave reads the fragments of its image with 16 ds_read_b128; the result leaves through a per-wave 64 x 272-byte
+strip in the (dead) rings as 16 stores of four whole 256-byte rows each.  Both replaced per-lane global accesses that
+touched 32 rows per instruction; same bits, -2 % per self-attention launch live, -16 % on the 512-key cross-attention.
 Same math as attention_v3.hip: Q pre-multiplied by scale*log2(e), accumulators of S start from -m (c_init), deferred
 rescale (wave-uniform rare branch when a lane maximum exceeds the reference by more than 2^RTHR), S^T accumulators consumed
 directly as the B operand of the PV MFMA (contraction index permuted consistently on both operands), K rows swizzled
