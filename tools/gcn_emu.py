@@ -648,6 +648,13 @@ class Machine:
             raise RuntimeError(f"line {ins.line}: misaligned ds_read_b128")
         self._ds_finish(w, ins, o[0], lambda: self._lds_read(addr, 16).view(np.uint32).reshape(64, 4))
 
+    def i_ds_read_b64(self, w, ins, o):
+        self._haz_read(w, ins, o[1], "mem")
+        addr = self.rd(w, o[1]).astype(np.int64) + ins.mods.get("offset", 0)
+        if (addr % 8).any():
+            raise RuntimeError(f"line {ins.line}: misaligned ds_read_b64")
+        self._ds_finish(w, ins, o[0], lambda: self._lds_read(addr, 8).view(np.uint32).reshape(64, 2))
+
     def i_ds_read_b32(self, w, ins, o):
         self._haz_read(w, ins, o[1], "mem")
         addr = self.rd(w, o[1]).astype(np.int64) + ins.mods.get("offset", 0)
@@ -664,6 +671,27 @@ class Machine:
             for l in range(64):
                 a = int(addr[l])
                 self.lds[a:a + 4] = np.frombuffer(np.uint32(data[l]).tobytes(), dtype=np.uint8)
+        if self.load_late:
+            w.lgkm_q.append(put)
+        else:
+            put()
+            w.lgkm_q.append(None)
+
+    def i_ds_write_b128(self, w, ins, o):
+        """ds_write_b128 vaddr, vdata[4] [offset]"""
+        self._haz_read(w, ins, o[0], "mem")
+        self._haz_read(w, ins, o[1], "mem")
+        addr = self.rd(w, o[0]).astype(np.int64) + ins.mods.get("offset", 0)
+        if (addr % 16).any():
+            raise RuntimeError(f"line {ins.line}: misaligned ds_write_b128")
+        data = np.stack([self.rd(w, o[1], i) for i in range(4)], axis=1).copy().view(np.uint8).reshape(64, 16)
+
+        def put():
+            for l in range(64):
+                a = int(addr[l])
+                if a + 16 > self.lds.size:
+                    raise RuntimeError(f"LDS write out of range {a}")
+                self.lds[a:a + 16] = data[l]
         if self.load_late:
             w.lgkm_q.append(put)
         else:

@@ -107,6 +107,8 @@ DEFAULT_CFG = {
                              # and each wave reads the fragments of ITS 64 rows with 16 ds_read_b128; before, 16
                              # global_load_dwordx4 per wave each touched 32 rows (32 bytes of every 256-byte row per
                              # instruction): 14.5 us of a 512-key launch (kbench_attn_fixed_cost_abl.log).  Needs nst >= 4.
+    "merge_rows": 1,         # (two-phase attention, with epi_lds) the earlier launch's result is fetched as whole rows through
+                             # the strip as well (it was 32 per-lane 8-byte loads per wave, each touching 32 rows)
     "final_wait": 0,         # s_waitcnt vmcnt(0) behind the last store (the wave ends right after the asm statement; stores
                              # in flight at s_endpgm complete on their own)
 }
@@ -1370,13 +1372,41 @@ def emit_epilogue(E):
         E.i(f"global_load_dword {v(t0 + 2 + qb)}, {v(lrow[qb])}, {s(S_LSEI, 2)}")
     # the earlier launch's O rows of this lane: 8 bytes per (qb, db, g) -> v0.. (the S buffers are dead)
     nq = M.NDB * (M.ACC // 4)
-    for qb in range(M.NQB):
-        for db in range(M.NDB):
-            for g in range(M.ACC // 4):
-                off = db * 64 + g * 16 if big else db * 32
-                q = (qb * nq + db * (M.ACC // 4) + g) * 2
-                E.i(f"global_load_dwordx2 {v(q, 2)}, {v(M.V_QOFF + qb)}, {s(S_O, 2)} offset:{off}")
-    E.i("s_waitcnt vmcnt(0)")
+    if via_lds and cfg["merge_rows"]:
+        # ... fetched as WHOLE ROWS (16 x four 256-byte rows, the read-back's lane map) into the strip and picked up from
+        # there in the accumulator layout: the per-lane loads touched 32 rows x 8 bytes per instruction
+        v_go2 = M.V_RM + 6
+        E.i(f"s_lshl_b32 {s(S_T + 2)}, {s(S_LDO)}, 2")                     # 4 rows
+        E.i(f"v_mov_b32 {v(v_go2)}, {v(v_go)}")
+        for it in range(16):
+            E.i(f"global_load_dwordx4 {v(64 + 4 * it, 4)}, {v(v_go2)}, {s(S_O, 2)}")
+            if it < 15:
+                E.i(f"v_add_u32 {v(v_go2)}, {s(S_T + 2)}, {v(v_go2)}")
+        E.i("s_waitcnt vmcnt(0)")
+        for it in range(16):
+            E.i(f"ds_write_b128 {v(v_rb)}, {v(64 + 4 * it, 4)} offset:{it * 4 * STRIP_ROW}")
+            if it % 8 == 7:
+                E.i("s_waitcnt lgkmcnt(0)")
+        n = 0
+        for qb in range(M.NQB):
+            for db in range(M.NDB):
+                for g in range(M.ACC // 4):
+                    off = db * 64 + g * 16 if big else db * 32
+                    q = (qb * nq + db * (M.ACC // 4) + g) * 2
+                    E.i(f"ds_read_b64 {v(q, 2)}, {v(soff[qb])} offset:{off}")
+                    n += 1
+                    if n % 8 == 0:
+                        E.i("s_waitcnt lgkmcnt(0)")
+        E.i("s_waitcnt lgkmcnt(0)")
+        E.lds_done = E.lds_issued
+    else:
+        for qb in range(M.NQB):
+            for db in range(M.NDB):
+                for g in range(M.ACC // 4):
+                    off = db * 64 + g * 16 if big else db * 32
+                    q = (qb * nq + db * (M.ACC // 4) + g) * 2
+                    E.i(f"global_load_dwordx2 {v(q, 2)}, {v(M.V_QOFF + qb)}, {s(S_O, 2)} offset:{off}")
+        E.i("s_waitcnt vmcnt(0)")
     for qb in range(M.NQB):
         prev, mm, wa, wb = t0 + 2 + qb, t0 + 6, t0 + 7, t0 + 8
         E.i(f"v_max_f32 {v(mm)}, {v(lse[qb])}, {v(prev)}")
