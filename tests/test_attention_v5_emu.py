@@ -169,6 +169,13 @@ def test_v5_two_phase_local_then_remote_merge(mfma):
     got = emu.bf16_to_f32(o2[:, pb.head * 128:(pb.head + 1) * 128].astype(np.uint32))
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 6e-3     # the partial O passes through bf16 once more
     assert np.abs(lse2 - lse_want).max() < 2e-2
+    # the earlier launch's result fetched as whole rows through the strip (cfg merge_rows) or lane by lane: the same bits,
+    # and the other head's columns of the output rows stay untouched
+    o2b, lse2b, _ = launch(pb, skip=loc, lse_in=lse1, lse_out=True, o_init=o1, dma_late=True, load_late=True,
+                           cfg={"mfma": mfma, "merge_rows": 0})
+    assert np.array_equal(o2, o2b) and np.array_equal(lse2, lse2b)
+    other = [c for c in range(o2.shape[1]) if not pb.head * 128 <= c < (pb.head + 1) * 128]
+    assert np.array_equal(o2[:, other], o1[:, other])
 
 
 S_SAFE = gen.S_SAFE
