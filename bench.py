@@ -287,7 +287,7 @@ def bench_main():
     ap.add_argument("--no_nocache", action="store_true", help="skip the second (cache off) timed region")
     ap.add_argument("--fp8_linear", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2, 3),
                     help="OPTIONAL precision mode, never the headline: QKV / FFN Linears on an fp8 e4m3 MFMA path "
-                         "(1: per-row / per-channel scales, 2: MX block scales)")
+                         "(1: per-row / per-channel scales, 2: MX block scales, 3: MX for the d x d Linears of a block too)")
     ap.add_argument("--layout", choices=("auto", "sp", "cfg2sp"), default="auto",
                     help="N > 1: 'sp' = the token sequence sharded over all N ranks, one K/V all-gather per layer "
                          "(north_star's split); 'cfg2sp' = CFG branches on two halves of the node x sequence parallel "
