@@ -772,8 +772,9 @@ static mc_status gemm_fp8_rows(mc_engine* e, const bf16_t* A, long lda, int M, i
   return MC_OK;
 }
 
-// LayerNorm + modulate whose consumer is an fp8 GEMM: with fp8_fused_quant the row goes straight to "aq" (+ scales) and
-// the function returns true; otherwise the bf16 row goes to "xn" as ever and the GEMM wrapper quantises it.
+// LayerNorm + modulate whose consumer may be an fp8 GEMM: with fp8_fused_quant the row goes straight to "aq" (+ scales) and
+// *fused is set (the GEMM wrapper is then called with A == nullptr); otherwise the bf16 row goes to "xn" as ever and the
+// GEMM wrapper quantises it.
 static mc_status ln_for_gemm(mc_engine* e, bool fp8_consumer, bool mx, const float* x, const float* sc, const float* sh,
                              int mode, const float* sc2, const float* sh2, const uint8_t* sel, hipStream_t s, bool* fused) {
   const int d = e->d, Lp = e->Lp;
