@@ -170,12 +170,32 @@ mc_status mc_set_vace_context(mc_engine* e, const float* vace_dev, float context
  * record of what was found. */
 mc_status mc_set_token_timesteps(mc_engine* e, const float* t_tokens_dev, mc_stream stream);
 
-/* Measurement hook: with profiling on, every SELF-attention launch of a forward is bracketed by a hipEvent pair on the
- * launch stream (sequence parallel: the local-shard and the remote-shards launch of a layer each; up to 8192 launches
- * between reads); mc_profile_read waits for them, returns the summed kernel time
- * and the launch count, and clears the log.  bench.py uses it for roofline.achieved over its timed region. */
-mc_status mc_profile_enable(mc_engine* e, int on);
+/* Measurement hook: hipEvent pairs on the launch stream around the launches of a forward, summed per class.
+ * mc_profile_enable(e, 1): every SELF-attention launch (sequence parallel: the local-shard and the remote-shards launch of a
+ * layer each) -- what bench.py's timed no-cache region carries for roofline.achieved.  (e, 2): every class below (a class
+ * that is several launches -- the two RMSNorm + RoPE launches of q and k, the fp8 quantise + GEMM pair, the embeds, the
+ * head -- is one pair around all of them); used by bench.py's separate "kernels_live" region.  (e, 0): off.  Up to 8192
+ * pairs between reads; further launches are not logged.  mc_profile_read_classes waits for the logged pairs, returns
+ * summed milliseconds and pair counts per class and clears the log; mc_profile_read is the self-attention class alone. */
+typedef enum {
+  MC_PROF_ATTN_SELF = 0,
+  MC_PROF_ATTN_CROSS = 1,
+  MC_PROF_GEMM_QKV = 2,     /* q | k | v Linear (bf16 store) */
+  MC_PROF_GEMM_O = 3,       /* self-attention o Linear, x += gate * o (fp32 read-modify-write) */
+  MC_PROF_GEMM_CROSS_Q = 4,
+  MC_PROF_GEMM_CROSS_O = 5, /* cross-attention o Linear, x += o */
+  MC_PROF_GEMM_FFN1 = 6,    /* Linear + GELU(tanh) */
+  MC_PROF_GEMM_FFN2 = 7,    /* Linear, x += gate * y (+ the MagCache residual capture on the last layer) */
+  MC_PROF_LN_MODULATE = 8,  /* the three LayerNorm (+ modulate) launches of a block */
+  MC_PROF_RMSNORM_ROPE = 9,
+  MC_PROF_EMBED = 10,       /* patch / time / text embeds of a forward */
+  MC_PROF_HEAD = 11,        /* head LayerNorm (+ the skip add) + Linear + unpatchify */
+  MC_PROF_OTHER = 12,       /* uncached text K|V, I2V image branch, calibration statistics */
+  MC_PROF_NCLASS = 13
+} mc_prof_class;
+mc_status mc_profile_enable(mc_engine* e, int level);
 mc_status mc_profile_read(mc_engine* e, double* attn_ms_total, int* attn_launches);
+mc_status mc_profile_read_classes(mc_engine* e, double ms_total[MC_PROF_NCLASS], int launches[MC_PROF_NCLASS]);
 
 /* ---- the same forward in phases (sequence parallel: the caller runs the K/V all-gather between
  * pre_attn and post_attn of every layer with its own communicator, e.g. torch.distributed/RCCL) */
@@ -187,6 +207,18 @@ mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream);  /* LN+m
  * layer then attends the remaining shards only and merges both parts (log-sum-exp weights) */
 mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream);
 mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream);
+/* The same layer loop in ONE call (sp_size > 1): for every layer in [layer_begin, layer_end) the engine runs pre_attn, calls
+ * gather(user, layer, 0, stream) -- the caller STARTS the all-gather of "kv_gather" on its own communicator, ordered behind
+ * the work `stream` already holds --, runs the local-shard attention beside it, calls gather(user, layer, 1, stream) -- the
+ * caller makes `stream` wait for that gather, no host sync; with overlap == 0 this call comes before the local-shard
+ * attention, so that nothing runs beside the collective --, then post_attn; a VACE control block follows
+ * its main layer in the same two phases with its own gather.  The callback returns 0 on success; anything else aborts the
+ * loop with MC_ESTATE.  Replaces 3 calls per layer (5 with VACE) by two re-entries for the collective; a C / C++ host
+ * calls ncclAllGather + hipStreamWaitEvent in the callback, the Python shim torch.distributed (magcache_amd/parallel.py).
+ * Reference counterpart: the USP flags of MagCache4Wan2.1/magcache_generate.py:813-829,891 (xfuser). */
+typedef int (*mc_sp_gather_fn)(void* user, int layer, int phase, mc_stream stream);
+mc_status mc_blocks_sp(mc_engine* e, int layer_begin, int layer_end, int branch, mc_mode mode, int overlap,
+                       mc_sp_gather_fn gather, void* user, mc_stream stream);
 /* VACE under sequence parallelism: control block i in the same two phases (K/V all-gather between them); call them
  * after mc_block_post_attn of main layer i * vace_stride, vace_block_post adds the hint to the main stream */
 mc_status mc_vace_block_pre(mc_engine* e, int i, mc_stream stream);
@@ -246,6 +278,9 @@ mc_status mc_op_gemm_bf16(const void* A_dev, long lda, const void* W_dev, long l
                           int N, int K, int epi, void* Cb_dev, long ldc, float* X_dev, long ldx,
                           const float* gate_dev, const void* X0_dev, long ldx0, float* R_dev, long ldr,
                           void* X0out_dev, long ldx0out, int m_valid, mc_stream stream);
+/* which kernel mc_op_gemm_bf16 (and the engine) runs for this problem under the current "gemm_kernel" option: 1 = the 128x128
+ * kernel, 2 = the 8-wave 256x256 kernel, 4 = gemm_bf16_v2; 0 = the shape is rejected.  (lda = ldw = K, ldc / ldx = N.) */
+int mc_op_gemm_bf16_kernel(int M, int N, int K, int epi);
 /* fp8 path (OCP e4m3, v_mfma_f32_32x32x64_f8f6f4): row-wise quantisation q = e4m3(x / s), s = max|row| / 448, and
  * C = (A_q W_q^T) * a_scale[m] * w_scale[n] + bias with the bf16 / gelu / residual-gate / fp32 epilogues */
 mc_status mc_op_quantize_rows_fp8(const void* x_dev, mc_dtype dtype, long ldx, int M, int K, void* q_dev, long ldq,

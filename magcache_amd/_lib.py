@@ -15,6 +15,9 @@ LIB_PATH = os.environ.get("MAGCACHE_HIP_LIB", LIB_PATH)
 MC_OK, MC_EINVAL, MC_ENOMEM, MC_EHIP, MC_ESTATE = 0, 1, 2, 3, 4
 MC_F32, MC_BF16 = 0, 1
 MC_MODE_FULL, MC_MODE_SKIP, MC_MODE_CALIB = 0, 1, 2
+# mc_prof_class, in enum order (include/magcache_hip.h)
+PROF_CLASSES = ("attn_self", "attn_cross", "gemm_qkv", "gemm_o", "gemm_cross_q", "gemm_cross_o", "gemm_ffn1", "gemm_ffn2",
+                "ln_modulate", "rmsnorm_rope", "embed", "head", "other")
 RULE_VARIANTS = {"wan21": 0, "hunyuan": 1, "flux": 2, "wan22_t2v": 3, "wan22_i2v": 4, "wan22_ti2v": 5, "framepack": 6,
                  "omnigen2": 7, "qwen": 8, "eval_wan": 9, "eval_opensora": 10}
 
@@ -35,6 +38,8 @@ class MagCacheHipError(RuntimeError):
 
 
 _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
+# mc_sp_gather_fn: int (*)(void* user, int layer, int phase, mc_stream stream)
+SP_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol include/magcache_hip.h declares
 SIGNATURES = {
@@ -56,10 +61,12 @@ SIGNATURES = {
     "mc_use_context": (_i, [_vp, _i]),
     "mc_profile_enable": (_i, [_vp, _i]),
     "mc_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
+    "mc_profile_read_classes": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
     "mc_embed": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _vp]),
     "mc_block_pre_attn": (_i, [_vp, _i, _vp]),
     "mc_block_attn_local": (_i, [_vp, _i, _vp]),
     "mc_block_post_attn": (_i, [_vp, _i, _i, _i, _vp]),
+    "mc_blocks_sp": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mc_vace_block_pre": (_i, [_vp, _i, _vp]),
     "mc_vace_block_post": (_i, [_vp, _i, _i, _i, _vp]),
     "mc_head": (_i, [_vp, _i, _i, _vp]),
@@ -76,6 +83,7 @@ SIGNATURES = {
     "mc_nearest_interp": (None, [C.POINTER(_d), _i, C.POINTER(_d), _i]),
     "mc_op_gemm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l,
                              _i, _vp]),
+    "mc_op_gemm_bf16_kernel": (_i, [_i, _i, _i, _i]),
     "mc_op_attention": (_i, [_vp, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
     "mc_op_quantize_rows_fp8": (_i, [_vp, _i, _l, _i, _i, _vp, _l, _vp, _vp]),
     "mc_op_gemm_fp8": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),

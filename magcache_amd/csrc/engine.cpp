@@ -98,9 +98,11 @@ struct mc_engine {
   int ctx_active = -1;
   const float* tok_t = nullptr;  // Wan2.2 TI2V: per-token timesteps of the next forwards (mc_set_token_timesteps)
   int HT = 64;                   // row stride of "head_tokens": 4*out_dim rounded up to 64
-  // optional in-stream timing of the dominant kernel (self-attention): hipEvent pairs around every launch
-  bool profile = false;
+  // optional in-stream timing: hipEvent pairs around the launches of a forward, tagged with a class (mc_prof_class).
+  // level 1 = the dominant kernel only (self-attention), level 2 = every launch of a block + embed / head
+  int profile = 0;
   std::vector<hipEvent_t> prof_ev;
+  std::vector<uint8_t> prof_cls;   // class of pair i (events 2 i, 2 i + 1)
   size_t prof_n = 0;  // events used
   // VACE (upstream wan/modules/vace_model.py VaceWanModel): n_vace extra blocks on a control stream c; block i feeds
   // main layer i * vace_stride through after_proj ("hint")
@@ -136,6 +138,30 @@ struct mc_engine {
 };
 
 namespace {
+
+// Measurement hook (mc_profile_enable): one hipEvent pair on the launch stream around the launches of the enclosing
+// scope, tagged with its class.  Level 1 brackets the self-attention launches only (what bench.py's timed region carries),
+// level 2 every class.  The pair is reserved at construction, so scopes may nest.  A failed record is not an error of
+// the forward: the pair is dropped from the log.
+struct Prof {
+  mc_engine* e;
+  hipStream_t s;
+  size_t idx = 0;
+  bool on = false;
+  Prof(mc_engine* e_, int cls, hipStream_t s_) : e(e_), s(s_) {
+    if (!e->profile || (e->profile < 2 && cls != MC_PROF_ATTN_SELF) || e->prof_n + 2 > e->prof_ev.size()) return;
+    idx = e->prof_n;
+    if (hipEventRecord(e->prof_ev[idx], s) != hipSuccess) return;
+    e->prof_cls[idx / 2] = (uint8_t)cls;
+    e->prof_n += 2;
+    on = true;
+  }
+  ~Prof() {
+    if (on && hipEventRecord(e->prof_ev[idx + 1], s) != hipSuccess) e->prof_cls[idx / 2] = 0xff;
+  }
+  Prof(const Prof&) = delete;
+  Prof& operator=(const Prof&) = delete;
+};
 
 template <class T>
 mc_status dev_alloc(mc_engine* e, T** p, size_t n) {
@@ -697,6 +723,7 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
   if (c.clip_dim > 0 && !e->have_clip)
     return fail(MC_ESTATE, "i2v model: mc_set_clip_fea must run before the forward (reference assert :226-227)");
   const int d = e->d;
+  Prof pr(e, MC_PROF_EMBED, s);
   // x = patch_embedding(latent): im2col -> GEMM, x (fp32) and ori_x (bf16), zero rows past seq_len
   bf16_t* tokens = e->buf<bf16_t>("tokens");
   if (e->Kp != c.in_dim * 4) HIP_TRY(hipMemsetAsync(tokens, 0, (size_t)e->Lp * e->Kp * 2, s));
@@ -806,6 +833,7 @@ static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float*
   const uint8_t* sel = tok_sel(e);
   bool fused = false;
   {
+    Prof pr(e, MC_PROF_LN_MODULATE, s);
     mc_status st = ln_for_gemm(e, e->P == 1 && l.q_wqkv, l.m_wqkv != nullptr, x, em + d, em, 0, em2 ? em2 + d : nullptr, em2,
                                sel, s, &fused);
     if (st != MC_OK) return st;
@@ -813,23 +841,31 @@ static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float*
   if (e->P == 1) {
     mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
-    if (l.q_wqkv) {
-      mc_status st = gemm_fp8_rows(e, fused ? nullptr : xn, d, Lp, d, l.q_wqkv, l.s_wqkv, l.m_wqkv, p, mc::EPI_BF16, s);
-      if (st != MC_OK) return st;
-    } else {
-      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    {
+      Prof pr(e, MC_PROF_GEMM_QKV, s);
+      if (l.q_wqkv) {
+        mc_status st = gemm_fp8_rows(e, fused ? nullptr : xn, d, Lp, d, l.q_wqkv, l.s_wqkv, l.m_wqkv, p, mc::EPI_BF16, s);
+        if (st != MC_OK) return st;
+      } else {
+        HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+      }
     }
+    Prof pr(e, MC_PROF_RMSNORM_ROPE, s);
     HIP_TRY(mc::launch_rmsnorm_rope(qkv, 3 * d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
     HIP_TRY(mc::launch_rmsnorm_rope(qkv + d, 3 * d, l.nk, e->cfg.eps, e->cs_table, 0, Lp, d, s));
   } else {
     // q -> qkv[:, :d] (ld d) ; [k|v] -> this rank's rows of the gather buffer (ld 2d)
     bf16_t* kvl = e->buf<bf16_t>("kv_local");
-    mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, d, d);
-    p.Cb = qkv; p.ldc = d;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
-    mc::GemmParams q = gp(xn, d, l.wqkv + (size_t)d * d, d, l.bqkv + d, Lp, 2 * d, d);
-    q.Cb = kvl; q.ldc = 2 * d;
-    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+    {
+      Prof pr(e, MC_PROF_GEMM_QKV, s);
+      mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, d, d);
+      p.Cb = qkv; p.ldc = d;
+      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+      mc::GemmParams q = gp(xn, d, l.wqkv + (size_t)d * d, d, l.bqkv + d, Lp, 2 * d, d);
+      q.Cb = kvl; q.ldc = 2 * d;
+      HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+    }
+    Prof pr(e, MC_PROF_RMSNORM_ROPE, s);
     HIP_TRY(mc::launch_rmsnorm_rope(qkv, d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
     HIP_TRY(mc::launch_rmsnorm_rope(kvl, 2 * d, l.nk, e->cfg.eps, e->cs_table, 0, Lp, d, s));
   }
@@ -859,12 +895,9 @@ mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream_) {
   a.K = kvl; a.ldk = 2 * d; a.V = kvl + d; a.ldv = 2 * d;
   a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
   a.lse_out = e->buf<float>("attn_lse");
-  const bool prof = e->profile && e->prof_n + 2 <= e->prof_ev.size();   // measurement hook, see mc_profile_enable
-  if (prof) HIP_TRY(hipEventRecord(e->prof_ev[e->prof_n], s));
-  HIP_TRY(mc::launch_attention(a, s));
-  if (prof) {
-    HIP_TRY(hipEventRecord(e->prof_ev[e->prof_n + 1], s));
-    e->prof_n += 2;
+  {
+    Prof pr(e, MC_PROF_ATTN_SELF, s);   // measurement hook, see mc_profile_enable
+    HIP_TRY(mc::launch_attention(a, s));
   }
   e->local_attn_layer = layer;
   return MC_OK;
@@ -905,15 +938,11 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
       }
       e->local_attn_layer = -1;
     }
-    const bool prof = e->profile && e->prof_n + 2 <= e->prof_ev.size();
-    if (prof) HIP_TRY(hipEventRecord(e->prof_ev[e->prof_n], s));
+    Prof pr(e, MC_PROF_ATTN_SELF, s);
     HIP_TRY(mc::launch_attention(a, s));
-    if (prof) {
-      HIP_TRY(hipEventRecord(e->prof_ev[e->prof_n + 1], s));
-      e->prof_n += 2;
-    }
   }
   {  // x = x + o(attn) * e[2]
+    Prof pr(e, MC_PROF_GEMM_O, s);
     mc::GemmParams p = gp(ao, d, l.wo, d, l.bo, Lp, d, d);
     p.X = x; p.ldx = d; p.gate = em + 2 * d;
     if (em2) { p.gate2 = em2 + 2 * d; p.gate_sel = sel; }
@@ -927,6 +956,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
   // ---- cross attention: x = x + o(attn(norm_q(q(norm3(x))), norm_k(k(ctx)), v(ctx)))
   bool fused_cq = false;
   {
+    Prof pr(e, MC_PROF_LN_MODULATE, s);
     mc_status st = ln_for_gemm(e, l.q_wcq != nullptr, true, x, l.n3w, l.n3b, 1, nullptr, nullptr, nullptr, s, &fused_cq);
     if (st != MC_OK) return st;
   }
@@ -935,18 +965,25 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
   {
     mc::GemmParams p = gp(xn, d, l.wcq, d, l.bcq, Lp, d, d);
     p.Cb = cq; p.ldc = d;
-    if (l.q_wcq) {
-      mc_status st = gemm_fp8_rows(e, fused_cq ? nullptr : xn, d, Lp, d, l.q_wcq, nullptr, l.m_wcq, p, mc::EPI_BF16, s);
-      if (st != MC_OK) return st;
-    } else {
-      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    {
+      Prof pr(e, MC_PROF_GEMM_CROSS_Q, s);
+      if (l.q_wcq) {
+        mc_status st = gemm_fp8_rows(e, fused_cq ? nullptr : xn, d, Lp, d, l.q_wcq, nullptr, l.m_wcq, p, mc::EPI_BF16, s);
+        if (st != MC_OK) return st;
+      } else {
+        HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+      }
     }
-    HIP_TRY(mc::launch_rmsnorm_rope(cq, d, l.cnq, e->cfg.eps, nullptr, 0, Lp, d, s));
+    {
+      Prof pr(e, MC_PROF_RMSNORM_ROPE, s);
+      HIP_TRY(mc::launch_rmsnorm_rope(cq, d, l.cnq, e->cfg.eps, nullptr, 0, Lp, d, s));
+    }
     if (e->ctx_active >= 0) {
       // constant over a video for this context: computed once by mc_set_context
       const size_t li = (size_t)(&l - (layer >= 0 ? e->layers.data() : e->vlayers.data())) + (layer >= 0 ? 0 : e->NL);
       ckv = e->buf<bf16_t>("ckv_cache") + ((size_t)e->ctx_active * (e->NL + e->NV) + li) * e->ctx_rows * 2 * d;
     } else {
+      Prof pr(e, MC_PROF_OTHER, s);
       mc_status kst = context_kv(e, l, e->buf<bf16_t>("ctx"), ckv, s);
       if (kst != MC_OK) return kst;
     }
@@ -955,8 +992,12 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     a.Q = cq; a.ldq = d; a.K = ckv; a.ldk = 2 * d; a.V = ckv + d; a.ldv = 2 * d;
     a.O = ao; a.ldo = d; a.Lq_pad = Lp; a.n_heads = e->H; a.scale = scale;
     a.shard_rows = e->ctx_rows; a.shard_valid = e->cfg.text_len; a.n_shards = 1;
-    HIP_TRY(mc::launch_attention(a, s));
+    {
+      Prof pr(e, MC_PROF_ATTN_CROSS, s);
+      HIP_TRY(mc::launch_attention(a, s));
+    }
     if (e->cfg.clip_dim > 0) {
+      Prof pr(e, MC_PROF_OTHER, s);
       // I2V (upstream WanI2VCrossAttention): + attention over the 257 CLIP image tokens with their own k/v
       bf16_t* ckvi = e->buf<bf16_t>("ckv_img");
       bf16_t* ao2 = e->buf<bf16_t>("ao2");
@@ -970,6 +1011,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
       HIP_TRY(mc::launch_attention(ai, s));
       HIP_TRY(mc::launch_add_bf16(ao, ao2, (size_t)Lp * d, s));
     }
+    Prof pr(e, MC_PROF_GEMM_CROSS_O, s);
     mc::GemmParams o = gp(ao, d, l.wco, d, l.bco, Lp, d, d);
     o.X = x; o.ldx = d; o.gate = nullptr;
     if (l.q_wco) {
@@ -982,6 +1024,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
   // ---- FFN: x = x + ffn(LN(x)*(1+e[4])+e[3]) * e[5]
   bool fused_ffn = false;
   {
+    Prof pr(e, MC_PROF_LN_MODULATE, s);
     mc_status st = ln_for_gemm(e, l.q_w1 != nullptr, l.m_w1 != nullptr, x, em + 4 * d, em + 3 * d, 0,
                                em2 ? em2 + 4 * d : nullptr, em2 ? em2 + 3 * d : nullptr, sel, s, &fused_ffn);
     if (st != MC_OK) return st;
@@ -995,19 +1038,23 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     const bool h_fp8 = l.m_w1 && l.m_w2 && g_fp8_fused_quant;
     uint8_t* hq = (uint8_t*)h;
     uint8_t* hmx = hq + (size_t)Lp * ffn;
-    if (l.q_w1) {
-      if (h_fp8) { p.Cq = hq; p.ldcq = ffn; p.c_mx = hmx; p.mx_rows_c = Lp; }
-      mc_status st = gemm_fp8_rows(e, fused_ffn ? nullptr : xn, d, Lp, d, l.q_w1, l.s_w1, l.m_w1, p,
-                                   h_fp8 ? mc::EPI_GELU_MXFP8 : mc::EPI_GELU_BF16, s);
-      if (st != MC_OK) return st;
-    } else {
-      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
+    {
+      Prof pr(e, MC_PROF_GEMM_FFN1, s);
+      if (l.q_w1) {
+        if (h_fp8) { p.Cq = hq; p.ldcq = ffn; p.c_mx = hmx; p.mx_rows_c = Lp; }
+        mc_status st = gemm_fp8_rows(e, fused_ffn ? nullptr : xn, d, Lp, d, l.q_w1, l.s_w1, l.m_w1, p,
+                                     h_fp8 ? mc::EPI_GELU_MXFP8 : mc::EPI_GELU_BF16, s);
+        if (st != MC_OK) return st;
+      } else {
+        HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_GELU_BF16, s));
+      }
     }
     mc::GemmParams q = gp(h, ffn, l.w2, ffn, l.b2, Lp, d, ffn);
     q.X = x; q.ldx = d; q.gate = em + 5 * d;
     if (em2) { q.gate2 = em2 + 5 * d; q.gate_sel = sel; }
     const bool f8 = l.q_w2 != nullptr;
     auto ffn2 = [&](int epi) -> mc_status {
+      Prof pr(e, MC_PROF_GEMM_FFN2, s);
       if (f8 && h_fp8) return gemm_fp8_rows(e, nullptr, ffn, Lp, ffn, l.q_w2, l.s_w2, l.m_w2, q, epi, s, hq, hmx);
       if (f8) return gemm_fp8_rows(e, h, ffn, Lp, ffn, l.q_w2, l.s_w2, l.m_w2, q, epi, s);
       HIP_TRY(mc::launch_gemm_bf16(q, epi, s));
@@ -1025,6 +1072,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
       if (mode == MC_MODE_CALIB) {
         if (!e->cfg.calibration) return fail(MC_ESTATE, "engine was created without calibration=1");
         if (e->have_res[branch]) {
+          Prof pr(e, MC_PROF_OTHER, s);
           HIP_TRY(mc::launch_calib_stats(e->residual(dst), d, e->residual(e->res_slot[branch]), d, e->Lr, d,
                                          e->buf<double>("calib_partial"), 2048, e->buf<double>("calib_sums"),
                                          e->buf<float>("calib_stats") + 3 * branch, s));
@@ -1108,6 +1156,45 @@ mc_status mc_vace_block_post(mc_engine* e, int i, int branch, mc_mode mode, mc_s
   return vace_post(e, i, branch, mode, (hipStream_t)stream);
 }
 
+// Sequence parallel, the layer loop in ONE call: for every layer in [layer_begin, layer_end)
+//   pre_attn -> gather(user, layer, 0)  [the caller STARTS its all-gather of "kv_gather", ordered behind what `stream` holds]
+//            -> attn_local              [this rank's shard, beside the gather]
+//            -> gather(user, layer, 1)  [the caller makes `stream` wait for the gather: no host sync; overlap == 0: this
+//                                        call comes BEFORE attn_local, nothing runs beside the collective]
+//            -> post_attn (+ the VACE control block of that layer in the same two phases, with its own gather)
+// i.e. exactly the sequence parallel.py issued phase by phase (mc_block_pre_attn / _attn_local / _post_attn stay exported:
+// same code underneath).  The host is re-entered only for the collective, twice per layer.
+mc_status mc_blocks_sp(mc_engine* e, int layer_begin, int layer_end, int branch, mc_mode mode, int overlap,
+                       mc_sp_gather_fn gather, void* user, mc_stream stream) {
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (!gather) return fail(MC_EINVAL, "null gather callback");
+  if (e->P < 2) return fail(MC_ESTATE, "mc_blocks_sp needs sp_size > 1 (one GPU: mc_forward)");
+  if (layer_begin < 0 || layer_end > e->NL || layer_begin > layer_end)
+    return fail(MC_EINVAL, "layers [%d, %d) out of range (num_layers %d)", layer_begin, layer_end, e->NL);
+  if (mode == MC_MODE_SKIP) return fail(MC_EINVAL, "a skipped forward runs no blocks (mc_embed -> mc_head)");
+  auto coll = [&](int layer, int phase) -> mc_status {
+    const int rc = gather(user, layer, phase, stream);
+    return rc == 0 ? MC_OK : fail(MC_ESTATE, "gather callback failed (layer %d, phase %d, code %d)", layer, phase, rc);
+  };
+  for (int l = layer_begin; l < layer_end; ++l) {
+    mc_status st = mc_block_pre_attn(e, l, stream);
+    if (st != MC_OK) return st;
+    if ((st = coll(l, 0)) != MC_OK) return st;
+    if (!overlap && (st = coll(l, 1)) != MC_OK) return st;     // serialised: nothing runs beside the collective
+    if ((st = mc_block_attn_local(e, l, stream)) != MC_OK) return st;
+    if (overlap && (st = coll(l, 1)) != MC_OK) return st;
+    if ((st = mc_block_post_attn(e, l, branch, mode, stream)) != MC_OK) return st;
+    if (e->NV > 0 && l % e->cfg.vace_stride == 0 && l / e->cfg.vace_stride < e->NV) {
+      const int i = l / e->cfg.vace_stride;
+      if ((st = mc_vace_block_pre(e, i, stream)) != MC_OK) return st;
+      if ((st = coll(l, 0)) != MC_OK) return st;
+      if ((st = coll(l, 1)) != MC_OK) return st;
+      if ((st = mc_vace_block_post(e, i, branch, mode, stream)) != MC_OK) return st;
+    }
+  }
+  return MC_OK;
+}
+
 // residual capture + calibration statistics as separate kernels (only when the last layer carries a VACE hint)
 static mc_status capture_unfused(mc_engine* e, int branch, mc_mode mode, hipStream_t s) {
   const int d = e->d;
@@ -1139,6 +1226,7 @@ mc_status mc_head(mc_engine* e, int branch, mc_mode mode, mc_stream stream_) {
   const float* eh2 = e->tok_t ? eh + 2 * d : nullptr;
   const uint8_t* sel = tok_sel(e);
   float* hn = e->buf<float>("h");
+  Prof pr(e, MC_PROF_HEAD, s);
   if (mode == MC_MODE_SKIP) {
     // skipped step: x = ori_x + residual_cache[branch] (:294-295), folded into the LayerNorm load
     if (!e->have_res[branch]) return fail(MC_ESTATE, "skip requested but residual_cache[%d] is empty", branch);
@@ -1158,6 +1246,7 @@ mc_status mc_unpatchify(mc_engine* e, const float* tokens_dev, int tok0, int n_t
   if (!e || !tokens_dev || !out_dev) return fail(MC_EINVAL, "null argument");
   if (tok0 < 0 || n_tok <= 0 || tok0 + n_tok > e->L) return fail(MC_EINVAL, "token range out of bounds");
   const mc_config& c = e->cfg;
+  Prof pr(e, MC_PROF_HEAD, (hipStream_t)stream_);
   HIP_TRY(mc::launch_unpatchify(tokens_dev, e->HT, c.out_dim, c.latent_f, c.latent_h, c.latent_w, tok0, n_tok, out_dev,
                                 (hipStream_t)stream_));
   return MC_OK;
@@ -1261,27 +1350,43 @@ mc_status mc_set_token_timesteps(mc_engine* e, const float* t_tokens_dev, mc_str
 
 mc_status mc_profile_enable(mc_engine* e, int on) {
   if (!e) return fail(MC_EINVAL, "null engine");
+  if (on < 0 || on > 2) return fail(MC_EINVAL, "profile level %d (0 off, 1 self-attention, 2 every class)", on);
   if (on && e->prof_ev.empty()) {
     e->prof_ev.resize(2 * 8192);
+    e->prof_cls.assign(8192, 0);
     for (auto& ev : e->prof_ev) HIP_TRY(hipEventCreate(&ev));
   }
-  e->profile = on != 0;
+  e->profile = on;
   e->prof_n = 0;
+  return MC_OK;
+}
+
+// waits for the logged pairs and sums them by class; clears the log
+mc_status mc_profile_read_classes(mc_engine* e, double ms_total[MC_PROF_NCLASS], int launches[MC_PROF_NCLASS]) {
+  if (!e || !ms_total || !launches) return fail(MC_EINVAL, "null argument");
+  for (int c = 0; c < MC_PROF_NCLASS; ++c) { ms_total[c] = 0.0; launches[c] = 0; }
+  const size_t n = e->prof_n;
+  e->prof_n = 0;
+  for (size_t i = 0; i + 1 < n; i += 2) {
+    const int c = e->prof_cls[i / 2];
+    if (c >= MC_PROF_NCLASS) continue;       // a pair whose second record failed
+    HIP_TRY(hipEventSynchronize(e->prof_ev[i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]));
+    ms_total[c] += ms;
+    launches[c] += 1;
+  }
   return MC_OK;
 }
 
 mc_status mc_profile_read(mc_engine* e, double* attn_ms_total, int* attn_launches) {
   if (!e || !attn_ms_total || !attn_launches) return fail(MC_EINVAL, "null argument");
-  double tot = 0.0;
-  for (size_t i = 0; i + 1 < e->prof_n; i += 2) {
-    HIP_TRY(hipEventSynchronize(e->prof_ev[i + 1]));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]));
-    tot += ms;
-  }
-  *attn_ms_total = tot;
-  *attn_launches = (int)(e->prof_n / 2);
-  e->prof_n = 0;
+  double ms[MC_PROF_NCLASS];
+  int n[MC_PROF_NCLASS];
+  mc_status st = mc_profile_read_classes(e, ms, n);
+  if (st != MC_OK) return st;
+  *attn_ms_total = ms[MC_PROF_ATTN_SELF];
+  *attn_launches = n[MC_PROF_ATTN_SELF];
   return MC_OK;
 }
 
@@ -1304,6 +1409,13 @@ mc_status mc_op_gemm_bf16(const void* A, long lda, const void* W, long ldw, cons
   if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "gemm: unsupported shape M=%d N=%d K=%d epi=%d", M, N, K, epi);
   HIP_TRY(err);
   return MC_OK;
+}
+
+int mc_op_gemm_bf16_kernel(int M, int N, int K, int epi) {
+  mc::GemmParams p = gp(nullptr, K, nullptr, K, nullptr, M, N, K);
+  p.ldc = N; p.ldx = N;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0) return 0;
+  return mc::gemm_bf16_kernel_for(p, epi);
 }
 
 mc_status mc_op_attention(const void* Q, long ldq, const void* K, long ldk, long kss, const void* V, long ldv,

@@ -238,7 +238,8 @@ static bool prefer_256(const GemmParams& p) {
   return t256 <= t128;
 }
 
-hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+// 1 = the 128x128 kernel, 2 = the 8-wave 256x256 kernel, 4 = gemm_bf16_v2
+int gemm_bf16_kernel_for(const GemmParams& p, int epi) {
   bool big = false;
   if (g_gemm_kernel != 1 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
       gemm_bf16_big_supported(p)) {
@@ -256,8 +257,16 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
   if (gemm_bf16_v2_supported(p) &&
       ((g_gemm_kernel == 0 && big && v2_epi) ||
        (g_gemm_kernel == 4 && (v2_epi || epi == EPI_RESID_CAPTURE || epi == EPI_F32))))
-    return launch_gemm_bf16_v2(p, epi, stream);
-  return big ? launch_gemm_bf16_big(p, epi, stream) : launch_gemm_bf16_small(p, epi, stream);
+    return 4;
+  return big ? 2 : 1;
+}
+
+hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+  switch (gemm_bf16_kernel_for(p, epi)) {
+    case 4: return launch_gemm_bf16_v2(p, epi, stream);
+    case 2: return launch_gemm_bf16_big(p, epi, stream);
+    default: return launch_gemm_bf16_small(p, epi, stream);
+  }
 }
 
 }  // namespace mc

@@ -40,18 +40,10 @@
 #ifndef MC_GEMM_V2_DEFER
 #define MC_GEMM_V2_DEFER 0
 #endif
-#ifndef MC_V2_EPI_ABL      // timing ablations of the epilogues (tools/build_gemm_v2_variants.py ...,epiabl=N; results WRONG):
-#define MC_V2_EPI_ABL 0    // 1 no stores (bf16 forms), 3 no x stores, 4 no x loads (residual form, not deferred)
-#endif
-#ifndef MC_V2_DEFER_ABL
-#define MC_V2_DEFER_ABL 0
-#endif
-#ifndef MC_V2_RESID_SPLIT
-#define MC_V2_RESID_SPLIT 1   // residual epilogue: a lane's two x quads are 256 bytes apart (whole lines per instruction) instead of adjacent
-#endif
-#ifndef MC_V2_XAHEAD
-#define MC_V2_XAHEAD 1     // residual form, not deferred: m blocks of x loaded ahead (2, 3, 5 measured: no faster)
-#endif
+// (This translation unit carries no wrong-result switches.  The timing ablations of rounds 3-4 -- epilogue without its stores /
+// x loads / x stores, no epilogue at all, the deferred form without its in-loop work -- are source transforms applied by
+// tools/build_gemm_v2_variants.py to a COPY of this file when an A/B library is built: the lines tagged [abl:...] below are
+// their anchors.)
 
 namespace mc {
 
@@ -63,6 +55,10 @@ constexpr int TB = 256;
 constexpr int V2_RING_BYTES = 4 * 32768;     // the operand ring (two 64 KiB K tiles, or four 32 KiB sub-stages)
 constexpr int V2_STRIP_BYTES = 16 * 272;      // per wave: the epilogue's transposition strip (16 rows x 128 bf16, rows padded)
 constexpr int V2_LDS_BYTES = V2_RING_BYTES + 4 * V2_STRIP_BYTES;
+// gelu_tanh_fast2 (gemm_epilogue.h) uses packed-fp32 VALU instructions, which give wrong results beside ANOTHER kernel's MFMA
+// waves on the same CU (common.h, MC_NO_PK_F32; profiles/r04/NOTES.md 4).  This kernel may use them because nothing can be
+// co-resident with its workgroup: it takes more than half of the CU's 160 KiB of LDS (and all 512 registers of every SIMD).
+static_assert(V2_LDS_BYTES > 160 * 1024 / 2, "gemm_v2 must own its CU: its GELU epilogue uses packed fp32 (see MC_NO_PK_F32)");
 constexpr int V2_SCRATCH_ELEMS = TB * TB;     // per workgroup: the deferred epilogue's bf16 tile
 #ifndef MC_GEMM_V2_DEFER_PAIRS
 #define MC_GEMM_V2_DEFER_PAIRS 8
@@ -148,7 +144,6 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       rio = __builtin_amdgcn_make_buffer_rsrc((void*)scr, 0, TB * TB * 2, 0x00020000);
       vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 2u;
     } else if (EPI == EPI_RESID_GATE) {
-#if MC_V2_RESID_SPLIT
       // lane -> columns 4 c16 .. + 3 and 64 + 4 c16 .. + 3 of the wave's 128: every x load / store instruction then covers 256
       // CONTIGUOUS bytes of a row (two whole 128-byte lines), instead of 16 bytes out of every 32 over all four lines
       if (p.gate) {
@@ -159,16 +154,6 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       row_b = (uint32_t)p.ldx * 4u;
       rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (size_t)tm0 * p.ldx + tn0), 0, rows * row_b, 0x00020000);
       vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 4) * 4u;
-#else
-      if (p.gate) {
-        const float* gp = p.gate + tn0 + wc_ * 128 + c16 * 8;
-        gA = *(const f32x4*)gp;
-        gB = *(const f32x4*)(gp + 4);
-      }
-      row_b = (uint32_t)p.ldx * 4u;
-      rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (size_t)tm0 * p.ldx + tn0), 0, rows * row_b, 0x00020000);
-      vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 4u;
-#endif
     } else {
       row_b = (uint32_t)p.ldc * 2u;
       rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cb + (size_t)tm0 * p.ldc + tn0), 0, rows * row_b, 0x00020000);
@@ -177,19 +162,15 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     // (row offsets live in the VGPR offset, which the hardware range-checks together with the immediate: rows past M are
     // dropped.)  Residual form here: the 8 x loads of m block mb + XA are issued BEFORE m block mb is transposed and
     // applied, pinned by sched_barrier -- hipcc otherwise sinks every load to its use (one round trip per pair of loads).
-    constexpr int XA = MC_V2_XAHEAD, XS = XA + 1;
-    constexpr uint32_t X2_OFF = MC_V2_RESID_SPLIT ? 256u : 16u;   // byte distance of the lane's second quad of x
+    constexpr int XA = 1, XS = XA + 1;           // m blocks of x loaded ahead (2, 3, 5 measured: no faster)
+    constexpr uint32_t X2_OFF = 256u;            // byte distance of the lane's second quad of x
     f32x4 xin[XS][4][2];
     auto load_x = [&](int mb, int set) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
-#if MC_V2_EPI_ABL == 4
-        xin[set][i][0] = xin[set][i][1] = gA;
-#else
-        xin[set][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow, 0, 0));
-        xin[set][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow + X2_OFF, 0, 0));
-#endif
+        xin[set][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow, 0, 0));           // [abl:x_load]
+        xin[set][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow + X2_OFF, 0, 0));  // [abl:x_load]
       }
     };
     if (resid_here) {
@@ -215,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       u32x4 rowv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (MC_V2_RESID_SPLIT && resid_here) {   // bf16 columns 4 c16 .. + 3 | 64 + 4 c16 .. + 3 of the row
+        if (resid_here) {   // bf16 columns 4 c16 .. + 3 | 64 + 4 c16 .. + 3 of the row
           const u32x2 lo = *(const u32x2*)(strip + rr * 272 + c16 * 8 + i * (4 * 272));
           const u32x2 hi = *(const u32x2*)(strip + rr * 272 + 128 + c16 * 8 + i * (4 * 272));
           rowv[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -238,18 +219,10 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
           xb[1] += __uint_as_float(w[2] & 0xffff0000u) * gB[1];
           xb[2] += __uint_as_float(w[3] << 16) * gB[2];
           xb[3] += __uint_as_float(w[3] & 0xffff0000u) * gB[3];
-#if MC_V2_EPI_ABL == 3
-          asm volatile("" ::"v"(xa), "v"(xb));
-#else
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xa), rio, vrow, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb), rio, vrow + X2_OFF, 0, 0);
-#endif
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xa), rio, vrow, 0, 0);            // [abl:x_store]
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb), rio, vrow + X2_OFF, 0, 0);   // [abl:x_store]
         } else {
-#if MC_V2_EPI_ABL == 1
-          asm volatile("" ::"v"(rowv[i]));
-#else
-          __builtin_amdgcn_raw_buffer_store_b128(rowv[i], rio, vrow, 0, 0);
-#endif
+          __builtin_amdgcn_raw_buffer_store_b128(rowv[i], rio, vrow, 0, 0);   // [abl:c_store]
         }
       }
       if (resid_here) __builtin_amdgcn_sched_barrier(0);
@@ -404,11 +377,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     const uint32_t d_ldx_b = (uint32_t)p.ldx * 4u;
     const uint32_t d_xnrec = __builtin_amdgcn_readfirstlane(pend ? (uint32_t)min(p.M - pm0, TB) * d_ldx_b : 0u);
     const float* d_gate = p.gate ? p.gate + pn0 : nullptr;
-#if MC_V2_DEFER_ABL & 2     // timing ablation: no deferred work inside the main loop
-    const int d_on = 0;
-#else
-    const int d_on = __builtin_amdgcn_readfirstlane(pend ? 1 : 0);
-#endif
+    const int d_on = __builtin_amdgcn_readfirstlane(pend ? 1 : 0);   // [abl:defer_in_loop]
     asm volatile(
 #include MC_GEMM_V2_BODY
         : MC_V2_OUTS
@@ -434,9 +403,8 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     // two K tiles, have LANDED before this trip's epilogue issues its first load or store (they are ~1.5 K tiles old here)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-#ifndef MC_V2_NO_EPI   // (timing ablation, tools/build_gemm_v2_variants.py ...,noepi=1: nothing is written)
     const f32x32 cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
-    if constexpr (LEAN) {
+    if constexpr (LEAN) {   // [abl:epilogue_begin]
       lean_epilogue(cc, m0, n0, defer, scr);
       if (defer) {
         pend = true;
@@ -445,14 +413,9 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       }
     } else {
       generic_epilogue(cc);
-    }
-#else
-    if (p.M < 0) p.X[0] = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0];
-#endif
+    }   // [abl:epilogue_end]
   }   // tile loop
-#if !(MC_V2_DEFER_ABL & 1)   // (timing ablation 1: the last tile's update is dropped)
-  if (CAN_DEFER && pend) deferred_tail(pm0, pn0, scr);
-#endif
+  if (CAN_DEFER && pend) deferred_tail(pm0, pn0, scr);   // [abl:defer_tail]
   // the last trip's "next tile" fetches (zeros: num_records 0) still write the ring: they must not outlive the workgroup
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
@@ -468,11 +431,9 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       :
 #include MC_GEMM_V2_CLOBBERS
   );
-#ifndef MC_V2_NO_EPI
   const f32x32 cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
   if constexpr (LEAN) lean_epilogue(cc, m0, n0, false, nullptr);
   else generic_epilogue(cc);
-#endif
 #endif
 }
 

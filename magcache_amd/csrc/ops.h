@@ -51,6 +51,7 @@ struct GemmParams {
 };
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
+int gemm_bf16_kernel_for(const GemmParams& p, int epi);                               // ... this one: 1 small, 2 8-wave 256^2, 4 v2
 hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stream);  // 128x128 tiles
 hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);    // 256x256 tiles, 8 waves
 bool gemm_bf16_big_supported(const GemmParams& p);

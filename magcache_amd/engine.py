@@ -204,7 +204,8 @@ class Engine:
         return float(r[0]), float(r[1]), int(r[2])
 
     def profile(self, on=True):
-        """bracket every self-attention launch with hipEvents on the launch stream (see mc_profile_read)"""
+        """hipEvent pairs on the launch stream (mc_profile_enable): True / 1 = every self-attention launch, 2 = every launch
+        class of a forward (mc_prof_class), False / 0 = off"""
         check(self.lib.mc_profile_enable(self.h, int(on)))
 
     def profile_read(self):
@@ -212,6 +213,13 @@ class Engine:
         ms, n = C.c_double(), C.c_int()
         check(self.lib.mc_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_read_classes(self):
+        """{class name: (summed ms, event pairs)} since the last read (profile level 2)"""
+        from ._lib import PROF_CLASSES
+        ms, n = (C.c_double * len(PROF_CLASSES))(), (C.c_int * len(PROF_CLASSES))()
+        check(self.lib.mc_profile_read_classes(self.h, ms, n))
+        return {name: (ms[i], n[i]) for i, name in enumerate(PROF_CLASSES)}
 
     def set_vace_context(self, vace_context, scale=1.0):
         """Wan2.1 VACE: vace_context [96, F, H, W] (None: change the scale only) and vace_context_scale."""
@@ -278,6 +286,26 @@ class Engine:
 
     def block_post_attn(self, layer, branch, mode):
         check(self.lib.mc_block_post_attn(self.h, layer, branch, mode, _stream()))
+
+    def blocks_sp(self, layer_begin, layer_end, branch, mode, overlap, gather):
+        """the sequence-parallel layer loop in one C call (mc_blocks_sp): gather(layer, phase) is called back twice per
+        layer -- phase 0: start the K|V all-gather, phase 1: make the launch stream wait for it.  An exception raised
+        inside the callback aborts the loop and is re-raised here."""
+        from ._lib import SP_GATHER_FN
+        err = []
+
+        def cb(_user, layer, phase, _stream_):
+            try:
+                gather(layer, phase)
+                return 0
+            except BaseException as ex:   # noqa: BLE001 -- must not propagate through the C frame
+                err.append(ex)
+                return 1
+        fn = SP_GATHER_FN(cb)
+        st = self.lib.mc_blocks_sp(self.h, layer_begin, layer_end, branch, mode, int(bool(overlap)), fn, None, _stream())
+        if err:
+            raise err[0]
+        check(st)
 
     def vace_block_pre(self, i):
         check(self.lib.mc_vace_block_pre(self.h, i, _stream()))

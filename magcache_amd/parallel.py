@@ -30,6 +30,8 @@ from ._lib import MC_MODE_CALIB, MC_MODE_SKIP
 
 # MAGCACHE_SP_OVERLAP=0: wait for the K/V all-gather before the local-shard attention (no kernel runs beside RCCL)
 SP_OVERLAP = os.environ.get("MAGCACHE_SP_OVERLAP", "1") != "0"
+# MAGCACHE_SP_C_LOOP=0: issue the per-layer phases from Python (three engine calls per layer) instead of one mc_blocks_sp call
+SP_C_LOOP = os.environ.get("MAGCACHE_SP_C_LOOP", "1") != "0"
 
 
 class ParallelLayout:
@@ -135,31 +137,51 @@ class SequenceParallelForward:
         dist.all_gather([self.kv[r] for r in range(self.P)], mine.clone(), group=self.group)
         return None
 
+    def _layers_by_phase(self, branch, mode):
+        """the layer loop issued phase by phase from Python (MAGCACHE_SP_C_LOOP=0, and engines without blocks_sp: the CPU
+        stand-in of the gloo tests); mc_blocks_sp runs exactly this sequence"""
+        e = self.e
+        for layer in range(self.NL):
+            e.block_pre_attn(layer)
+            work = self._all_gather_kv()
+            if work is not None and not SP_OVERLAP:
+                work.wait()
+                work = None
+            e.block_attn_local(layer)          # overlaps the gather: needs only this rank's shard
+            if work is not None:
+                work.wait()                    # stream dependency, no host sync
+            e.block_post_attn(layer, branch, mode)
+            nv, stride = getattr(e, "vace_layers", 0), getattr(e, "vace_stride", 0)
+            if nv and layer % stride == 0 and layer // stride < nv:
+                # VACE control block of this layer: same two phases on the control stream, then the hint
+                i = layer // stride
+                e.vace_block_pre(i)
+                work = self._all_gather_kv()
+                if work is not None:
+                    work.wait()
+                e.vace_block_post(i, branch, mode)
+
     def forward(self, latent, t, context, branch, mode, out=None):
         e = self.e
         if out is None:
             out = torch.empty((e.cfg["out_dim"],) + tuple(e.grid), dtype=torch.float32, device=self.kv.device)
         e.embed(latent, t, context)
         if mode != MC_MODE_SKIP:
-            for layer in range(self.NL):
-                e.block_pre_attn(layer)
-                work = self._all_gather_kv()
-                if work is not None and not SP_OVERLAP:
-                    work.wait()
-                    work = None
-                e.block_attn_local(layer)          # overlaps the gather: needs only this rank's shard
-                if work is not None:
-                    work.wait()                    # stream dependency, no host sync
-                e.block_post_attn(layer, branch, mode)
-                nv, stride = getattr(e, "vace_layers", 0), getattr(e, "vace_stride", 0)
-                if nv and layer % stride == 0 and layer // stride < nv:
-                    # VACE control block of this layer: same two phases on the control stream, then the hint
-                    i = layer // stride
-                    e.vace_block_pre(i)
-                    work = self._all_gather_kv()
-                    if work is not None:
-                        work.wait()
-                    e.vace_block_post(i, branch, mode)
+            if SP_C_LOOP and hasattr(e, "blocks_sp"):
+                # ONE call into the engine for the whole layer loop (mc_blocks_sp); it calls back for the collective only:
+                # phase 0 = start the gather (asynchronous: RCCL runs it on its own stream, ordered behind pre_attn),
+                # phase 1 = the launch stream waits for it (stream dependency, no host sync)
+                pending = [None]
+
+                def gather(layer, phase):
+                    if phase == 0:
+                        pending[0] = self._all_gather_kv()
+                    elif pending[0] is not None:
+                        pending[0].wait()
+                        pending[0] = None
+                e.blocks_sp(0, self.NL, branch, mode, SP_OVERLAP, gather)
+            else:
+                self._layers_by_phase(branch, mode)
             if mode == MC_MODE_CALIB:
                 has = e.calib_has_stats(branch)
                 if has:

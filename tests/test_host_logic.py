@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -29,6 +30,26 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_lib.SIGNATURES) == declared
     assert b"gfx950" in lib.mc_version()
+
+
+def test_product_sources_carry_no_wrong_result_switches():
+    """The timing ablations that make a kernel WRONG on purpose live in the A/B builders (source transforms on a copy:
+    tools/build_gemm_v2_variants.py ablate(); generator options of gen_attention_v5.py), not behind -D macros in the shipped
+    translation units; and the builder's anchors still exist in gemm_bf16_v2.hip."""
+    csrc = os.path.join(ROOT, "magcache_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".cpp", ".h")):
+            src = open(os.path.join(csrc, fn)).read()
+            for macro in ("MC_V2_EPI_ABL", "MC_V2_DEFER_ABL", "MC_V2_NO_EPI", "MC_V2_RESID_SPLIT", "MC_V2_XAHEAD"):
+                assert macro not in src, (fn, macro)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_gemm_v2_variants as BV
+    text = open(os.path.join(csrc, "gemm_bf16_v2.hip")).read()
+    for kv in ({"noepi": "1"}, {"epiabl": "1"}, {"epiabl": "3"}, {"epiabl": "4"}, {"deferabl": "3"}):
+        out = BV.ablate(text, kv)
+        assert out != text and out.count("raw_buffer") <= text.count("raw_buffer")
+    # (the attention / GEMM streams that ship are the generators' DEFAULT configuration, abl = "":
+    #  test_attention_v5_emu.py / test_gemm_v2_emu.py ::*_inc_file_is_current regenerate them byte for byte)
 
 
 def test_no_oracle_import_in_product():

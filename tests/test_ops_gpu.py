@@ -331,6 +331,68 @@ def test_gemm_linearity_full_shape(kernel_variant):
     torch.testing.assert_close(outs[0][idx], a[idx].float() @ Wt.float().t(), rtol=0, atol=0)
 
 
+def _v2_sample_rows(M):
+    """>= 512 rows spread over M tiles of 256 at the start, the middle and the end of the row range (under the grouped,
+    XCD-contiguous tile order these land in the first, middle and last persistent trips of different workgroups), and inside
+    a tile the rows where a wave's strip / range-check arithmetic changes: 0..3, 104..131 (incl. 108-111 and 124-127, where the
+    first lean epilogue addressed rows through the buffer soffset and was wrong: profiles/r04/NOTES.md 1.4), 250..255."""
+    tiles = [0, 1, 2, 3, 31, 32, 37, 63, 64, 65, 95, 100, 125, 126, 127]
+    inside = list(range(0, 4)) + list(range(104, 132)) + list(range(250, 256))
+    rows = torch.tensor([t * 256 + r for t in tiles for r in inside if t * 256 + r < M])
+    assert rows.numel() >= 512
+    return rows.to(DEV)
+
+
+@pytest.mark.parametrize("N,K,epi", [(4608, 1536, "bf16"), (8960, 1536, "gelu"), (1536, 8960, "resid_gate"),
+                                     (1536, 8960, "resid_nogate"), (1536, 1536, "resid_gate"), (1536, 1536, "resid_nogate")],
+                         ids=["qkv-bf16", "ffn1-gelu", "ffn2-resid-gate", "ffn2-resid", "o-resid-gate", "o-resid"])
+def test_gemm_v2_full_shape_epilogues_rows(N, K, epi):
+    """gemm_bf16_v2 -- what the SHIPPED by-shape dispatch (gemm_kernel = 0) runs for the four Linears of a Wan block -- at the
+    headline M = 32768, where a workgroup walks 3 (O), 9 (QKV), 17.5 (FFN-1: 35 x 128 tiles on 256 CUs) or 3 (FFN-2) tiles
+    persistently: the hand-over "epilogue strip in LDS while the next tile's K tiles 0, 1 are already prefetched" runs in every
+    trip but the last.  (a) sampled rows x ALL columns against the fp32 product A Wt^T with the tolerances of
+    test_gemm_bf16_epilogues; (b) the whole output bit-identical to the 8-wave kernel (gemm_kernel = 2), which has no
+    persistent loop and no strip."""
+    lib = _lib.load()
+    M = 32768
+    A = rnd(M, K, seed=21, dtype=torch.bfloat16)
+    Wt = rnd(N, K, seed=22, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=23)
+    rows = _v2_sample_rows(M)
+    ref = (A[rows].double() @ Wt.double().t() + bias.double()).float()
+    gate = rnd(N, seed=25) if epi == "resid_gate" else None
+
+    def run(kernel):
+        _lib.check(lib.mc_set_option(b"gemm_kernel", kernel))
+        try:
+            if epi in ("bf16", "gelu"):
+                out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+                H.gemm(A, Wt, bias, 0 if epi == "bf16" else 1, Cb=out)
+            else:
+                out = rnd(M, N, seed=24)
+                H.gemm(A, Wt, bias, 2, X=out, gate=gate)
+        finally:
+            _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
+        return out
+
+    got = run(0)
+    if epi == "bf16":
+        torch.testing.assert_close(got[rows].float(), ref, rtol=1e-2, atol=1e-2)
+        assert rel_l2(got[rows], ref) < 4e-3
+    elif epi == "gelu":
+        torch.testing.assert_close(got[rows].float(), F.gelu(ref.bfloat16().float(), approximate="tanh"), rtol=2e-2, atol=2e-2)
+    else:
+        x_in = rnd(M, N, seed=24)[rows]
+        want = x_in + ref.bfloat16().float() * (gate if gate is not None else 1.0)
+        torch.testing.assert_close(got[rows], want, rtol=1e-2, atol=2e-2 * math.sqrt(K / 1536))
+        assert rel_l2(got[rows] - x_in, want - x_in) < 4e-3
+    other = run(2)
+    assert torch.equal(got.view(torch.int16 if got.dtype == torch.bfloat16 else torch.int32),
+                       other.view(torch.int16 if other.dtype == torch.bfloat16 else torch.int32))
+    # and the dispatch did pick the generated-stream kernel for this shape (otherwise (b) compared a kernel with itself)
+    assert lib.mc_op_gemm_bf16_kernel(M, N, K, 0 if epi == "bf16" else 1 if epi == "gelu" else 2) == 4
+
+
 # ----------------------------------------------------------------------------- attention
 def attn_ref(q, k, v, n_heads, valid_idx):
     Lq = q.shape[0]
