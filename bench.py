@@ -301,6 +301,19 @@ def cpu_baseline(cfg, max_threads):
                 seconds_per_forward_extrapolated=t_full)
 
 
+def engine_bytes_estimate(cfg, sp_size=1):
+    """HBM one engine needs on a rank, from the geometry (an upper estimate, +10 %): weights are replicated (bf16 Linears, an
+    e4m3 copy of the quantised ones with fp8_linear), the workspace holds this rank's L / sp_size tokens (DESIGN section 2's
+    table: x fp32, x0 / xn / ao bf16, qkv, h, two residual slots fp32) plus the K|V gather buffer of the whole sequence."""
+    d, f, n = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
+    lin = n * (8 * d * d + 2 * d * f)
+    weights = lin * (2 + (1 if cfg.get("fp8_linear") else 0)) + 4 * cfg["text_dim"] * d
+    lp = (SEQ // sp_size + 255) // 256 * 256
+    ws = lp * (4 * d + 3 * 2 * d + 2 * 3 * d + 2 * f + 2 * 4 * d) + (sp_size * lp * 2 * d * 2 if sp_size > 1 else 0)
+    ws += 2 * n * 512 * 2 * d * 2                  # text K|V cache of two prompts
+    return 1.1 * (weights + ws)
+
+
 STAGE = ["start"]        # where a failure happened (reported in the error line of a multi-GPU run)
 
 
@@ -320,6 +333,8 @@ def main():
         return bench_main()
     except BaseException as e:   # noqa: BLE001  (SystemExit from argparse included: the line is the contract)
         import traceback
+        if isinstance(e, SystemExit) and not e.code:
+            raise                                   # --help and other clean exits are not failures
         if rank == 0:
             print(json.dumps({"metric": "denoising steps/sec (MagCache on), Wan2.1-T2V-1.3B 480p 81f", "value": None,
                               "unit": "steps/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
@@ -436,9 +451,10 @@ def bench_main():
         layouts = {n: PAR.ParallelLayout(cfg_parallel=(n == "cfg2sp")) for n in names}   # every rank builds every group
         models = {}
         # memory: --layout auto holds one engine per candidate layout on every GPU until the ablation has chosen
-        # (weights + workspace each: 2.8 + 2.1 GB at 1.3B); refuse early, with the numbers, rather than fail in hipMalloc
+        # (weights + this rank's share of the workspace each, engine_bytes_estimate); refuse early, with the numbers, rather
+        # than fail in hipMalloc.  (Ranks sharing one device -- the one-GPU tests -- each see the same free figure.)
         free_b, total_b = torch.cuda.mem_get_info()
-        need_b = len(names) * 6.5e9
+        need_b = sum(engine_bytes_estimate(cfg, layouts[n].sp_size) for n in names)
         extra["hbm_free_gb_at_start"] = round(free_b / 1e9, 1)
         if free_b < need_b:
             raise RuntimeError(f"{len(names)} engines need ~{need_b / 1e9:.0f} GB, {free_b / 1e9:.1f} GB free of {total_b / 1e9:.0f} GB "

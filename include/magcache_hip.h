@@ -90,6 +90,8 @@ const char* mc_version(void);
  *                   (gemm_bf16_big.hip) for the per-token-gate, residual-capture, embed and fp32 epilogues; the 128x128
  *                   kernel for everything else.  1 = the 128x128 kernel everywhere, 2 = the 8-wave 256x256 kernel wherever
  *                   it applies, 4 = gemm_bf16_v2 wherever it applies.  All three give the same bits.
+ *   "gemm_splitk"   1 (default) = split-K by shape (see mc_op_set_splitk_workspace below), 0 = never, 2..16 = that many
+ *                   slices wherever K divides (parity tests).
  *   "gemm_defer"    no effect in the shipped library.  (A/B libraries whose gemm_bf16_v2 stream was generated with
  *                   tools/gen_gemm_v2.py --defer 1 apply a gated-residual epilogue inside the next output tile's main
  *                   loop -- bit-identical, measured 1.5-4 % slower, DESIGN 3.2 -- and 0 switches that off at run time.)
@@ -115,6 +117,11 @@ mc_status mc_set_option(const char* key, int value);
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
 mc_status mc_create(const mc_config* cfg, mc_engine** out);
+/* ABI rule for mc_config: it only grows at its END and a zero in a new field means "as before".  mc_create reads
+ * sizeof(mc_config) of THIS header; a caller compiled against an older header (a shorter struct) must call
+ * mc_create_sized(cfg, sizeof(mc_config) as IT knows it, out): the missing tail is taken as zeros.  History: 0.1 ends at
+ * vace_in_dim, 0.2 adds fp8_linear, 0.3 no_context_cache and no_token_timesteps; mc_version() names the library's. */
+mc_status mc_create_sized(const mc_config* cfg, size_t cfg_bytes, mc_engine** out);
 void mc_destroy(mc_engine* e);
 size_t mc_workspace_bytes(const mc_engine* e);
 mc_status mc_set_workspace(mc_engine* e, void* ws_dev, size_t bytes);
@@ -281,6 +288,16 @@ mc_status mc_op_gemm_bf16(const void* A_dev, long lda, const void* W_dev, long l
 /* which kernel mc_op_gemm_bf16 (and the engine) runs for this problem under the current "gemm_kernel" option: 1 = the 128x128
  * kernel, 2 = the 8-wave 256x256 kernel, 4 = gemm_bf16_v2; 0 = the shape is rejected.  (lda = ldw = K, ldc / ldx = N.) */
 int mc_op_gemm_bf16_kernel(int M, int N, int K, int epi);
+/* Split-K (gemm_bf16_v2): when a problem's 256 x 256 tiles cover at most half of the CUs and K is long (the M = 512 .. 1536
+ * projections back to d of an MM-DiT block at image sizes: N = 3072, K = 12288 / 15360), the K loop is cut into S slices, S x
+ * tiles workgroups park their fp32 accumulators in a scratch buffer and a second launch sums the slices in index order and
+ * applies the epilogue (deterministic; not bit-identical to the unsplit summation order).  The engines carry the scratch in
+ * their workspace ("splitk0" / "splitk1"); the single-op entry point uses the buffer set here (NULL: never split).
+ * mc_op_gemm_bf16_splitk = the number of slices mc_op_gemm_bf16 would use for this problem now (1 = no split; contiguous
+ * operands assumed); mc_op_gemm_splitk_need = scratch bytes the by-shape policy wants for it (0 = it does not split). */
+mc_status mc_op_set_splitk_workspace(void* ws_dev, size_t bytes);
+int mc_op_gemm_bf16_splitk(int M, int N, int K, int epi);
+size_t mc_op_gemm_splitk_need(int M, int N, int K, int epi);
 /* fp8 path (OCP e4m3, v_mfma_f32_32x32x64_f8f6f4): row-wise quantisation q = e4m3(x / s), s = max|row| / 448, and
  * C = (A_q W_q^T) * a_scale[m] * w_scale[n] + bias with the bf16 / gelu / residual-gate / fp32 epilogues */
 mc_status mc_op_quantize_rows_fp8(const void* x_dev, mc_dtype dtype, long ldx, int M, int K, void* q_dev, long ldq,

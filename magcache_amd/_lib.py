@@ -47,6 +47,7 @@ SIGNATURES = {
     "mc_version": (C.c_char_p, []),
     "mc_set_option": (_i, [C.c_char_p, _i]),
     "mc_create": (_i, [C.POINTER(McConfig), C.POINTER(_vp)]),
+    "mc_create_sized": (_i, [C.POINTER(McConfig), _sz, C.POINTER(_vp)]),
     "mc_destroy": (None, [_vp]),
     "mc_workspace_bytes": (_sz, [_vp]),
     "mc_set_workspace": (_i, [_vp, _vp, _sz]),
@@ -84,6 +85,9 @@ SIGNATURES = {
     "mc_op_gemm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l,
                              _i, _vp]),
     "mc_op_gemm_bf16_kernel": (_i, [_i, _i, _i, _i]),
+    "mc_op_gemm_bf16_splitk": (_i, [_i, _i, _i, _i]),
+    "mc_op_gemm_splitk_need": (_sz, [_i, _i, _i, _i]),
+    "mc_op_set_splitk_workspace": (_i, [_vp, _sz]),
     "mc_op_attention": (_i, [_vp, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _vp]),
     "mc_op_quantize_rows_fp8": (_i, [_vp, _i, _l, _i, _i, _vp, _l, _vp, _vp]),
     "mc_op_gemm_fp8": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),

@@ -190,15 +190,23 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------ MM-DiT per-head RMSNorm + RoPE (q and k)
-// One wave per row; a head is 128 channels = 64 lanes x one (2i, 2i+1) pair, i.e. exactly one RoPE pair per lane.
+// A head is 128 channels = 64 lanes x one (2i, 2i+1) pair, i.e. exactly one RoPE pair per lane.  One wave per (row, q | k,
+// group of HN_HEADS heads): the heads of a group are loaded together and then normalised one after the other.  (Rounds 1-4
+// ran ONE wave per row through all 2 x n_heads heads serially -- 48 dependent load / reduce / store round trips, 35 us for
+// FLUX's [1536, 2 x 24 heads] where the bytes need 6 us: 2.7 ms of a 38 ms FLUX forward.)  Same arithmetic per head.
+constexpr int HN_HEADS = 4;
 MC_NO_PK_F32 __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__ x, long ldx, long k_col0,
                                                             const float* __restrict__ wq,
                                                             const float* __restrict__ wk, float eps,
                                                             const float* __restrict__ cs, int cs_row0, int M,
                                                             int n_heads) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int groups = (n_heads + HN_HEADS - 1) / HN_HEADS;
+  const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (row, part, head group)
+  const int row = (int)(unit / (2 * groups));
   if (row >= M) return;
+  const int rem = (int)(unit - (long)row * 2 * groups);
+  const int part = rem / groups, h0 = (rem - part * groups) * HN_HEADS;
   float cc = 1.f, sn = 0.f;
 #if defined(MC_PK_EXPERIMENT) && MC_PK_EXPERIMENT == 2
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -208,66 +216,91 @@ MC_NO_PK_F32 __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t*
     cc = t[0];
     sn = t[1];
   }
-#pragma unroll 1
-  for (int part = 0; part < 2; ++part) {
-    uint32_t* xr = (uint32_t*)(x + (size_t)row * ldx + (part ? k_col0 : 0)) + lane;
-    const float* w = part ? wk : wq;
-    f32x2 wv = {1.f, 1.f};
-    if (w) wv = *(const f32x2*)(w + 2 * lane);
-    for (int h = 0; h < n_heads; ++h) {
+  uint32_t* xr = (uint32_t*)(x + (size_t)row * ldx + (part ? k_col0 : 0)) + lane;
+  const float* w = part ? wk : wq;
+  f32x2 wv = {1.f, 1.f};
+  if (w) wv = *(const f32x2*)(w + 2 * lane);
+  uint32_t b[HN_HEADS];
+#pragma unroll
+  for (int j = 0; j < HN_HEADS; ++j) {
+    const int h = min(h0 + j, n_heads - 1);
 #if defined(MC_PK_EXPERIMENT) && MC_PK_EXPERIMENT == 2
-      const uint32_t b = __hip_atomic_load(xr + h * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b[j] = __hip_atomic_load(xr + h * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-      const uint32_t b = xr[h * 64];
+    b[j] = xr[h * 64];
 #endif
-      float re = __uint_as_float(b << 16), im = __uint_as_float(b & 0xffff0000u);
-      if (w) {
-        // upstream RMSNorm (diffusers / hyvideo): norm in fp32, cast to the activation dtype, then * weight
-        const float rstd = rsqrtf(wave_sum(re * re + im * im) * (1.0f / 128.0f) + eps);
-        re = bf16_round(re * rstd) * wv[0];
-        im = bf16_round(im * rstd) * wv[1];
-        if (cs) {  // the weighted value is a bf16 tensor upstream before RoPE is applied in fp32
-          re = bf16_round(re);
-          im = bf16_round(im);
-        }
+  }
+#pragma unroll
+  for (int j = 0; j < HN_HEADS; ++j) {
+    const int h = h0 + j;
+    if (h >= n_heads) break;
+    float re = __uint_as_float(b[j] << 16), im = __uint_as_float(b[j] & 0xffff0000u);
+    if (w) {
+      // upstream RMSNorm (diffusers / hyvideo): norm in fp32, cast to the activation dtype, then * weight
+      const float rstd = rsqrtf(wave_sum(re * re + im * im) * (1.0f / 128.0f) + eps);
+      re = bf16_round(re * rstd) * wv[0];
+      im = bf16_round(im * rstd) * wv[1];
+      if (cs) {  // the weighted value is a bf16 tensor upstream before RoPE is applied in fp32
+        re = bf16_round(re);
+        im = bf16_round(im);
       }
-      const float r2 = re * cc - im * sn, i2 = re * sn + im * cc;
-      xr[h * 64] = pack_bf16x2(r2, i2);
     }
+    const float r2 = re * cc - im * sn, i2 = re * sn + im * cc;
+    xr[h * 64] = pack_bf16x2(r2, i2);
   }
 #if defined(MC_PK_EXPERIMENT) && MC_PK_EXPERIMENT == 2
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
 }
 
+// y = act_out(W x' + b), x' = act_in(x): bf16 weights [N, K] read ONCE (non-temporal), the vector staged in LDS with its
+// activation applied once per block (rounds 1-4 re-read x from L1 for every row -- twice the weight bytes through the CU's
+// address path -- and ran at 3.2 TB/s on FLUX's 6.5 GB modulation matrix).  A wave owns GV_ROWS consecutive rows: GV_ROWS
+// independent 16-byte weight loads per lane and step.  Per row the products are summed in the same order as before.
+constexpr int GV_ROWS = 4;
 __global__ __launch_bounds__(256) void gemv_bf16w_kernel(const bf16_t* __restrict__ Wt, const float* __restrict__ x,
                                                          const float* __restrict__ b, float* __restrict__ y, int N,
                                                          int K, int act_in, int act_out, int accumulate) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  const bf16_t* wr = Wt + (size_t)n * K;
-  float acc = 0.f;
-  for (int k = lane * 8; k < K; k += 512) {
-    const u32x4 wv = *(const u32x4*)(wr + k);
-    f32x4 x0 = *(const f32x4*)(x + k), x1 = *(const f32x4*)(x + k + 4);
+  extern __shared__ __attribute__((aligned(16))) float gv_x[];
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    f32x4 v = *(const f32x4*)(x + k);
     if (act_in == 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x0[j] = silu(x0[j]);
-        x1[j] = silu(x1[j]);
-      }
+      for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
     }
-    acc += (__uint_as_float(wv[0] << 16) * x0[0] + __uint_as_float(wv[0] & 0xffff0000u) * x0[1]) +
-           (__uint_as_float(wv[1] << 16) * x0[2] + __uint_as_float(wv[1] & 0xffff0000u) * x0[3]) +
-           (__uint_as_float(wv[2] << 16) * x1[0] + __uint_as_float(wv[2] & 0xffff0000u) * x1[1]) +
-           (__uint_as_float(wv[3] << 16) * x1[2] + __uint_as_float(wv[3] & 0xffff0000u) * x1[3]);
+    *(f32x4*)(gv_x + k) = v;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    float r = acc + (b ? b[n] : 0.f);
-    if (act_out == 1) r = silu(r);
-    y[n] = accumulate ? y[n] + r : r;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GV_ROWS;
+  if (n0 >= N) return;
+  const bf16_t* wr[GV_ROWS];
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r) wr[r] = Wt + (size_t)min(n0 + r, N - 1) * K;
+  float acc[GV_ROWS];
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r) acc[r] = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const f32x4 x0 = *(const f32x4*)(gv_x + k), x1 = *(const f32x4*)(gv_x + k + 4);
+    u32x4 wv[GV_ROWS];
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r) wv[r] = __builtin_nontemporal_load((const u32x4*)(wr[r] + k));
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r)
+      acc[r] += (__uint_as_float(wv[r][0] << 16) * x0[0] + __uint_as_float(wv[r][0] & 0xffff0000u) * x0[1]) +
+                (__uint_as_float(wv[r][1] << 16) * x0[2] + __uint_as_float(wv[r][1] & 0xffff0000u) * x0[3]) +
+                (__uint_as_float(wv[r][2] << 16) * x1[0] + __uint_as_float(wv[r][2] & 0xffff0000u) * x1[1]) +
+                (__uint_as_float(wv[r][3] << 16) * x1[2] + __uint_as_float(wv[r][3] & 0xffff0000u) * x1[3]);
+  }
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r) {
+    const float a = wave_sum(acc[r]);
+    const int n = n0 + r;
+    if (lane == 0 && n < N) {
+      float v = a + (b ? b[n] : 0.f);
+      if (act_out == 1) v = silu(v);
+      y[n] = accumulate ? y[n] + v : v;
+    }
   }
 }
 
@@ -597,16 +630,18 @@ hipError_t launch_rmsnorm_rope(bf16_t* x, long ldx, const float* w, float eps, c
 hipError_t launch_headnorm_rope(bf16_t* x, long ldx, long k_col0, const float* wq, const float* wk, float eps,
                                 const float* cs, int cs_row0, int M, int n_heads, hipStream_t stream) {
   if (M <= 0 || n_heads <= 0 || (ldx % 2) != 0 || (k_col0 % 2) != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(headnorm_rope_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, ldx, k_col0, wq, wk, eps, cs,
-                     cs_row0, M, n_heads);
+  const long units = (long)M * 2 * ((n_heads + HN_HEADS - 1) / HN_HEADS);
+  hipLaunchKernelGGL(headnorm_rope_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, x, ldx, k_col0, wq, wk, eps,
+                     cs, cs_row0, M, n_heads);
   return hipGetLastError();
 }
 
 hipError_t launch_gemv_bf16w(const bf16_t* W, const float* x, const float* b, float* y, int N, int K, int act_in,
                              int act_out, int accumulate, hipStream_t stream) {
-  if ((K % 8) != 0 || N <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gemv_bf16w_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, x, b, y, N, K, act_in, act_out,
-                     accumulate);
+  if ((K % 8) != 0 || N <= 0 || K > 16384) return hipErrorInvalidValue;     // the vector lives in LDS: 64 KiB at most
+  const int rows_per_block = 4 * GV_ROWS;
+  hipLaunchKernelGGL(gemv_bf16w_kernel, dim3((N + rows_per_block - 1) / rows_per_block), dim3(256), (size_t)K * sizeof(float),
+                     stream, W, x, b, y, N, K, act_in, act_out, accumulate);
   return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -248,7 +249,21 @@ extern int g_mmdit_two_streams;   // mmdit_engine.cpp: mc_set_option("mmdit_two_
 extern "C" {
 
 const char* mc_last_error(void) { return g_err; }
-const char* mc_version(void) { return "magcache_hip 0.3 (gfx950)"; }
+const char* mc_version(void) { return "magcache_hip 0.4 (gfx950)"; }
+
+// mc_config only ever grows at its END, and a zero in a new field keeps the behaviour older callers had: a caller built
+// against an older header passes ITS sizeof(mc_config) and the tail reads as zeros (instead of being read past the end of
+// the caller's struct, as mc_create would)
+mc_status mc_create_sized(const mc_config* cfg, size_t cfg_bytes, mc_engine** out) {
+  if (!cfg || !out) return fail(MC_EINVAL, "null argument");
+  if (cfg_bytes < offsetof(mc_config, fp8_linear) || cfg_bytes > sizeof(mc_config) || (cfg_bytes % sizeof(int)) != 0)
+    return fail(MC_EINVAL, "mc_config of %zu bytes: this library knows %zu (0.1 layout) .. %zu", cfg_bytes,
+                offsetof(mc_config, fp8_linear), sizeof(mc_config));
+  mc_config full;
+  memset(&full, 0, sizeof(full));
+  memcpy(&full, cfg, cfg_bytes);
+  return mc_create(&full, out);
+}
 
 mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   if (!cfg || !out) return fail(MC_EINVAL, "null argument");
@@ -1398,6 +1413,10 @@ mc_status mc_state_reset(mc_engine* e) {
 }
 
 // ------------------------------------------------------------------------------------------------ ops
+// split-K scratch of the single-op entry point (mc_op_set_splitk_workspace): the engines carry their own in their workspace
+static float* g_op_splitk_ws = nullptr;
+static size_t g_op_splitk_bytes = 0;
+
 mc_status mc_op_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, int M, int N, int K,
                           int epi, void* Cb, long ldc, float* X, long ldx, const float* gate, const void* X0,
                           long ldx0, float* R, long ldr, void* X0out, long ldx0out, int m_valid, mc_stream s) {
@@ -1405,6 +1424,7 @@ mc_status mc_op_gemm_bf16(const void* A, long lda, const void* W, long ldw, cons
   p.Cb = (bf16_t*)Cb; p.ldc = ldc; p.X = X; p.ldx = ldx; p.gate = gate;
   p.X0 = (const bf16_t*)X0; p.ldx0 = ldx0; p.R = R; p.ldr = ldr;
   p.X0out = (bf16_t*)X0out; p.ldx0out = ldx0out; p.m_valid = m_valid;
+  p.splitk_ws = g_op_splitk_ws; p.splitk_ws_bytes = g_op_splitk_bytes;
   hipError_t err = mc::launch_gemm_bf16(p, epi, (hipStream_t)s);
   if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "gemm: unsupported shape M=%d N=%d K=%d epi=%d", M, N, K, epi);
   HIP_TRY(err);
@@ -1416,6 +1436,22 @@ int mc_op_gemm_bf16_kernel(int M, int N, int K, int epi) {
   p.ldc = N; p.ldx = N;
   if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0) return 0;
   return mc::gemm_bf16_kernel_for(p, epi);
+}
+
+int mc_op_gemm_bf16_splitk(int M, int N, int K, int epi) {
+  mc::GemmParams p = gp(nullptr, K, nullptr, K, nullptr, M, N, K);
+  p.ldc = N; p.ldx = N;
+  p.splitk_ws = g_op_splitk_ws; p.splitk_ws_bytes = g_op_splitk_bytes;
+  if (M <= 0 || N <= 0 || K <= 0 || (mc::g_gemm_kernel != 0 && mc::g_gemm_kernel != 4)) return 1;
+  return mc::gemm_splitk_slices(p, epi);
+}
+
+size_t mc_op_gemm_splitk_need(int M, int N, int K, int epi) { return mc::gemm_splitk_ws_need(M, N, K, epi); }
+
+mc_status mc_op_set_splitk_workspace(void* ws_dev, size_t bytes) {
+  g_op_splitk_ws = (float*)ws_dev;
+  g_op_splitk_bytes = ws_dev ? bytes : 0;
+  return MC_OK;
 }
 
 mc_status mc_op_attention(const void* Q, long ldq, const void* K, long ldk, long kss, const void* V, long ldv,
@@ -1566,6 +1602,9 @@ mc_status mc_set_option(const char* key, int value) {
     if ((value < 0 || value > 2) && value != 4)
       return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 4 (256x256, 4 waves, generated stream)");
     mc::g_gemm_kernel = value;
+  } else if (k == "gemm_splitk") {
+    if (value < 0 || value > 16) return fail(MC_EINVAL, "gemm_splitk must be 0 (never), 1 (by shape) or 2..16 (that many K slices wherever valid)");
+    mc::g_gemm_splitk = value;
   } else if (k == "gemm_defer") {
     if (value != 0 && value != 1) return fail(MC_EINVAL, "gemm_defer must be 0 (residual epilogues in place) or 1 (deferred into the next tile's main loop)");
     mc::g_gemm_defer = value;

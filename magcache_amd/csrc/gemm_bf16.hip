@@ -262,6 +262,11 @@ int gemm_bf16_kernel_for(const GemmParams& p, int epi) {
 }
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+  // few tiles, long K, scratch at hand: K in slices on gemm_bf16_v2 + one reduce launch (policy: gemm_bf16_v2.hip)
+  if (g_gemm_kernel == 0 || g_gemm_kernel == 4) {
+    const int slices = gemm_splitk_slices(p, epi);
+    if (slices > 1) return launch_gemm_bf16_v2_splitk(p, epi, slices, stream);
+  }
   switch (gemm_bf16_kernel_for(p, epi)) {
     case 4: return launch_gemm_bf16_v2(p, epi, stream);
     case 2: return launch_gemm_bf16_big(p, epi, stream);

@@ -77,28 +77,45 @@ __device__ __forceinline__ float agpr_read(float a) {
   return x;
 }
 
+// virtual work unit vt (XCD-contiguous, v2_unit) -> K slice and output tile origin; tiles grouped along M (as gemm_bf16_big.hip)
+__device__ __forceinline__ void v2_place(int vt, int tilesM, int tilesN, int GROUP_M, int& slice, int& tile, int& tm0, int& tn0) {
+  const int ntiles = tilesM * tilesN;
+  slice = vt / ntiles;
+  tile = vt - slice * ntiles;
+  const int per_group = GROUP_M * tilesN;
+  const int grp = tile / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tilesM - first_m, GROUP_M);
+  const int in_grp = tile - grp * per_group;
+  tm0 = (first_m + in_grp % gsz) * TB;
+  tn0 = (in_grp / gsz) * TB;
+}
+
+// split-K scratch: the accumulators of (slice, tile) in the MFMA layout itself -- quad (nb, mb) of wave w is 64 lanes x 16
+// bytes, contiguous: [slice][tile][wave][quad nb * 8 + mb][lane][4]
+static_assert(MC_GEMM_V2_MFMA == 16, "the split-K reduce decodes the 16x16x32 accumulator layout: quad (nb, mb) = register (8 nb + mb) * 4");
+__device__ __forceinline__ size_t v2_partial_off(int slice, int tile, int ntiles, int wave, int quad) {
+  return ((((size_t)slice * ntiles + tile) * 4 + wave) * 64 + quad) * 256;
+}
+
+// slices > 1 (EPI_SPLITK_PARTIAL only): the work units are (K slice, output tile) pairs, p.K / slices columns of A and W each
 template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M, bf16_t* scratch_all) {
+__global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M, bf16_t* scratch_all,
+                                                         int slices) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // ---- tile mapping: XCD-contiguous, grouped along M (as gemm_bf16_big.hip)
   const int ntiles = tilesM * tilesN;
-  int m0 = 0, n0 = 0;
-  auto place = [&](int t, int& tm0, int& tn0) {
-    const int vt = xcd_remap(t, ntiles);
-    const int per_group = GROUP_M * tilesN;
-    const int grp = vt / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(tilesM - first_m, GROUP_M);
-    const int in_grp = vt - grp * per_group;
-    tm0 = (first_m + in_grp % gsz) * TB;
-    tn0 = (in_grp / gsz) * TB;
+  const int nunits = ntiles * slices;
+  int m0 = 0, n0 = 0, sl = 0, tl = 0;
+  auto place = [&](int t, int& slice, int& tile, int& tm0, int& tn0) {
+    v2_place(xcd_remap(t, nunits), tilesM, tilesN, GROUP_M, slice, tile, tm0, tn0);
   };
+  const int Ks = p.K / slices;             // columns of this launch's K slices
   const uint32_t lda_b = (uint32_t)p.lda * 2, ldw_b = (uint32_t)p.ldw * 2;
-  // bytes reachable from a tile's first element: rows past M / N are out of range and read zeros
-  auto a_nrec_of = [&](int tm0) { return (uint32_t)min((size_t)(p.M - tm0) * lda_b - (size_t)(p.lda - p.K) * 2, (size_t)0xffffff00u); };
-  auto w_nrec_of = [&](int tn0) { return (uint32_t)min((size_t)(p.N - tn0) * ldw_b - (size_t)(p.ldw - p.K) * 2, (size_t)0xffffff00u); };
-  const int nk = p.K / 32;
+  // bytes reachable from a (tile, slice)'s first element: rows past M / N are out of range and read zeros
+  auto a_nrec_of = [&](int tm0) { return (uint32_t)min((size_t)(p.M - tm0) * lda_b - (size_t)(p.lda - Ks) * 2, (size_t)0xffffff00u); };
+  auto w_nrec_of = [&](int tn0) { return (uint32_t)min((size_t)(p.N - tn0) * ldw_b - (size_t)(p.ldw - Ks) * 2, (size_t)0xffffff00u); };
+  const int nk = Ks / 32;
   const uint32_t lds0 = (uint32_t)(uintptr_t)MC_LDS_PTR(smem);
   constexpr bool LEAN = MC_GEMM_V2_MFMA == 16 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RESID_GATE);
   constexpr bool CAN_DEFER = MC_GEMM_V2_PERSIST && MC_GEMM_V2_SCHED_H && MC_GEMM_V2_DEFER && EPI == EPI_RESID_GATE;
@@ -349,6 +366,18 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     }
   };
 
+  // ---- split-K: this (slice, tile)'s accumulators leave in their own layout, one coalesced 1 KiB store per quad and wave
+  auto partial_store = [&](const f32x32 (&cc)[8], int slice, int tile) {
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    float* dst = p.splitk_ws + v2_partial_off(slice, tile, ntiles, wv, 0) + ln * 4;
+#pragma unroll
+    for (int qd = 0; qd < 64; ++qd) {
+      const f32x32& t = cc[qd >> 3];
+      const int e = (qd & 7) * 4;
+      *(f32x4*)(dst + (size_t)qd * 256) = f32x4{agpr_read(t[e]), agpr_read(t[e + 1]), agpr_read(t[e + 2]), agpr_read(t[e + 3])};
+    }
+  };
+
 #if MC_GEMM_V2_PERSIST
   // one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...: the asm statement is one trip; its last two K tiles fetch
   // the first two of the NEXT output tile, which land in the LDS ring under the epilogue below (tools/gen_gemm_v2.py)
@@ -356,16 +385,16 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
   const bool defer = CAN_DEFER && scr != nullptr && p.K >= V2_DEFER_MIN_K;
   bool pend = false;        // a tile's residual update is waiting in the scratch tile
   int pm0 = 0, pn0 = 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    place(tile, m0, n0);
+  for (int tile = blockIdx.x; tile < nunits; tile += gridDim.x) {
+    place(tile, sl, tl, m0, n0);
     const int next_tile = tile + (int)gridDim.x;
-    int nm0 = 0, nn0 = 0;
-    const bool more = next_tile < ntiles;
-    if (more) place(next_tile, nm0, nn0);
-    const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
-    const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
-    const bf16_t* a_next = p.A + (size_t)nm0 * p.lda;
-    const bf16_t* w_next = p.W + (size_t)nn0 * p.ldw;
+    int nm0 = 0, nn0 = 0, nsl = 0, ntl = 0;
+    const bool more = next_tile < nunits;
+    if (more) place(next_tile, nsl, ntl, nm0, nn0);
+    const bf16_t* a_tile = p.A + (size_t)m0 * p.lda + (size_t)sl * Ks;
+    const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw + (size_t)sl * Ks;
+    const bf16_t* a_next = p.A + (size_t)nm0 * p.lda + (size_t)nsl * Ks;
+    const bf16_t* w_next = p.W + (size_t)nn0 * p.ldw + (size_t)nsl * Ks;
     const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
     const uint32_t a_nrec_n = __builtin_amdgcn_readfirstlane(more ? a_nrec_of(nm0) : 0u);
     const uint32_t w_nrec_n = __builtin_amdgcn_readfirstlane(more ? w_nrec_of(nn0) : 0u);
@@ -404,7 +433,9 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     const f32x32 cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
-    if constexpr (LEAN) {   // [abl:epilogue_begin]
+    if constexpr (EPI == EPI_SPLITK_PARTIAL) {   // [abl:epilogue_begin]
+      partial_store(cc, sl, tl);
+    } else if constexpr (LEAN) {
       lean_epilogue(cc, m0, n0, defer, scr);
       if (defer) {
         pend = true;
@@ -419,9 +450,9 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
   // the last trip's "next tile" fetches (zeros: num_records 0) still write the ring: they must not outlive the workgroup
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-  place(blockIdx.x, m0, n0);
-  const bf16_t* a_tile = p.A + (size_t)m0 * p.lda;
-  const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw;
+  place(blockIdx.x, sl, tl, m0, n0);
+  const bf16_t* a_tile = p.A + (size_t)m0 * p.lda + (size_t)sl * Ks;
+  const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw + (size_t)sl * Ks;
   const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
   f32x32 c0, c1, c2, c3, c4, c5, c6, c7;
   asm volatile(
@@ -432,7 +463,8 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
 #include MC_GEMM_V2_CLOBBERS
   );
   const f32x32 cc[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
-  if constexpr (LEAN) lean_epilogue(cc, m0, n0, false, nullptr);
+  if constexpr (EPI == EPI_SPLITK_PARTIAL) partial_store(cc, sl, tl);
+  else if constexpr (LEAN) lean_epilogue(cc, m0, n0, false, nullptr);
   else generic_epilogue(cc);
 #endif
 }
@@ -460,12 +492,36 @@ bf16_t* v2_scratch(hipStream_t stream, int n_wg) {
   return (bf16_t*)pnew;
 }
 
+// ---- split-K, second launch: out = epilogue(sum over slices (index order) + bias).  One block per (tile, wave quadrant):
+// thread = (16 quads, lane) of the partial layout, so every load is a coalesced 16 bytes per lane; the epilogue arithmetic
+// is gemm_epilogue.h's, on the MFMA layout's quads (4 consecutive columns of one row)
 template <int EPI>
-hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M, int slices) {
+  const int ntiles = tilesM * tilesN;
+  const int tile = blockIdx.x >> 2, wave = blockIdx.x & 3;
+  const int lane = threadIdx.x & 63, qg = threadIdx.x >> 6;
+  int sl, tl, m0, n0;
+  v2_place(tile, tilesM, tilesN, GROUP_M, sl, tl, m0, n0);    // tile < ntiles: slice 0, the tile's origin
+  const int wr = wave >> 1, wc = wave & 1;
+  const int mrow = lane & 15, ncol = 4 * (lane >> 4);
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int qd = qg * 16 + j, nb = qd >> 3, mb = qd & 7;
+    const int m = m0 + wr * 128 + mb * 16 + mrow, n = n0 + wc * 128 + nb * 16 + ncol;
+    f32x4 acc = *(const f32x4*)(p.splitk_ws + v2_partial_off(0, tile, ntiles, wave, qd) + lane * 4);
+    for (int s = 1; s < slices; ++s) acc += *(const f32x4*)(p.splitk_ws + v2_partial_off(s, tile, ntiles, wave, qd) + lane * 4);
+    if (m >= p.M) continue;
+    if (p.bias) acc += *(const f32x4*)(p.bias + n);
+    gemm_epilogue_quad<EPI>(p, m, n, acc);
+  }
+}
+
+template <int EPI>
+hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream, int slices = 1) {
   const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
   static std::atomic<uint64_t> lds_ready{0};
   if (hipError_t e = ensure_dynamic_lds((const void*)gemm_v2_kernel<EPI>, V2_LDS_BYTES, lds_ready); e != hipSuccess) return e;
-  int grid = tilesM * tilesN;
+  int grid = tilesM * tilesN * slices;
   bf16_t* scratch = nullptr;
 #if MC_GEMM_V2_PERSIST
   static int n_cu = 0;
@@ -482,7 +538,15 @@ hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream) {
 #endif
 #endif
   hipLaunchKernelGGL((gemm_v2_kernel<EPI>), dim3(grid), dim3(256), V2_LDS_BYTES, stream, p, tilesM, tilesN,
-                     tilesN >= 32 ? 4 : 8, scratch);
+                     tilesN >= 32 ? 4 : 8, scratch, slices);
+  return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t launch_reduce_t(const GemmParams& p, int slices, hipStream_t stream) {
+  const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(tilesM * tilesN * 4), dim3(256), 0, stream, p, tilesM, tilesN,
+                     tilesN >= 32 ? 4 : 8, slices);
   return hipGetLastError();
 }
 
@@ -503,6 +567,55 @@ hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream)
     case EPI_RESID_GATE: return launch_v2_t<EPI_RESID_GATE>(p, stream);
     case EPI_RESID_CAPTURE: return launch_v2_t<EPI_RESID_CAPTURE>(p, stream);
     case EPI_F32: return launch_v2_t<EPI_F32>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---- split-K policy.  A 256 x 256 tile per CU: a problem with T tiles keeps T of the 256 CUs busy for K / 64 K-tile steps.
+// With S slices S T workgroups run K / (64 S) steps each, then one pass over the S T partial tiles (256 KiB each, written and
+// read once).  Worth it when T <= 128 and a slice stays long enough to amortise its prologue and the second launch
+// (K / S >= 2048: 32 K-tile steps ~ 45 us against ~3 us of partial store + ~10 us of reduce).  Shapes that qualify here:
+// the FLUX / small-latent MM-DiT projections back to d (M = 512 .. 1536 rows, N = 3072, K = 12288 / 15360); nothing of the
+// Wan / HunyuanVideo video shapes (thousands of tiles).
+int g_gemm_splitk = 1;
+
+static int splitk_choose(int M, int N, int K, int epi, size_t ws_bytes, bool unlimited) {
+  if (!g_gemm_splitk) return 1;
+  if (!(epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE)) return 1;
+  if (M <= 0 || N <= 0 || (N % TB) != 0) return 1;
+  const long tiles = (long)((M + TB - 1) / TB) * (N / TB);
+  if (tiles > 128 && g_gemm_splitk == 1) return 1;
+  const int smax = g_gemm_splitk > 1 ? g_gemm_splitk : (int)std::min<long>(16, 256 / tiles);
+  for (int s = smax; s >= 2; --s) {
+    if (K % (s * 128) != 0) continue;
+    const int ks = K / s;
+    if (ks < (g_gemm_splitk > 1 ? 256 : 2048)) continue;
+    if (!unlimited && (size_t)s * tiles * TB * TB * sizeof(float) > ws_bytes) continue;
+    return s;
+  }
+  return 1;
+}
+
+int gemm_splitk_slices(const GemmParams& p, int epi) {
+  if (!p.splitk_ws || p.gate_sel || !gemm_bf16_v2_supported(p)) return 1;
+  return splitk_choose(p.M, p.N, p.K, epi, p.splitk_ws_bytes, false);
+}
+
+size_t gemm_splitk_ws_need(int M, int N, int K, int epi) {
+  const int s = splitk_choose(M, N, K, epi, 0, true);
+  return s > 1 ? (size_t)s * ((M + TB - 1) / TB) * (N / TB) * TB * TB * sizeof(float) : 0;
+}
+
+hipError_t launch_gemm_bf16_v2_splitk(const GemmParams& p, int epi, int slices, hipStream_t stream) {
+  if (!gemm_bf16_v2_supported(p) || slices < 2 || !p.splitk_ws || p.K % (slices * 128) != 0 || p.K / slices < 256 ||
+      (size_t)slices * ((p.M + TB - 1) / TB) * (p.N / TB) * TB * TB * sizeof(float) > p.splitk_ws_bytes)
+    return hipErrorInvalidValue;
+  if (hipError_t e = launch_v2_t<EPI_SPLITK_PARTIAL>(p, stream, slices); e != hipSuccess) return e;
+  switch (epi) {
+    case EPI_BF16: return launch_reduce_t<EPI_BF16>(p, slices, stream);
+    case EPI_GELU_BF16: return launch_reduce_t<EPI_GELU_BF16>(p, slices, stream);
+    case EPI_RESID_GATE: return launch_reduce_t<EPI_RESID_GATE>(p, slices, stream);
+    case EPI_RESID_CAPTURE: return launch_reduce_t<EPI_RESID_CAPTURE>(p, slices, stream);
     default: return hipErrorInvalidValue;
   }
 }

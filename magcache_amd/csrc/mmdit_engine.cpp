@@ -149,6 +149,17 @@ struct mc_mmdit {
 
 namespace {
 
+// every GEMM of the engine: the split-K scratch of the stream it runs on rides along (launch_gemm_bf16 decides by shape
+// whether to use it: the projections back to d at FLUX sizes do, nothing at HunyuanVideo's 119 k tokens does)
+hipError_t gemm(const mc_mmdit* e, mc::GemmParams p, int epi, hipStream_t s) {
+  auto it = e->bufs.find((e->side && s == e->side) ? "splitk1" : "splitk0");
+  if (it != e->bufs.end() && it->second.bytes > 0 && e->ws) {
+    p.splitk_ws = reinterpret_cast<float*>(e->ws + it->second.off);
+    p.splitk_ws_bytes = it->second.bytes;
+  }
+  return mc::launch_gemm_bf16(p, epi, s);
+}
+
 template <class T>
 mc_status dev_alloc(mc_mmdit* e, T** p, size_t n) {
   void* q = nullptr;
@@ -381,6 +392,22 @@ mc_status mc_mmdit_create(const mc_mmdit_config* cfg, mc_mmdit** out) {
   add_buf(e, cur, "head_tokens", Li * 64 * 4);
   add_buf(e, cur, "residual0", Sp * d * 4);
   if (c.calibration) add_buf(e, cur, "residual1", Sp * d * 4);
+  {
+    // split-K scratch (gemm_bf16_v2): the largest any GEMM of a block wants, one buffer per stream that may run GEMMs
+    size_t need_all = 0, need_txt = 0;
+    auto upd = [&](size_t& n, int M, int N, int K, int epi) { n = std::max(n, mc::gemm_splitk_ws_need(M, N, K, epi)); };
+    for (int M : {(int)Li, (int)e->Lt, (int)e->S}) {
+      for (size_t* n : {&need_all, M == e->Lt ? &need_txt : &need_all}) {
+        upd(*n, M, 3 * d, d, mc::EPI_BF16);
+        upd(*n, M, d, d, mc::EPI_RESID_GATE);
+        upd(*n, M, 4 * d, d, mc::EPI_GELU_BF16);
+        upd(*n, M, d, 4 * d, mc::EPI_RESID_GATE);
+        upd(*n, M, d, 5 * d, mc::EPI_RESID_GATE);
+      }
+    }
+    if (need_all) add_buf(e, cur, "splitk0", need_all);
+    if (need_txt) add_buf(e, cur, "splitk1", need_txt);
+  }
   add_buf(e, cur, "calib_partial", (2048 * 4 + 2) * 8);   // + the arrival ticket of calib_stats_kernel
   add_buf(e, cur, "calib_sums", 64);
   add_buf(e, cur, "calib_stats", 64);
@@ -572,18 +599,18 @@ mc_status run_refiner(mc_mmdit* e, const float* txt_dev, int txt_valid, float* v
     HIP_TRY(mc::launch_ln_modulate(xt, d, nullptr, 0, r.n1w, r.n1b, 1, 1e-6f, xn, d, nullptr, 0, Lt, d, s));
     mc::GemmParams p = gp(xn, d, r.wqkv, d, r.bqkv, Lt, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    HIP_TRY(gemm(e, p, mc::EPI_BF16, s));
     MC_TRY(joint_attention(e, Ltp, txt_valid, s));
     mc::GemmParams o = gp(am, 5 * d, r.wo, d, r.bo, Lt, d, d);
     o.X = xt; o.ldx = d; o.gate = gates;
-    HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+    HIP_TRY(gemm(e, o, mc::EPI_RESID_GATE, s));
     HIP_TRY(mc::launch_ln_modulate(xt, d, nullptr, 0, r.n2w, r.n2b, 1, 1e-6f, xn, d, nullptr, 0, Lt, d, s));
     mc::GemmParams f1 = gp(xn, d, r.w1, d, r.b1, Lt, 4 * d, d);
     f1.Cb = am + d; f1.ldc = 5 * d;
-    HIP_TRY(mc::launch_gemm_bf16(f1, mc::EPI_SILU_BF16, s));
+    HIP_TRY(gemm(e, f1, mc::EPI_SILU_BF16, s));
     mc::GemmParams f2 = gp(am + d, 5 * d, r.w2, 4 * d, r.b2, Lt, d, 4 * d);
     f2.X = xt; f2.ldx = d; f2.gate = gates + d;
-    HIP_TRY(mc::launch_gemm_bf16(f2, mc::EPI_RESID_GATE, s));
+    HIP_TRY(gemm(e, f2, mc::EPI_RESID_GATE, s));
   }
   return MC_OK;
 }
@@ -600,7 +627,7 @@ mc_status stream_pre_attn(const mc_mmdit* e, const Stream& w, const float* mod, 
     HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, mod + d, mod, 0, 1e-6f, xn, d, nullptr, 0, rows, d, s));
     mc::GemmParams p = gp(xn, d, w.wqkv, d, w.bqkv, rows, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    HIP_TRY(gemm(e, p, mc::EPI_BF16, s));
   }
   if (phases & 2) HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, w.qn, w.kn, 1e-6f, e->cs, row0, rows, e->H, s));
   return MC_OK;
@@ -617,19 +644,19 @@ mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod,
   bf16_t* am = e->buf<bf16_t>("am") + (size_t)row0 * 5 * d;
   mc::GemmParams o = gp(am, 5 * d, w.wo, d, w.bo, rows, d, d);
   o.X = x; o.ldx = d; o.gate = mod + 2 * d;
-  HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+  HIP_TRY(gemm(e, o, mc::EPI_RESID_GATE, s));
   HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, mod + 4 * d, mod + 3 * d, 0, 1e-6f, xn, d, nullptr, 0, rows, d, s));
   mc::GemmParams f1 = gp(xn, d, w.w1, d, w.b1, rows, 4 * d, d);
   f1.Cb = am + d; f1.ldc = 5 * d;
-  HIP_TRY(mc::launch_gemm_bf16(f1, mc::EPI_GELU_BF16, s));
+  HIP_TRY(gemm(e, f1, mc::EPI_GELU_BF16, s));
   mc::GemmParams f2 = gp(am + d, 5 * d, w.w2, 4 * d, w.b2, rows, d, 4 * d);
   f2.X = x; f2.ldx = d; f2.gate = mod + 5 * d;
   if (capture_to) {
     f2.X0 = e->buf<bf16_t>("x0") + (size_t)row0 * d; f2.ldx0 = d;
     f2.R = capture_to + (size_t)row0 * d; f2.ldr = d;
-    HIP_TRY(mc::launch_gemm_bf16(f2, mc::EPI_RESID_CAPTURE, s));
+    HIP_TRY(gemm(e, f2, mc::EPI_RESID_CAPTURE, s));
   } else {
-    HIP_TRY(mc::launch_gemm_bf16(f2, mc::EPI_RESID_GATE, s));
+    HIP_TRY(gemm(e, f2, mc::EPI_RESID_GATE, s));
   }
   return MC_OK;
 }
@@ -725,7 +752,7 @@ mc_status mc_mmdit_begin(mc_mmdit* e, const float* img_dev, double timestep, dou
     }
     mc::GemmParams p = gp(tokens, e->Kp, e->w_in, e->Kp, e->b_in, Li, d, e->Kp);
     p.X = x + (size_t)e->img0 * d; p.ldx = d; p.X0out = x0; p.ldx0out = d; p.m_valid = Li;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
+    HIP_TRY(gemm(e, p, mc::EPI_EMBED, s));
   }
   if (mode != MC_MODE_SKIP) {
     // ---- text embedding -> text rows of x   (flux :314; hunyuan :72-78 incl. the token refiner); replicated per rank
@@ -733,7 +760,7 @@ mc_status mc_mmdit_begin(mc_mmdit* e, const float* img_dev, double timestep, dou
     HIP_TRY(mc::launch_cast_pad_bf16(txt_dev, c.txt_dim, Lt, Lt, c.txt_dim, tin, c.txt_dim, s));
     mc::GemmParams p = gp(tin, c.txt_dim, e->w_ctx, c.txt_dim, e->b_ctx, Lt, d, c.txt_dim);
     p.X = x + (size_t)e->txt0 * d; p.ldx = d; p.X0out = e->buf<bf16_t>("txt_e"); p.ldx0out = d; p.m_valid = Lt;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_EMBED, s));
+    HIP_TRY(gemm(e, p, mc::EPI_EMBED, s));
     if (hy) MC_TRY(run_refiner(e, txt_dev, txt_valid, vecs, s));
   }
   return MC_OK;
@@ -784,10 +811,10 @@ mc_status mc_mmdit_block_pre(mc_mmdit* e, int blk, mc_stream stream_) {
     HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, m + d, m, 0, 1e-6f, xn, d, nullptr, 0, S, d, s));
     mc::GemmParams p = gp(xn, d, g.w_in, d, g.b_in, S, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    HIP_TRY(gemm(e, p, mc::EPI_BF16, s));
     mc::GemmParams q = gp(xn, d, g.w_in + (size_t)3 * d * d, d, g.b_in + 3 * d, S, 4 * d, d);
     q.Cb = am + d; q.ldc = 5 * d;
-    HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_GELU_BF16, s));
+    HIP_TRY(gemm(e, q, mc::EPI_GELU_BF16, s));
     HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, g.qn, g.kn, 1e-6f, e->cs, 0, S, e->H, s));
   }
   if (e->P > 1) {
@@ -890,9 +917,9 @@ mc_status mc_mmdit_block_post(mc_mmdit* e, int blk, mc_stream stream_) {
     o.X = e->buf<float>("x"); o.ldx = d; o.gate = m + 2 * d;
     if (last) {   // MagCache residual capture (flux :428, hunyuan :140); the text rows of R are scratch
       o.X0 = e->buf<bf16_t>("x0"); o.ldx0 = d; o.R = e->residual_joint(e->dst); o.ldr = d;
-      HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_CAPTURE, s));
+      HIP_TRY(gemm(e, o, mc::EPI_RESID_CAPTURE, s));
     } else {
-      HIP_TRY(mc::launch_gemm_bf16(o, mc::EPI_RESID_GATE, s));
+      HIP_TRY(gemm(e, o, mc::EPI_RESID_GATE, s));
     }
   }
   if (last) {

@@ -19,6 +19,7 @@ enum GemmEpi {
   EPI_F32 = 5,           // X = acc + bias (fp32 store)
   EPI_GELU_ERF_BF16 = 6, // Cb = bf16(gelu_erf(bf16(acc + bias)))   (128x128 kernel only)
   EPI_SILU_BF16 = 7,     // Cb = bf16(silu(bf16(acc + bias)))       (128x128 kernel only; HunyuanVideo token refiner)
+  EPI_SPLITK_PARTIAL = 9,// (internal, gemm_bf16_v2 split-K) the fp32 accumulators of one K slice of a tile -> splitk_ws
   EPI_GELU_MXFP8 = 8,    // as 1, then MX-quantised in the epilogue: Cq = e4m3 bytes, c_mx = E8M0 block scales -- the A
                          // operand of the next MX GEMM, the bits launch_quantize_rows_mx would make of Cb (gemm_mxfp8 only)
 };
@@ -38,6 +39,11 @@ struct GemmParams {
   // per-token modulation (Wan2.2 TI2V: two timestep values per forward): rows with gate_sel[m] != 0 use gate2
   const float* gate2;
   const uint8_t* gate_sel;
+  // split-K scratch (gemm_bf16_v2 only, optional): when a shape's 256 x 256 tiles fill less than half of the CUs and K is
+  // long, launch_gemm_bf16 cuts K into S slices, every (tile, slice) workgroup parks its fp32 accumulators here and a second
+  // launch sums the slices in index order and applies the epilogue (deterministic; not bit-identical to the unsplit sum).
+  // null / too small: no split.  Must not be shared by GEMMs that may run concurrently.
+  float* splitk_ws; size_t splitk_ws_bytes;
   // fp8 GEMM (launch_gemm_fp8): A / W point to OCP e4m3 bytes, C = (A W^T) * a_scale[m] * w_scale[n] + bias
   const float* a_scale;
   const float* w_scale;
@@ -58,6 +64,12 @@ bool gemm_bf16_big_supported(const GemmParams& p);
 hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream);     // 256x256 tiles, 4 waves, generated stream
 bool gemm_bf16_v2_supported(const GemmParams& p);
 extern int g_gemm_defer;   // (libraries whose gemm_v2 stream was generated with --defer 1 only; the shipped one is not) 0: epilogues in place
+// split-K (gemm_bf16_v2.hip): slices launch_gemm_bf16 would cut this problem's K into (1 = no split) given p.splitk_ws_bytes;
+// bytes of scratch the split it would choose with unlimited scratch needs (0 = it would not split)
+int gemm_splitk_slices(const GemmParams& p, int epi);
+size_t gemm_splitk_ws_need(int M, int N, int K, int epi);
+hipError_t launch_gemm_bf16_v2_splitk(const GemmParams& p, int epi, int slices, hipStream_t stream);
+extern int g_gemm_splitk;  // mc_set_option("gemm_splitk"): 1 = by shape (default), 0 = never, 2..16 = force that many slices where valid
 extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported, 4: generation 2 where supported
 // fp8 (e4m3) operands, 256x256 tiles, v_mfma_f32_32x32x64_f8f6f4; K (fp8 elements) a multiple of 256
 hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);

@@ -119,7 +119,7 @@ class Engine:
         self.sp_rank, self.sp_size, self.n_branches = sp_rank, sp_size, n_branches
         self.vace_layers, self.vace_stride = vace_geometry(cfg)
         h = C.c_void_p()
-        check(self.lib.mc_create(C.byref(c), C.byref(h)))
+        check(self.lib.mc_create_sized(C.byref(c), C.sizeof(c), C.byref(h)))
         self.h = h
         nbytes = self.lib.mc_workspace_bytes(self.h)
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)

@@ -207,7 +207,9 @@ class WanModelHIP:
                     raise ValueError(f"per-token timesteps with {n} distinct values: the engine supports at most two "
                                      "per forward (Wan2.2 TI2V: conditioning frame + the step's t)")
                 self._tok_t_key = _tensor_key(t)
+            self.check_token_timesteps(block=False)       # the record of an EARLIER trusted forward, if it has arrived
             self.engine.set_token_timesteps(tv)
+            self._tok_trusted = trusted
             t = tv[-1:]
         elif hasattr(self.engine, "set_token_timesteps"):
             self.engine.set_token_timesteps(None)
@@ -224,7 +226,34 @@ class WanModelHIP:
             out = self._sp.forward(lat, t, ctx, branch, mode)
         else:
             out = self.engine.forward(lat, t, ctx, branch=branch, mode=mode)
+        if getattr(self, "_tok_trusted", False):
+            # a tensor that skipped the value check: fetch the engine's own count of tokens carrying NEITHER of the two
+            # timesteps it modulated with -- asynchronously (pinned buffer + event, no sync here); it is looked at when it
+            # has arrived (next per-token forward) and, blocking, by check_token_timesteps() at the end of sampling
+            self._tok_trusted = False
+            if getattr(self, "_tok_rec", None) is None:
+                self._tok_rec = torch.zeros(3, dtype=torch.float32).pin_memory()
+                self._tok_ev = torch.cuda.Event()
+            self._tok_rec.copy_(self.engine.buffer("tok_t2", torch.float32)[:3], non_blocking=True)
+            self._tok_ev.record()
+            self._tok_pending = True
         return [out.float()]
+
+    def check_token_timesteps(self, block=True):
+        """Raise if a forward that was TRUSTED to carry at most two distinct per-token timesteps (t._mc_two_valued,
+        MAGCACHE_VALIDATE_TOKEN_T=0) did not: the engine counted tokens that were neither max t nor min t (it modulated
+        them as one of the two).  block=False only looks if the record has already arrived."""
+        if not getattr(self, "_tok_pending", False):
+            return
+        if block:
+            self._tok_ev.synchronize()
+        elif not self._tok_ev.query():
+            return
+        self._tok_pending = False
+        tmax, tmin, neither = (float(v) for v in self._tok_rec)
+        if neither > 0:
+            raise ValueError(f"per-token timesteps: {int(neither)} tokens carried neither t = {tmax:g} nor t = {tmin:g} in a "
+                             "forward whose tensor was tagged two-valued (the engine supports at most two distinct values)")
 
     def __call__(self, *args, **kwargs):
         # dispatch through the CLASS attribute so that `Model.__class__.forward = fn` takes effect,

@@ -290,4 +290,6 @@ def sample_ti2v(model, noise, context, context_null, sampling_steps=50, shift=5.
         latent = fs.step(i, latent, v)
         if mask_tok is not None:
             latent = (1.0 - mask_lat) * z + mask_lat * latent
+    if hasattr(model, "check_token_timesteps"):
+        model.check_token_timesteps()            # the vouched-for `mask * t` really was two-valued in every forward
     return latent

@@ -28,6 +28,7 @@ class CpuShardEngine:
         self.res = [None, None]
         self.stats = [None, None]
         self._has = [False, False]
+        self.log = []            # call order: ("pre" | "local" | "post", layer)
 
     def buffer(self, name, dtype=None):
         return self.bufs[name]
@@ -50,6 +51,7 @@ class CpuShardEngine:
             self.ctx = kw["context"]
 
     def block_pre_attn(self, layer):
+        self.log.append(("pre", layer))
         b = self.o.blocks[layer]
         n, dh = self.o.num_heads, self.o.dim // self.o.num_heads
         with torch.no_grad():
@@ -65,8 +67,22 @@ class CpuShardEngine:
 
     def block_attn_local(self, layer):
         self.local_calls = getattr(self, "local_calls", 0) + 1   # the stand-in attends all shards in post_attn
+        self.log.append(("local", layer))
+
+    def blocks_sp(self, layer_begin, layer_end, branch, mode, overlap, gather):
+        """mc_blocks_sp restated (csrc/engine.cpp): the call order the C loop issues, with the same callback protocol"""
+        for layer in range(layer_begin, layer_end):
+            self.block_pre_attn(layer)
+            gather(layer, 0)
+            if not overlap:
+                gather(layer, 1)
+            self.block_attn_local(layer)
+            if overlap:
+                gather(layer, 1)
+            self.block_post_attn(layer, branch, mode)
 
     def block_post_attn(self, layer, branch, mode):
+        self.log.append(("post", layer))
         b = self.o.blocks[layer]
         o = self.o
         n, dh, d = o.num_heads, o.dim // o.num_heads, o.dim

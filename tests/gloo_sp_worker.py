@@ -31,7 +31,23 @@ def main():
     ctx = torch.randn(9, cfg["text_dim"], generator=g)
     e = CpuShardEngine(oracle, grid, rank, world)
     sp = SequenceParallelForward(e)
-    full = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()
+    # the gather's position in the call order: wrap it into the engine's log
+    real_gather = sp._all_gather_kv
+
+    def logged_gather():
+        e.log.append(("gather",))
+        return real_gather()
+    sp._all_gather_kv = logged_gather
+    from magcache_amd import parallel as PAR
+    assert PAR.SP_C_LOOP and hasattr(e, "blocks_sp")
+    full = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()       # one blocks_sp call + callbacks
+    log_c, e.log = e.log, []
+    PAR.SP_C_LOOP = False
+    full_phase = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()  # three engine calls per layer
+    log_p, e.log = e.log, []
+    PAR.SP_C_LOOP = True
+    want_log = [x for l in range(cfg["num_layers"]) for x in (("pre", l), ("gather",), ("local", l), ("post", l))]
+    order_ok = log_c == want_log and log_p == want_log and bool(torch.equal(full, full_phase))
     skip = sp.forward(lat * 1.01, 650.0, ctx, 0, MC_MODE_SKIP).clone()
     sp.forward(lat, 700.0, ctx, 1, MC_MODE_CALIB)
     sp.forward(lat * 0.9, 600.0, ctx, 1, MC_MODE_CALIB)
@@ -53,7 +69,7 @@ def main():
     want = MR.calibration_stats(mc2.residual_cache[1], r_prev)
     rel = lambda a, b: float((a - b).norm() / b.norm())
     # k/v travel as bf16 through the gather buffer (as in the engine): tolerance 1e-2, not 1e-6
-    res = dict(rank=rank, rel_full=rel(full, f1), rel_skip=rel(skip, s1),
+    res = dict(rank=rank, order_ok=order_ok, rel_full=rel(full, f1), rel_skip=rel(skip, s1),
                calib_err=max(abs(a - b) for a, b in zip(e.stats[1], want)))
     gathered = [None] * world
     dist.all_gather_object(gathered, res)

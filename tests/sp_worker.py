@@ -43,6 +43,25 @@ def main():
     sp.forward(lat * 0.9, 600.0, ctx, 1, MC_MODE_CALIB)
     stats = e.calib_stats(1)
     res = e.residual(0).clone()
+    # the layer loop in ONE engine call (mc_blocks_sp, the default) == the same phases issued one by one from Python
+    from magcache_amd import parallel as PAR
+    assert PAR.SP_C_LOOP
+    PAR.SP_C_LOOP = False
+    full_by_phase = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()
+    PAR.SP_C_LOOP = True
+    c_loop_equal = bool(torch.equal(full, full_by_phase))
+    # an exception inside the gather callback surfaces as that exception, the engine stays usable
+    def boom():
+        raise RuntimeError("gather failed on purpose")
+    real = sp._all_gather_kv
+    sp._all_gather_kv = boom
+    try:
+        sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL)
+        cb_error = "no exception"
+    except RuntimeError as ex:
+        cb_error = str(ex)
+    sp._all_gather_kv = real
+    again_equal = bool(torch.equal(sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL), full))
     torch.cuda.synchronize()
     gathered = [torch.zeros_like(res.cpu()) for _ in range(world)]
     dist.all_gather(gathered, res.cpu())
@@ -76,6 +95,7 @@ def main():
         e1.forward(lat * 0.9, 600.0, ctx, 1, MC_MODE_CALIB)
         st1 = e1.calib_stats(1)
         out = dict(rel_full=rel(full, f1), rel_skip=rel(skip, s1), rel_vace=rel_vace,
+                   c_loop_equal=c_loop_equal, cb_error=cb_error, again_equal=again_equal,
                    rel_calib=max(abs(a - b) for a, b in zip(stats, st1)),
                    rel_residual=rel(torch.cat(gathered), e1.residual(0).cpu()), stats=stats, stats1=st1)
         json.dump(out, open(a.out, "w"))

@@ -393,6 +393,10 @@ def test_sequence_parallel_two_ranks_one_gpu(tmp_path):
     assert res["rel_skip"] < 3e-3, res
     assert res["rel_calib"] < 1e-4, res
     assert res["rel_vace"] < 3e-3, res          # VACE control blocks under sequence parallelism
+    # one mc_blocks_sp call per forward == the phase-by-phase sequence, bit for bit; a failing collective inside the callback
+    # comes back as its own exception and the next forward is right again
+    assert res["c_loop_equal"] and res["again_equal"], res
+    assert res["cb_error"] == "gather failed on purpose", res
 
 
 def test_generate_entry_point_short_run(tmp_path):
@@ -655,6 +659,20 @@ def test_wan22_ti2v_per_token_timesteps_vs_reference_golden(golden_dir):
     e_hip, e_bf = rel_l2(got.cpu(), ref32), rel_l2(refbf, ref32)
     assert e_hip < 2 * e_bf + 1e-3 and e_hip < 2e-2, (e_hip, e_bf)
     assert m.engine.token_timestep_record() == (float(ts[0]), 0.0, 0)                     # (iii)
+    # (iii b) a tensor TAGGED two-valued skips the up-front value check; when the tag lies, the engine's own record is read
+    # back lazily and the lie surfaces at check_token_timesteps() -- and an honest tag passes
+    bad = (mask * float(ts[0])).unsqueeze(0).clone()
+    bad[0, -3:] = 123.0                                   # a third value
+    bad._mc_two_valued = True
+    m([lat], t=bad, context=[ctx], seq_len=L)
+    with pytest.raises(ValueError, match="neither"):
+        m.check_token_timesteps()
+    with pytest.raises(ValueError, match="distinct values"):        # untagged: refused before anything runs
+        m([lat], t=bad.clone(), context=[ctx], seq_len=L)
+    good = (mask * float(ts[0])).unsqueeze(0).clone()
+    good._mc_two_valued = True
+    m([lat], t=good, context=[ctx], seq_len=L)
+    m.check_token_timesteps()
     # (iv) scalar t == uniform per-token t
     a = m([lat], t=torch.tensor([float(ts[2])], device=DEV), context=[ctx], seq_len=L)[0].clone()
     b = m([lat], t=torch.full((1, L), float(ts[2]), device=DEV), context=[ctx], seq_len=L)[0]

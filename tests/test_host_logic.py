@@ -32,6 +32,21 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.mc_version()
 
 
+def test_splitk_policy_is_host_arithmetic():
+    """the split-K policy (gemm_bf16_v2.hip splitk_choose) through the C ABI, no GPU: no scratch -> never; the scratch the
+    policy asks for matches slices x tiles x 256 KiB; the video shapes of Wan / HunyuanVideo never split"""
+    lib = _lib.load()
+    for M, N, K in [(1536, 3072, 15360), (1024, 3072, 12288), (512, 3072, 12288), (32768, 1536, 8960)]:
+        assert lib.mc_op_gemm_bf16_splitk(M, N, K, 2) == 1               # no scratch set in this process
+    tiles = lambda M, N: ((M + 255) // 256) * (N // 256)               # noqa: E731
+    assert lib.mc_op_gemm_splitk_need(1536, 3072, 15360, 2) == 3 * tiles(1536, 3072) * 256 * 256 * 4
+    assert lib.mc_op_gemm_splitk_need(1024, 3072, 12288, 2) == 4 * tiles(1024, 3072) * 256 * 256 * 4
+    assert lib.mc_op_gemm_splitk_need(512, 3072, 12288, 3) == 6 * tiles(512, 3072) * 256 * 256 * 4
+    for M, N, K, epi in [(32768, 1536, 8960, 2), (32768, 4608, 1536, 0), (75600, 5120, 13824, 2), (119056, 3072, 15360, 2),
+                         (1536, 3072, 3072, 2), (1536, 3072, 15360, 5), (1536, 3000, 15360, 2)]:
+        assert lib.mc_op_gemm_splitk_need(M, N, K, epi) == 0, (M, N, K, epi)
+
+
 def test_product_sources_carry_no_wrong_result_switches():
     """The timing ablations that make a kernel WRONG on purpose live in the A/B builders (source transforms on a copy:
     tools/build_gemm_v2_variants.py ablate(); generator options of gen_attention_v5.py), not behind -D macros in the shipped
@@ -101,9 +116,9 @@ def test_c_rule_rejects_bad_arguments():
 def test_set_option_validates_keys_and_values():
     """mc_set_option is host state only (no GPU): every documented key takes its documented values and nothing else."""
     lib = _lib.load()
-    ok = {b"gemm_kernel": (0, 1, 2, 4), b"attn_kernel": (0, 3, 5), b"mmdit_two_streams": (-1, 0, 1, 2, 6), b"gemm_defer": (0, 1),
+    ok = {b"gemm_splitk": (0, 1, 2, 16), b"gemm_kernel": (0, 1, 2, 4), b"attn_kernel": (0, 3, 5), b"mmdit_two_streams": (-1, 0, 1, 2, 6), b"gemm_defer": (0, 1),
           b"fp8_fused_quant": (0, 1)}
-    bad = {b"gemm_kernel": (-1, 3, 5, 9), b"attn_kernel": (1, 2, 4, 6), b"mmdit_two_streams": (-2, 7), b"gemm_defer": (-1, 2),
+    bad = {b"gemm_splitk": (-1, 17), b"gemm_kernel": (-1, 3, 5, 9), b"attn_kernel": (1, 2, 4, 6), b"mmdit_two_streams": (-2, 7), b"gemm_defer": (-1, 2),
            b"fp8_fused_quant": (-1, 2)}
     try:
         for key, vals in ok.items():
@@ -116,6 +131,7 @@ def test_set_option_validates_keys_and_values():
         assert lib.mc_set_option(b"no_such_option", 0) == _lib.MC_EINVAL
         assert lib.mc_set_option(None, 0) == _lib.MC_EINVAL
     finally:
+        lib.mc_set_option(b"gemm_splitk", 1)
         lib.mc_set_option(b"gemm_kernel", 0)
         lib.mc_set_option(b"attn_kernel", 0)
         lib.mc_set_option(b"mmdit_two_streams", 0)

@@ -393,6 +393,91 @@ def test_gemm_v2_full_shape_epilogues_rows(N, K, epi):
     assert lib.mc_op_gemm_bf16_kernel(M, N, K, 0 if epi == "bf16" else 1 if epi == "gelu" else 2) == 4
 
 
+@pytest.fixture
+def splitk_ws():
+    """scratch for the single-op entry point's split-K path (the engines carry their own in their workspace)"""
+    lib = _lib.load()
+    ws = torch.empty(96 << 20, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.mc_op_set_splitk_workspace(H.P(ws), ws.numel()))
+    yield ws
+    _lib.check(lib.mc_op_set_splitk_workspace(None, 0))
+    _lib.check(lib.mc_set_option(b"gemm_splitk", 1))
+
+
+@pytest.mark.parametrize("M,N,K,want_slices", [(1536, 3072, 15360, 3), (1024, 3072, 12288, 4), (512, 3072, 12288, 6),
+                                               (1536, 3072, 3072, 1), (1000, 3072, 12288, 4), (32768, 1536, 8960, 1)],
+                         ids=["flux-single-out", "flux-img-mlp2", "flux-txt-mlp2", "flux-o-no-split", "ragged-M", "wan-ffn2-no-split"])
+def test_gemm_splitk_by_shape(M, N, K, want_slices, splitk_ws):
+    """Split-K (gemm_bf16_v2 + the reduce launch) under the SHIPPED policy at the FLUX.1 512x512 shapes it exists for
+    (reference call sites: MagCache4FLUX/magcache_flux.py:342-426, the projections back to d of a double / single block):
+    the policy picks the documented slice counts and nothing for the shapes it should leave alone; all four epilogues it
+    serves against the fp64 product with test_gemm_bf16_epilogues' tolerances; the result is deterministic (slices summed in
+    index order) and agrees with the unsplit kernel to fp32 summation-order noise."""
+    lib = _lib.load()
+    assert lib.mc_op_gemm_bf16_splitk(M, N, K, 2) == want_slices
+    if want_slices == 1:
+        assert lib.mc_op_gemm_splitk_need(M, N, K, 2) == 0
+        return
+    assert 0 < lib.mc_op_gemm_splitk_need(M, N, K, 2) <= splitk_ws.numel()
+    A = rnd(M, K, seed=31, dtype=torch.bfloat16)
+    Wt = rnd(N, K, seed=32, scale=0.02, dtype=torch.bfloat16)
+    bias = rnd(N, seed=33)
+    gate = rnd(N, seed=35)
+    ref = (A.double() @ Wt.double().t() + bias.double()).float()
+    x_in = rnd(M, N, seed=34)
+    X0 = rnd(M, N, seed=36, dtype=torch.bfloat16)
+
+    def run_all():
+        cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        H.gemm(A, Wt, bias, 0, Cb=cb)
+        cg = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        H.gemm(A, Wt, bias, 1, Cb=cg)
+        xr = x_in.clone()
+        H.gemm(A, Wt, bias, 2, X=xr, gate=gate)
+        xc, R = x_in.clone(), torch.zeros(M, N, device=DEV)
+        H.gemm(A, Wt, bias, 3, X=xc, gate=gate, X0=X0, R=R)
+        return cb, cg, xr, xc, R
+    cb, cg, xr, xc, R = run_all()
+    atol_k = math.sqrt(K / 1536)
+    torch.testing.assert_close(cb.float(), ref, rtol=1e-2, atol=1e-2)
+    assert rel_l2(cb, ref) < 4e-3
+    torch.testing.assert_close(cg.float(), F.gelu(ref.bfloat16().float(), approximate="tanh"), rtol=2e-2, atol=2e-2)
+    want = x_in + ref.bfloat16().float() * gate
+    torch.testing.assert_close(xr, want, rtol=1e-2, atol=2e-2 * atol_k)
+    assert rel_l2(xr - x_in, want - x_in) < 4e-3
+    assert torch.equal(xc, xr) and torch.equal(R, xc - X0.float())            # capture: exact, one fp32 subtraction
+    again = run_all()
+    for a, b in zip((cb, cg, xr, xc, R), again):
+        assert torch.equal(a, b)                                               # deterministic
+    _lib.check(lib.mc_set_option(b"gemm_splitk", 0))
+    assert lib.mc_op_gemm_bf16_splitk(M, N, K, 2) == 1
+    unsplit = run_all()
+    # same products, another fp32 summation order: bf16 outputs differ by at most one rounding step on a few elements
+    assert rel_l2(cb, unsplit[0]) < 1e-3 and rel_l2(xr - x_in, unsplit[2] - x_in) < 1e-3
+    torch.testing.assert_close(cb.float(), unsplit[0].float(), rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("slices", [2, 3, 8])
+def test_gemm_splitk_forced_slices_small_shapes(slices, splitk_ws):
+    """every slice count on small problems, incl. a ragged last M tile and a single tile (gemm_splitk = N forces N slices
+    wherever K divides): fp32-store-free check through the bf16 and gated-residual epilogues"""
+    lib = _lib.load()
+    _lib.check(lib.mc_set_option(b"gemm_splitk", slices))
+    for M, N, K in [(256, 256, 128 * slices * 2), (300, 512, 128 * slices * 3), (77, 768, 128 * slices * 2)]:
+        assert lib.mc_op_gemm_bf16_splitk(M, N, K, 0) == slices, (M, N, K)
+        A = rnd(M, K, seed=41, dtype=torch.bfloat16)
+        Wt = rnd(N, K, seed=42, scale=0.05, dtype=torch.bfloat16)
+        bias = rnd(N, seed=43)
+        ref = (A.double() @ Wt.double().t() + bias.double()).float()
+        cb = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        H.gemm(A, Wt, bias, 0, Cb=cb)
+        torch.testing.assert_close(cb.float(), ref, rtol=1e-2, atol=1e-2)
+        x_in = rnd(M, N, seed=44)
+        x = x_in.clone()
+        H.gemm(A, Wt, bias, 2, X=x, gate=None)
+        torch.testing.assert_close(x, x_in + ref.bfloat16().float(), rtol=1e-2, atol=2e-2)
+
+
 # ----------------------------------------------------------------------------- attention
 def attn_ref(q, k, v, n_heads, valid_idx):
     Lq = q.shape[0]
@@ -491,6 +576,26 @@ def test_attention_strided_qkv_and_online_softmax_rescale(attn_variant, gain, q_
     H.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, heads, L, L - 3, 1, 1 / math.sqrt(128))
     want = attn_ref(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], heads, torch.arange(L - 3, device=DEV))
     torch.testing.assert_close(o.float(), want, rtol=2e-2, atol=2e-2)
+
+
+def test_attention_output_rows_not_16_byte_aligned_take_the_fallback_kernel():
+    """attention_v5 writes O as whole rows with 16-byte stores: an output whose row stride is 4 (mod 8) elements, or whose base
+    is only 8-byte aligned, is outside its contract and must run on attention_v3 -- same result either way."""
+    Lq, heads, keys = 512, 2, 320
+    d = heads * 128
+    q = rnd(Lq, d, seed=1, dtype=torch.bfloat16)
+    k = rnd(keys, d, seed=2, dtype=torch.bfloat16)
+    v = rnd(keys, d, seed=3, dtype=torch.bfloat16)
+    want = attn_ref(q, k, v, heads, torch.arange(300, device=DEV))
+    o_ok = torch.zeros(Lq, d, dtype=torch.bfloat16, device=DEV)
+    H.attention(q, k, v, o_ok, heads, keys, 300, 1, 1 / math.sqrt(128))
+    wide = torch.zeros(Lq, d + 4, dtype=torch.bfloat16, device=DEV)             # ldo % 8 == 4
+    H.attention(q, k, v, wide[:, :d], heads, keys, 300, 1, 1 / math.sqrt(128))
+    shifted = torch.zeros(Lq * d + 8, dtype=torch.bfloat16, device=DEV)[4:4 + Lq * d].view(Lq, d)   # base 8 (mod 16) bytes
+    H.attention(q, k, v, shifted, heads, keys, 300, 1, 1 / math.sqrt(128))
+    for got in (o_ok, wide[:, :d], shifted):
+        assert rel_l2(got, want) < 6e-3
+    assert float(wide[:, d:].abs().max()) == 0.0
 
 
 def test_attention_full_shape_properties():

@@ -21,6 +21,9 @@ def test_sequence_parallel_orchestration_gloo(tmp_path):
         assert x["rel_full"] < 1e-2, x
         assert x["rel_skip"] < 1e-2, x
         assert x["calib_err"] < 1e-3, x
+        # the layer loop as ONE engine call with gather callbacks (mc_blocks_sp's protocol, restated by the stand-in) issues
+        # pre -> gather -> local -> post per layer exactly like the phase-by-phase loop, and gives the same bits
+        assert x["order_ok"], x
 
 
 import pytest  # noqa: E402

@@ -109,6 +109,8 @@ DEFAULT_CFG = {
                              # instruction): 14.5 us of a 512-key launch (kbench_attn_fixed_cost_abl.log).  Needs nst >= 4.
     "merge_rows": 1,         # (two-phase attention, with epi_lds) the earlier launch's result is fetched as whole rows through
                              # the strip as well (it was 32 per-lane 8-byte loads per wave, each touching 32 rows)
+    "dma_mod": "",           # cache-policy bits on the LDS-DMA loads of K / V / Q tiles: "" (default), "nt", "sc1" (agent scope: no L1
+                             # allocation; a tile is read once per workgroup, its reuse is in L2 across the head's 128 workgroups)
     "final_wait": 0,         # s_waitcnt vmcnt(0) behind the last store (the wave ends right after the asm statement; stores
                              # in flight at s_endpgm complete on their own)
 }
@@ -439,7 +441,7 @@ def combine_lanes(M, x, op):
 def dma_piece(M, op, j):
     """1 KiB piece j of this wave's 4 for operand op: rows 16 wv + 4 j .. +3 of the tile; M0 = this wave's 4 KiB of the slot"""
     src, srd, cur = (M.V_SRCK, S_KSRD, S_KCUR) if op == "K" else (M.V_SRCV, S_VSRD, S_VCUR)
-    return f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(cur)} offen offset:{1024 * j} lds"
+    return f"buffer_load_dwordx4 {v(src + j)}, {s(srd, 4)}, {s(cur)} offen offset:{1024 * j}{DMA_MOD} lds"
 
 
 def cursor_advance(E, op):
@@ -1212,7 +1214,7 @@ def emit_prologue(E):
             E.i(f"s_add_u32 m0, {s(S_LDSW)}, {(nst + w) * TILE}")
             E.i("s_nop 0")
             for j in range(4):
-                E.i(f"buffer_load_dwordx4 {v(v_srcq + j)}, {s(S_QSRD, 4)}, {s(S_VSLOT)} offen offset:{1024 * j} lds")
+                E.i(f"buffer_load_dwordx4 {v(v_srcq + j)}, {s(S_QSRD, 4)}, {s(S_VSLOT)} offen offset:{1024 * j}{DMA_MOD} lds")
             if w < 3:
                 E.i(f"s_add_u32 {s(S_VSLOT)}, {s(S_VSLOT)}, {s(S_RET)}")
     else:
@@ -1605,8 +1607,13 @@ def emit_vote(E):
     E.i("s_branch L_restart")
 
 
+DMA_MOD = ""                 # cfg "dma_mod" of the stream being generated (set by generate)
+
+
 def generate(cfg=None):
+    global DMA_MOD
     cfg = full_cfg(cfg)
+    DMA_MOD = (" " + str(cfg["dma_mod"]).replace("+", " ")) if cfg["dma_mod"] else ""
     nst = cfg["nst"]
     U = nst * 2 // math.gcd(nst, 2)
     assert cfg["ahead"] >= 1 and cfg["ahead"] + 2 <= nst + 1, "ring too shallow for this prefetch distance"
@@ -1706,7 +1713,7 @@ def parse_overrides(items):
     cfg = {}
     for it in items or []:
         k, val = it.split("=", 1)
-        if k == "abl":
+        if k in ("abl", "dma_mod"):
             cfg[k] = val
             continue
         cfg[k] = [int(x) for x in val.split(",")] if k == "dma_at" else (float(val) if "." in val else int(val))
