@@ -53,6 +53,51 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def pmc_traffic_live(timeout_s=120):
+    """HBM bytes per self-attention launch measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE -- the TCC
+    block cannot hold both in one pass; --kernel-trace only, no other trace domain, as the MI355X guide prescribes) over
+    tools/kbench.bin attn1 (the bench's self-attention shape through the C ABI, torch-free) in a child process.  Units: the
+    counters are in KiB; FETCH_SIZE is taken at 1.00x -- calibrated on this access pattern in profiles/r01/pmc_traffic.json
+    (a 201 MB streaming read in the same pass read 1.00x), not the guide's generic x2.  Returns (bytes, detail dict) or
+    (None, reason).  MC_BENCH_PMC=0 skips it."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("MC_BENCH_PMC", "1") == "0":
+        return None, "MC_BENCH_PMC=0"
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    kbench = os.path.join(ROOT, "tools", "kbench.bin")
+    lib = os.path.join(ROOT, "magcache_amd", "libmagcache_hip.so")
+    if not (os.path.exists(prof) and os.path.exists(kbench)):
+        return None, "rocprofv3 or tools/kbench.bin missing"
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mc_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                                kbench, "attn1", "1", "2", lib], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                               capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if "attn_fwd_v5_kernel" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    tot += float(row["Counter_Value"])
+                    n += 1
+            if n == 0:
+                return None, f"no attn_fwd_v5_kernel rows for {ctr}"
+            out[ctr] = (tot / n, n)
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+            return None, f"{ctr}: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    by = (out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0]) * 1024.0
+    return by, {"fetch_kib": out["FETCH_SIZE"][0], "write_kib": out["WRITE_SIZE"][0], "dispatches": out["FETCH_SIZE"][1]}
+
+
 def timed(fn, sync, barrier):
     barrier()
     sync()
@@ -363,6 +408,7 @@ def bench_main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernels", action="store_true")
     ap.add_argument("--no_nocache", action="store_true", help="skip the second (cache off) timed region")
+    ap.add_argument("--no_table", action="store_true", help="skip the back-to-back per-kernel table (1 s pre-heat per kernel)")
     ap.add_argument("--fp8_linear", type=int, nargs="?", const=1, default=0, choices=(0, 1, 2, 3),
                     help="OPTIONAL precision mode, never the headline: QKV / FFN Linears on an fp8 e4m3 MFMA path "
                          "(1: per-row / per-channel scales, 2: MX block scales, 3: MX for the d x d Linears of a block too)")
@@ -592,7 +638,12 @@ def bench_main():
         }
         line.update(extra)
         if world == 1 and not args.no_kernels:
-            k = kernel_rooflines(cfg, device)
+            if args.no_table:        # (A/B runs: tools/live_ab.sh) only the live figures
+                tr, tr_src = pmc_traffic("attn_fwd_v5_kernel")
+                k = {"attention_back_to_back": dict(bound="mfma", achieved=None, peak=2500.0, unit="TFLOP/s", frac=None, traffic=tr,
+                                                    traffic_source=f"committed PMC pass, not this run: {tr_src}")}
+            else:
+                k = kernel_rooflines(cfg, device)
             line["roofline"] = {kk: k["attention_back_to_back"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic",
                                                                   "traffic_source")}
             if attn_live and attn_live[1] > 0:
@@ -605,7 +656,16 @@ def bench_main():
                                         measured="hipEvent pairs around every self-attention launch of the timed "
                                                  "no-cache region (mc_profile_read)")
             line["roofline"]["kernel"] = "attn_fwd_v5_kernel (self-attention, 71% of forward FLOPs)"
-            line["kernels"] = k
+            by, detail = pmc_traffic_live()
+            if by is not None:
+                line["roofline"].update(traffic=by, traffic_detail=detail, traffic_source=(
+                    "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over "
+                    "tools/kbench.bin attn1 in a child process, KiB x 1024, FETCH_SIZE at the 1.00x calibrated in "
+                    "profiles/r01/pmc_traffic.json; algorithmic bytes 402653184"))
+            else:
+                line["roofline"]["traffic_source"] += f" (live PMC pass unavailable: {detail})"
+            if not args.no_table:
+                line["kernels"] = k
             if live:
                 line["kernels_live"] = kernels_live(cfg, *live)
         if world > 1 and attn_live and attn_live[1] > 0:

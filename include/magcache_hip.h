@@ -85,11 +85,13 @@ const char* mc_version(void);
 /* Process-wide tuning knobs (no reference counterpart; results are identical for every setting up to fp32 summation
  * order, bit-identical where noted).
  *   "gemm_kernel"   0 = chosen by shape (default): gemm_bf16_v2.hip -- 256x256 tile, 4 waves x (128 x 128), one wave per
- *                   SIMD, generated instruction stream, persistent over output tiles -- for the bf16 / GELU / gated-residual
- *                   epilogues of shapes with K >= 1024 whose tile count suits 256-tiles; the 8-wave 256x256 kernel
- *                   (gemm_bf16_big.hip) for the per-token-gate, residual-capture, embed and fp32 epilogues; the 128x128
- *                   kernel for everything else.  1 = the 128x128 kernel everywhere, 2 = the 8-wave 256x256 kernel wherever
- *                   it applies, 4 = gemm_bf16_v2 wherever it applies.  All three give the same bits.
+ *                   SIMD, generated instruction stream, persistent over output tiles -- for every epilogue of shapes with
+ *                   K >= 1024 whose tile count suits 256-tiles (bf16 / GELU / gated residual incl. the MagCache residual
+ *                   capture and per-token gates as lean row-major epilogues, bf16 | GELU with two destinations, fp32 store);
+ *                   the 128x128 kernel for everything else (small or odd shapes, K < 1024, the embed epilogues).
+ *                   1 = the 128x128 kernel everywhere, 2 = the 8-wave 256x256 kernel (gemm_bf16_big.hip) wherever it
+ *                   applies -- since round 5 only reachable this way: the independent implementation the parity tests
+ *                   and A/B runs compare gemm_bf16_v2 with --, 4 = gemm_bf16_v2 wherever it applies.  All give the same bits.
  *   "gemm_splitk"   1 (default) = split-K by shape (see mc_op_set_splitk_workspace below), 0 = never, 2..16 = that many
  *                   slices wherever K divides (parity tests).
  *   "gemm_defer"    no effect in the shipped library.  (A/B libraries whose gemm_bf16_v2 stream was generated with
@@ -285,6 +287,20 @@ mc_status mc_op_gemm_bf16(const void* A_dev, long lda, const void* W_dev, long l
                           int N, int K, int epi, void* Cb_dev, long ldc, float* X_dev, long ldx,
                           const float* gate_dev, const void* X0_dev, long ldx0, float* R_dev, long ldr,
                           void* X0out_dev, long ldx0out, int m_valid, mc_stream stream);
+/* the gated-residual epilogues with PER-TOKEN gates (Wan2.2 TI2V: two timesteps per forward, mc_set_token_timesteps):
+ * X[m] += (gate_sel[m] ? gate2 : gate) * bf16(acc + bias); capture != 0: and R = X_new - X0 (MagCache residual capture,
+ * MagCache4Wan2.2/magcache_generate.py:309-322).  gate_sel: one byte per row. */
+mc_status mc_op_gemm_bf16_resid_sel(const void* A_dev, long lda, const void* W_dev, long ldw, const float* bias_dev, int M,
+                                    int N, int K, int capture, float* X_dev, long ldx, const float* gate_dev,
+                                    const float* gate2_dev, const unsigned char* gate_sel_dev, const void* X0_dev, long ldx0,
+                                    float* R_dev, long ldr, mc_stream stream);
+/* two Linears over the same rows as one launch: columns [0, n_split) -> Cb = bf16(acc + bias), columns [n_split, N) ->
+ * Cb2[m][n - n_split] = bf16(gelu_tanh(bf16(acc + bias))) (the single block of an MM-DiT: q|k|v and MLP-in,
+ * MagCache4FLUX/magcache_flux.py:389-421 calls it through diffusers' FluxSingleTransformerBlock).  One gemm_bf16_v2 launch
+ * where that kernel serves the shape, otherwise the two launches it replaces -- the same bits either way. */
+mc_status mc_op_gemm_bf16_gelu_split(const void* A_dev, long lda, const void* W_dev, long ldw, const float* bias_dev, int M,
+                                     int N, int K, int n_split, void* Cb_dev, long ldc, void* Cb2_dev, long ldc2,
+                                     mc_stream stream);
 /* which kernel mc_op_gemm_bf16 (and the engine) runs for this problem under the current "gemm_kernel" option: 1 = the 128x128
  * kernel, 2 = the 8-wave 256x256 kernel, 4 = gemm_bf16_v2; 0 = the shape is rejected.  (lda = ldw = K, ldc / ldx = N.) */
 int mc_op_gemm_bf16_kernel(int M, int N, int K, int epi);

@@ -84,6 +84,8 @@ SIGNATURES = {
     "mc_nearest_interp": (None, [C.POINTER(_d), _i, C.POINTER(_d), _i]),
     "mc_op_gemm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l,
                              _i, _vp]),
+    "mc_op_gemm_bf16_resid_sel": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp]),
+    "mc_op_gemm_bf16_gelu_split": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
     "mc_op_gemm_bf16_kernel": (_i, [_i, _i, _i, _i]),
     "mc_op_gemm_bf16_splitk": (_i, [_i, _i, _i, _i]),
     "mc_op_gemm_splitk_need": (_sz, [_i, _i, _i, _i]),

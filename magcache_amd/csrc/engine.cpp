@@ -1431,6 +1431,30 @@ mc_status mc_op_gemm_bf16(const void* A, long lda, const void* W, long ldw, cons
   return MC_OK;
 }
 
+mc_status mc_op_gemm_bf16_resid_sel(const void* A, long lda, const void* W, long ldw, const float* bias, int M, int N, int K,
+                                    int capture, float* X, long ldx, const float* gate, const float* gate2,
+                                    const unsigned char* gate_sel, const void* X0, long ldx0, float* R, long ldr, mc_stream s) {
+  mc::GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, M, N, K);
+  p.X = X; p.ldx = ldx; p.gate = gate; p.gate2 = gate2; p.gate_sel = gate_sel;
+  p.X0 = (const bf16_t*)X0; p.ldx0 = ldx0; p.R = R; p.ldr = ldr;
+  if (!gate || !gate2 || !gate_sel) return fail(MC_EINVAL, "gemm (per-token gates): gate, gate2 and gate_sel are required");
+  hipError_t err = mc::launch_gemm_bf16(p, capture ? mc::EPI_RESID_CAPTURE : mc::EPI_RESID_GATE, (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "gemm (per-token gates): unsupported shape M=%d N=%d K=%d", M, N, K);
+  HIP_TRY(err);
+  return MC_OK;
+}
+
+mc_status mc_op_gemm_bf16_gelu_split(const void* A, long lda, const void* W, long ldw, const float* bias, int M, int N, int K,
+                                     int n_split, void* Cb, long ldc, void* Cb2, long ldc2, mc_stream s) {
+  mc::GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, M, N, K);
+  p.Cb = (bf16_t*)Cb; p.ldc = ldc; p.n_split = n_split; p.Cb2 = (bf16_t*)Cb2; p.ldc2 = ldc2;
+  hipError_t err = mc::launch_gemm_bf16(p, mc::EPI_BF16_GELU_SPLIT, (hipStream_t)s);
+  if (err == hipErrorInvalidValue)
+    return fail(MC_EINVAL, "gemm (bf16 | gelu split): unsupported shape M=%d N=%d K=%d n_split=%d", M, N, K, n_split);
+  HIP_TRY(err);
+  return MC_OK;
+}
+
 int mc_op_gemm_bf16_kernel(int M, int N, int K, int epi) {
   mc::GemmParams p = gp(nullptr, K, nullptr, K, nullptr, M, N, K);
   p.ldc = N; p.ldx = N;

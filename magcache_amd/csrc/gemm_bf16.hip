@@ -253,15 +253,30 @@ int gemm_bf16_kernel_for(const GemmParams& p, int epi) {
   // epilogues wherever the 8-wave kernel would run: +16 % QKV, +17 % cross-attention Q, +9 % O + residual, +3.5 % FFN-1,
   // +1.7 % FFN-2 in one interleaved run (profiles/r04/kbench_gemm_v2h_lean.log), bit-identical results.  gemm_kernel = 4
   // forces it for every epilogue it has (the others run its generic, slow epilogue code), 2 forces the 8-wave kernel.
-  const bool v2_epi = epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE;
-  if (gemm_bf16_v2_supported(p) &&
-      ((g_gemm_kernel == 0 && big && v2_epi) ||
-       (g_gemm_kernel == 4 && (v2_epi || epi == EPI_RESID_CAPTURE || epi == EPI_F32))))
-    return 4;
+  // Round 5: the residual-capture epilogue and the per-token gates (Wan2.2 TI2V) are lean epilogues of gemm_bf16_v2 too, and
+  // the (cold) fp32 store takes its generic epilogue: the by-shape dispatch no longer launches the 8-wave kernel at all --
+  // gemm_bf16_big.hip stays in the library as gemm_kernel = 2, the independent implementation the parity tests and A/B runs
+  // compare gemm_bf16_v2 with bit for bit.
+  const bool v2_epi = epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE ||
+                      epi == EPI_BF16_GELU_SPLIT || epi == EPI_F32;
+  if (gemm_bf16_v2_supported(p) && v2_epi && ((g_gemm_kernel == 0 && big) || g_gemm_kernel == 4)) return 4;
   return big ? 2 : 1;
 }
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+  if (epi == EPI_BF16_GELU_SPLIT && gemm_bf16_kernel_for(p, epi) != 4) {
+    // only gemm_bf16_v2 has the two-destination epilogue: everywhere else the two Linears run as two launches (same bits)
+    if (p.n_split <= 0 || p.n_split >= p.N || (p.n_split % 4) != 0 || !p.Cb2) return hipErrorInvalidValue;
+    GemmParams a = p, b = p;
+    a.N = p.n_split;
+    b.W = p.W + (size_t)p.n_split * p.ldw;
+    b.bias = p.bias ? p.bias + p.n_split : nullptr;
+    b.N = p.N - p.n_split;
+    b.Cb = p.Cb2;
+    b.ldc = p.ldc2;
+    if (hipError_t e = launch_gemm_bf16(a, EPI_BF16, stream); e != hipSuccess) return e;
+    return launch_gemm_bf16(b, EPI_GELU_BF16, stream);
+  }
   // few tiles, long K, scratch at hand: K in slices on gemm_bf16_v2 + one reduce launch (policy: gemm_bf16_v2.hip)
   if (g_gemm_kernel == 0 || g_gemm_kernel == 4) {
     const int slices = gemm_splitk_slices(p, epi);

@@ -117,12 +117,19 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
   auto w_nrec_of = [&](int tn0) { return (uint32_t)min((size_t)(p.N - tn0) * ldw_b - (size_t)(p.ldw - Ks) * 2, (size_t)0xffffff00u); };
   const int nk = Ks / 32;
   const uint32_t lds0 = (uint32_t)(uintptr_t)MC_LDS_PTR(smem);
-  constexpr bool LEAN = MC_GEMM_V2_MFMA == 16 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RESID_GATE);
+  // residual forms: x += gate * bf16(acc + bias); CAPTURE: and R = x_new - ori_x (the MagCache residual, last layer's FFN-2);
+  // SEL: the gate vector is chosen per row (gate_sel[m] ? gate2 : gate -- Wan2.2 TI2V's two timesteps per forward)
+  constexpr bool CAPTURE = EPI == EPI_RESID_CAPTURE || EPI == EPI_RESID_CAPTURE_SEL;
+  constexpr bool SEL = EPI == EPI_RESID_GATE_SEL || EPI == EPI_RESID_CAPTURE_SEL;
+  constexpr bool RESID = EPI == EPI_RESID_GATE || CAPTURE || SEL;
+  constexpr bool LEAN = MC_GEMM_V2_MFMA == 16 && (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || RESID || EPI == EPI_BF16_GELU_SPLIT);
   constexpr bool CAN_DEFER = MC_GEMM_V2_PERSIST && MC_GEMM_V2_SCHED_H && MC_GEMM_V2_DEFER && EPI == EPI_RESID_GATE;
 
   // ---- the lean epilogues.  to_scratch false: this tile's own epilogue (bf16 / GELU store, or x += gate * value right
   //      here); true: bf16 values into the workgroup's scratch tile (the residual update follows in the next trip's main loop)
-  auto lean_epilogue = [&](const f32x32 (&cc)[8], int tm0, int tn0, bool to_scratch, bf16_t* scr) {
+  // (gelu_tag: std::true_type = GELU on the values; fixed by EPI except for EPI_BF16_GELU_SPLIT, where the tile's column decides)
+  auto lean_epilogue_t = [&](auto gelu_tag, const f32x32 (&cc)[8], int tm0, int tn0, bool to_scratch, bf16_t* scr) {
+    constexpr bool GELU = decltype(gelu_tag)::value;
     // nothing lane-dependent lives across the asm statement: lane ids are recomputed here
     const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int l15 = ln & 15, g4 = ln >> 4, rr = ln >> 4, c16 = ln & 15;
@@ -152,15 +159,16 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     // writes and reads.
     char* strip = smem + V2_RING_BYTES + wv * V2_STRIP_BYTES;
     const uint32_t wr_off = (uint32_t)(l15 * 272 + g4 * 8), rd_off = (uint32_t)(rr * 272 + c16 * 16);
-    const bool resid_here = EPI == EPI_RESID_GATE && !to_scratch;
-    f32x4 gA = {1.f, 1.f, 1.f, 1.f}, gB = gA;      // residual form: gate of columns 8 c16 .. + 7
-    __amdgpu_buffer_rsrc_t rio;
-    uint32_t vio, row_b;
-    if (EPI == EPI_RESID_GATE && to_scratch) {
+    const bool resid_here = RESID && !to_scratch;
+    f32x4 gA = {1.f, 1.f, 1.f, 1.f}, gB = gA;      // residual form: gate of columns 4 c16 .. + 3 and 64 + 4 c16 .. + 3
+    f32x4 gA2 = gA, gB2 = gA;                        // SEL: the second gate vector
+    __amdgpu_buffer_rsrc_t rio, rx0, rres;
+    uint32_t vio, row_b, v0 = 0, row0_b = 0, vres = 0, rowr_b = 0;
+    if (RESID && to_scratch) {
       row_b = TB * 2u;
       rio = __builtin_amdgcn_make_buffer_rsrc((void*)scr, 0, TB * TB * 2, 0x00020000);
       vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 2u;
-    } else if (EPI == EPI_RESID_GATE) {
+    } else if (RESID) {
       // lane -> columns 4 c16 .. + 3 and 64 + 4 c16 .. + 3 of the wave's 128: every x load / store instruction then covers 256
       // CONTIGUOUS bytes of a row (two whole 128-byte lines), instead of 16 bytes out of every 32 over all four lines
       if (p.gate) {
@@ -168,12 +176,36 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
         gA = *(const f32x4*)gp;
         gB = *(const f32x4*)(gp + 64);
       }
+      if constexpr (SEL) {
+        if (p.gate) {
+          const float* gp = p.gate2 + tn0 + wc_ * 128 + c16 * 4;
+          gA2 = *(const f32x4*)gp;
+          gB2 = *(const f32x4*)(gp + 64);
+        }
+      }
       row_b = (uint32_t)p.ldx * 4u;
       rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (size_t)tm0 * p.ldx + tn0), 0, rows * row_b, 0x00020000);
       vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 4) * 4u;
+      rx0 = rres = rio;          // (only read when CAPTURE)
+      if constexpr (CAPTURE) {   // ori_x (bf16) in, R (fp32) out: the same rows and column quads
+        row0_b = (uint32_t)p.ldx0 * 2u;
+        rx0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X0 + (size_t)tm0 * p.ldx0 + tn0), 0, rows * row0_b, 0x00020000);
+        v0 = (uint32_t)(wr_ * 128 + rr) * row0_b + (uint32_t)(wc_ * 128 + c16 * 4) * 2u;
+        rowr_b = (uint32_t)p.ldr * 4u;
+        rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + (size_t)tm0 * p.ldr + tn0), 0, rows * rowr_b, 0x00020000);
+        vres = (uint32_t)(wr_ * 128 + rr) * rowr_b + (uint32_t)(wc_ * 128 + c16 * 4) * 4u;
+      }
     } else {
-      row_b = (uint32_t)p.ldc * 2u;
-      rio = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cb + (size_t)tm0 * p.ldc + tn0), 0, rows * row_b, 0x00020000);
+      bf16_t* cb = p.Cb;
+      long ldc = p.ldc;
+      int tn = tn0;
+      if constexpr (EPI == EPI_BF16_GELU_SPLIT && GELU) {      // the GELU half has its own destination
+        cb = p.Cb2;
+        ldc = p.ldc2;
+        tn = tn0 - p.n_split;
+      }
+      row_b = (uint32_t)ldc * 2u;
+      rio = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + (size_t)tm0 * ldc + tn), 0, rows * row_b, 0x00020000);
       vio = (uint32_t)(wr_ * 128 + rr) * row_b + (uint32_t)(wc_ * 128 + c16 * 8) * 2u;
     }
     // (row offsets live in the VGPR offset, which the hardware range-checks together with the immediate: rows past M are
@@ -182,12 +214,20 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     constexpr int XA = 1, XS = XA + 1;           // m blocks of x loaded ahead (2, 3, 5 measured: no faster)
     constexpr uint32_t X2_OFF = 256u;            // byte distance of the lane's second quad of x
     f32x4 xin[XS][4][2];
+    u32x2 x0in[CAPTURE ? XS : 1][4][2];        // CAPTURE: ori_x quads of the same rows
+    uint32_t selin[SEL ? XS : 1][4];           // SEL: gate_sel of the lane's 4 rows of the m block
     auto load_x = [&](int mb, int set) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const uint32_t vrow = vio + (uint32_t)(mb * 16 + 4 * i) * row_b;
         xin[set][i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow, 0, 0));           // [abl:x_load]
         xin[set][i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rio, vrow + X2_OFF, 0, 0));  // [abl:x_load]
+        if constexpr (CAPTURE) {
+          const uint32_t v0row = v0 + (uint32_t)(mb * 16 + 4 * i) * row0_b;
+          x0in[set][i][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx0, v0row, 0, 0));
+          x0in[set][i][1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx0, v0row + 128u, 0, 0));
+        }
+        if constexpr (SEL) selin[set][i] = p.gate_sel[min(tm0 + wr_ * 128 + mb * 16 + 4 * i + rr, p.M - 1)];
       }
     };
     if (resid_here) {
@@ -204,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
         f32x4 val = acc_quad(mb, nb) + bq[nb];
-        if constexpr (EPI == EPI_GELU_BF16) {
+        if constexpr (GELU) {
           const f32x2 y0 = gelu_tanh_fast2(bf16_round2(val[0], val[1])), y1 = gelu_tanh_fast2(bf16_round2(val[2], val[3]));
           val = f32x4{y0[0], y0[1], y1[0], y1[1]};
         }
@@ -228,21 +268,49 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
           // x[row][8 c16 .. + 7] += gate * bf16 value (the Linear's output was rounded to bf16 above, like autocast)
           f32x4 xa = xin[mb % XS][i][0], xb = xin[mb % XS][i][1];
           const u32x4 w = rowv[i];
-          xa[0] += __uint_as_float(w[0] << 16) * gA[0];
-          xa[1] += __uint_as_float(w[0] & 0xffff0000u) * gA[1];
-          xa[2] += __uint_as_float(w[1] << 16) * gA[2];
-          xa[3] += __uint_as_float(w[1] & 0xffff0000u) * gA[3];
-          xb[0] += __uint_as_float(w[2] << 16) * gB[0];
-          xb[1] += __uint_as_float(w[2] & 0xffff0000u) * gB[1];
-          xb[2] += __uint_as_float(w[3] << 16) * gB[2];
-          xb[3] += __uint_as_float(w[3] & 0xffff0000u) * gB[3];
+          f32x4 ga = gA, gb = gB;
+          if constexpr (SEL) {
+            if (selin[mb % XS][i]) {
+              ga = gA2;
+              gb = gB2;
+            }
+          }
+          xa[0] += __uint_as_float(w[0] << 16) * ga[0];
+          xa[1] += __uint_as_float(w[0] & 0xffff0000u) * ga[1];
+          xa[2] += __uint_as_float(w[1] << 16) * ga[2];
+          xa[3] += __uint_as_float(w[1] & 0xffff0000u) * ga[3];
+          xb[0] += __uint_as_float(w[2] << 16) * gb[0];
+          xb[1] += __uint_as_float(w[2] & 0xffff0000u) * gb[1];
+          xb[2] += __uint_as_float(w[3] << 16) * gb[2];
+          xb[3] += __uint_as_float(w[3] & 0xffff0000u) * gb[3];
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xa), rio, vrow, 0, 0);            // [abl:x_store]
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xb), rio, vrow + X2_OFF, 0, 0);   // [abl:x_store]
+          if constexpr (CAPTURE) {   // MagCache residual capture (reference magcache_generate.py:299): R = x_out - ori_x
+            const u32x2 oa = x0in[mb % XS][i][0], ob = x0in[mb % XS][i][1];
+            const f32x4 ra = {xa[0] - __uint_as_float(oa[0] << 16), xa[1] - __uint_as_float(oa[0] & 0xffff0000u),
+                              xa[2] - __uint_as_float(oa[1] << 16), xa[3] - __uint_as_float(oa[1] & 0xffff0000u)};
+            const f32x4 rb_ = {xb[0] - __uint_as_float(ob[0] << 16), xb[1] - __uint_as_float(ob[0] & 0xffff0000u),
+                               xb[2] - __uint_as_float(ob[1] << 16), xb[3] - __uint_as_float(ob[1] & 0xffff0000u)};
+            const uint32_t vr = vres + (uint32_t)(mb * 16 + 4 * i) * rowr_b;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ra), rres, vr, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rb_), rres, vr + X2_OFF, 0, 0);
+          }
         } else {
           __builtin_amdgcn_raw_buffer_store_b128(rowv[i], rio, vrow, 0, 0);   // [abl:c_store]
         }
       }
       if (resid_here) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  auto lean_epilogue = [&](const f32x32 (&cc)[8], int tm0, int tn0, bool to_scratch, bf16_t* scr) {
+    if constexpr (EPI == EPI_GELU_BF16) {
+      lean_epilogue_t(std::true_type{}, cc, tm0, tn0, to_scratch, scr);
+    } else if constexpr (EPI == EPI_BF16_GELU_SPLIT) {
+      if (tn0 >= p.n_split) lean_epilogue_t(std::true_type{}, cc, tm0, tn0, to_scratch, scr);
+      else lean_epilogue_t(std::false_type{}, cc, tm0, tn0, to_scratch, scr);
+    } else {
+      lean_epilogue_t(std::false_type{}, cc, tm0, tn0, to_scratch, scr);
     }
   };
 
@@ -369,12 +437,17 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
   // ---- split-K: this (slice, tile)'s accumulators leave in their own layout, one coalesced 1 KiB store per quad and wave
   auto partial_store = [&](const f32x32 (&cc)[8], int slice, int tile) {
     const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    float* dst = p.splitk_ws + v2_partial_off(slice, tile, ntiles, wv, 0) + ln * 4;
+    // this wave's 64 KiB of the scratch through one descriptor: lane offset in the VGPR, the quad's 1 KiB in the scalar
+    // offset (64 per-quad 64-bit addresses would cost 128 VGPRs)
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.splitk_ws + v2_partial_off(slice, tile, ntiles, wv, 0)), 0, 64 * 1024, 0x00020000);
+    const uint32_t vl = (uint32_t)ln * 16u;
 #pragma unroll
     for (int qd = 0; qd < 64; ++qd) {
       const f32x32& t = cc[qd >> 3];
       const int e = (qd & 7) * 4;
-      *(f32x4*)(dst + (size_t)qd * 256) = f32x4{agpr_read(t[e]), agpr_read(t[e + 1]), agpr_read(t[e + 2]), agpr_read(t[e + 3])};
+      const f32x4 val = {agpr_read(t[e]), agpr_read(t[e + 1]), agpr_read(t[e + 2]), agpr_read(t[e + 3])};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rp, vl, qd * 1024, 0);
     }
   };
 
@@ -492,27 +565,55 @@ bf16_t* v2_scratch(hipStream_t stream, int n_wg) {
   return (bf16_t*)pnew;
 }
 
-// ---- split-K, second launch: out = epilogue(sum over slices (index order) + bias).  One block per (tile, wave quadrant):
-// thread = (16 quads, lane) of the partial layout, so every load is a coalesced 16 bytes per lane; the epilogue arithmetic
-// is gemm_epilogue.h's, on the MFMA layout's quads (4 consecutive columns of one row)
+// ---- split-K, second launch: out = epilogue(sum over slices (index order) + bias).  One block per (tile, wave quadrant,
+// 16 of its 64 quads): a thread owns 4 quads of the partial layout (every load a coalesced 16 bytes per lane), loads all
+// their slices and -- residual forms -- their x quads FIRST, then adds and stores (gemm_epilogue.h's arithmetic on the MFMA
+// layout's quads: 4 consecutive columns of one row).  tiles x 16 blocks: enough waves per CU to cover the L2 / HBM latency
+// (the first version, 4 blocks per tile and 16 serial quads per thread, ran at 2.8 TB/s: 34 us for FLUX's 72 x 3 partials).
+constexpr int RQ = 4;    // quads per thread
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M, int slices) {
   const int ntiles = tilesM * tilesN;
-  const int tile = blockIdx.x >> 2, wave = blockIdx.x & 3;
+  const int tile = blockIdx.x >> 4, wave = (blockIdx.x >> 2) & 3, chunk = blockIdx.x & 3;
   const int lane = threadIdx.x & 63, qg = threadIdx.x >> 6;
   int sl, tl, m0, n0;
   v2_place(tile, tilesM, tilesN, GROUP_M, sl, tl, m0, n0);    // tile < ntiles: slice 0, the tile's origin
   const int wr = wave >> 1, wc = wave & 1;
   const int mrow = lane & 15, ncol = 4 * (lane >> 4);
-#pragma unroll 4
-  for (int j = 0; j < 16; ++j) {
-    const int qd = qg * 16 + j, nb = qd >> 3, mb = qd & 7;
-    const int m = m0 + wr * 128 + mb * 16 + mrow, n = n0 + wc * 128 + nb * 16 + ncol;
-    f32x4 acc = *(const f32x4*)(p.splitk_ws + v2_partial_off(0, tile, ntiles, wave, qd) + lane * 4);
-    for (int s = 1; s < slices; ++s) acc += *(const f32x4*)(p.splitk_ws + v2_partial_off(s, tile, ntiles, wave, qd) + lane * 4);
-    if (m >= p.M) continue;
-    if (p.bias) acc += *(const f32x4*)(p.bias + n);
-    gemm_epilogue_quad<EPI>(p, m, n, acc);
+  const int qd0 = chunk * 16 + qg * RQ;
+  f32x4 acc[RQ];
+  int mm[RQ], nn[RQ];
+#pragma unroll
+  for (int j = 0; j < RQ; ++j) {
+    const int qd = qd0 + j, nb = qd >> 3, mb = qd & 7;
+    mm[j] = m0 + wr * 128 + mb * 16 + mrow;
+    nn[j] = n0 + wc * 128 + nb * 16 + ncol;
+    acc[j] = *(const f32x4*)(p.splitk_ws + v2_partial_off(0, tile, ntiles, wave, qd) + lane * 4);
+  }
+  for (int s = 1; s < slices; ++s) {
+#pragma unroll
+    for (int j = 0; j < RQ; ++j) acc[j] += *(const f32x4*)(p.splitk_ws + v2_partial_off(s, tile, ntiles, wave, qd0 + j) + lane * 4);
+  }
+  if constexpr (EPI == EPI_RESID_GATE || EPI == EPI_RESID_CAPTURE) {
+    ResidIn in[RQ];
+    f32x4 gt[RQ];
+#pragma unroll
+    for (int j = 0; j < RQ; ++j) {
+      const int ml = min(mm[j], p.M - 1);
+      in[j] = resid_load<EPI>(p, ml, nn[j]);
+      gt[j] = p.gate ? *(const f32x4*)(p.gate + nn[j]) : f32x4{1.f, 1.f, 1.f, 1.f};
+      if (p.bias) acc[j] += *(const f32x4*)(p.bias + nn[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RQ; ++j)
+      if (mm[j] < p.M) resid_apply<EPI>(p, mm[j], nn[j], acc[j], gt[j], in[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < RQ; ++j) {
+      if (mm[j] >= p.M) continue;
+      if (p.bias) acc[j] += *(const f32x4*)(p.bias + nn[j]);
+      gemm_epilogue_quad<EPI>(p, mm[j], nn[j], acc[j]);
+    }
   }
 }
 
@@ -545,7 +646,7 @@ hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream, int slices = 1) 
 template <int EPI>
 hipError_t launch_reduce_t(const GemmParams& p, int slices, hipStream_t stream) {
   const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
-  hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(tilesM * tilesN * 4), dim3(256), 0, stream, p, tilesM, tilesN,
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(tilesM * tilesN * 16), dim3(256), 0, stream, p, tilesM, tilesN,
                      tilesN >= 32 ? 4 : 8, slices);
   return hipGetLastError();
 }
@@ -553,8 +654,7 @@ hipError_t launch_reduce_t(const GemmParams& p, int slices, hipStream_t stream) 
 }  // namespace
 
 bool gemm_bf16_v2_supported(const GemmParams& p) {
-  // (the per-row gate selection of Wan2.2 TI2V stays with the 8-wave kernel: the lean residual epilogue has one gate vector)
-  return !p.gate_sel && p.M > 0 && p.N > 0 && (p.N % TB) == 0 && (p.K % 128) == 0 && p.K >= 256 && (p.lda % 8) == 0 &&
+  return p.M > 0 && p.N > 0 && (p.N % TB) == 0 && (p.K % 128) == 0 && p.K >= 256 && (p.lda % 8) == 0 &&
          (p.ldw % 8) == 0 && (size_t)p.M * (size_t)p.lda < (1ull << 31) && (size_t)p.N * (size_t)p.ldw < (1ull << 31) &&
          (size_t)TB * (size_t)std::max(p.ldx, p.ldc) * 4 < (1ull << 31);
 }
@@ -564,9 +664,15 @@ hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream)
   switch (epi) {
     case EPI_BF16: return launch_v2_t<EPI_BF16>(p, stream);
     case EPI_GELU_BF16: return launch_v2_t<EPI_GELU_BF16>(p, stream);
-    case EPI_RESID_GATE: return launch_v2_t<EPI_RESID_GATE>(p, stream);
-    case EPI_RESID_CAPTURE: return launch_v2_t<EPI_RESID_CAPTURE>(p, stream);
+    case EPI_RESID_GATE: return p.gate_sel ? launch_v2_t<EPI_RESID_GATE_SEL>(p, stream) : launch_v2_t<EPI_RESID_GATE>(p, stream);
+    case EPI_RESID_CAPTURE:
+      if (!p.X0 || !p.R || (size_t)TB * (size_t)p.ldr * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+      return p.gate_sel ? launch_v2_t<EPI_RESID_CAPTURE_SEL>(p, stream) : launch_v2_t<EPI_RESID_CAPTURE>(p, stream);
     case EPI_F32: return launch_v2_t<EPI_F32>(p, stream);
+    case EPI_BF16_GELU_SPLIT:
+      if (p.n_split <= 0 || p.n_split >= p.N || (p.n_split % TB) != 0 || !p.Cb2 || (size_t)TB * (size_t)p.ldc2 * 4 >= (1ull << 31))
+        return hipErrorInvalidValue;
+      return launch_v2_t<EPI_BF16_GELU_SPLIT>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -809,12 +809,13 @@ mc_status mc_mmdit_block_pre(mc_mmdit* e, int blk, mc_stream stream_) {
     bf16_t* xn = e->buf<bf16_t>("xn");
     bf16_t* am = e->buf<bf16_t>("am");
     HIP_TRY(mc::launch_ln_modulate(x, d, nullptr, 0, m + d, m, 0, 1e-6f, xn, d, nullptr, 0, S, d, s));
-    mc::GemmParams p = gp(xn, d, g.w_in, d, g.b_in, S, 3 * d, d);
+    // linear1 of the single block = [q | k | v ; MLP-in] over the same rows: ONE launch with two destinations (the q|k|v
+    // columns to "qkv", the GELU'd MLP columns to "am"[:, d:]) -- 504 tiles at FLUX 512^2 are two trips of the 256 CUs, the
+    // two launches were 216 + 288 = one + two
+    mc::GemmParams p = gp(xn, d, g.w_in, d, g.b_in, S, 7 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
-    HIP_TRY(gemm(e, p, mc::EPI_BF16, s));
-    mc::GemmParams q = gp(xn, d, g.w_in + (size_t)3 * d * d, d, g.b_in + 3 * d, S, 4 * d, d);
-    q.Cb = am + d; q.ldc = 5 * d;
-    HIP_TRY(gemm(e, q, mc::EPI_GELU_BF16, s));
+    p.n_split = 3 * d; p.Cb2 = am + d; p.ldc2 = 5 * d;
+    HIP_TRY(gemm(e, p, mc::EPI_BF16_GELU_SPLIT, s));
     HIP_TRY(mc::launch_headnorm_rope(qkv, 3 * d, d, g.qn, g.kn, 1e-6f, e->cs, 0, S, e->H, s));
   }
   if (e->P > 1) {

@@ -19,6 +19,11 @@ enum GemmEpi {
   EPI_F32 = 5,           // X = acc + bias (fp32 store)
   EPI_GELU_ERF_BF16 = 6, // Cb = bf16(gelu_erf(bf16(acc + bias)))   (128x128 kernel only)
   EPI_SILU_BF16 = 7,     // Cb = bf16(silu(bf16(acc + bias)))       (128x128 kernel only; HunyuanVideo token refiner)
+  EPI_BF16_GELU_SPLIT = 10, // columns [0, n_split): Cb = bf16(acc + bias); columns [n_split, N): Cb2[m][n - n_split] =
+                         // bf16(gelu_tanh(bf16(acc + bias))) -- two Linears over the same rows as ONE launch (the single block's
+                         // q|k|v and MLP-in of an MM-DiT: 216 + 288 tiles are 2 + 2 trips of 256 CUs apart, 2 together)
+  EPI_RESID_GATE_SEL = 11,    // (internal, gemm_bf16_v2) EPI_RESID_GATE / _CAPTURE with per-row gates: the launcher picks them
+  EPI_RESID_CAPTURE_SEL = 12, // when gate_sel != null, so that the form without per-token gates keeps its code
   EPI_SPLITK_PARTIAL = 9,// (internal, gemm_bf16_v2 split-K) the fp32 accumulators of one K slice of a tile -> splitk_ws
   EPI_GELU_MXFP8 = 8,    // as 1, then MX-quantised in the epilogue: Cq = e4m3 bytes, c_mx = E8M0 block scales -- the A
                          // operand of the next MX GEMM, the bits launch_quantize_rows_mx would make of Cb (gemm_mxfp8 only)
@@ -44,6 +49,8 @@ struct GemmParams {
   // launch sums the slices in index order and applies the epilogue (deterministic; not bit-identical to the unsplit sum).
   // null / too small: no split.  Must not be shared by GEMMs that may run concurrently.
   float* splitk_ws; size_t splitk_ws_bytes;
+  // EPI_BF16_GELU_SPLIT: first GELU column (a multiple of 256) and the GELU half's destination
+  int n_split; bf16_t* Cb2; long ldc2;
   // fp8 GEMM (launch_gemm_fp8): A / W point to OCP e4m3 bytes, C = (A W^T) * a_scale[m] * w_scale[n] + bias
   const float* a_scale;
   const float* w_scale;

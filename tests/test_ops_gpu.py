@@ -33,7 +33,8 @@ def kernel_variant(request):
     """Every GEMM test runs with the 128x128 kernel forced, with the 8-wave 256x256 counted-vmcnt kernel
     (gemm_bf16_big.hip) forced wherever the shape allows, with the 4-wave 256x256 kernel (generated stream,
     gemm_bf16_v2.hip) forced wherever ITS shape and epilogue rules allow, and with the shipped by-shape dispatch (which
-    picks gemm_bf16_v2 for the bf16 / GELU / gated-residual epilogues of large shapes since round 4)."""
+    picks gemm_bf16_v2 for every epilogue of large shapes -- since round 5 also the residual capture, per-token gates and the
+    fp32 store: the 8-wave kernel is reachable through gemm_kernel = 2 only)."""
     lib = _lib.load()
     _lib.check(lib.mc_set_option(b"gemm_kernel", request.param))
     yield request.param
@@ -476,6 +477,77 @@ def test_gemm_splitk_forced_slices_small_shapes(slices, splitk_ws):
         x = x_in.clone()
         H.gemm(A, Wt, bias, 2, X=x, gate=None)
         torch.testing.assert_close(x, x_in + ref.bfloat16().float(), rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 1536, 8960), (1000, 768, 1024), (300, 512, 512)],
+                         ids=["wan-ffn2-full-shape", "ragged", "small"])
+def test_gemm_resid_capture_and_per_token_gates_all_kernels(M, N, K):
+    """The residual-capture epilogue (last layer's FFN-2: MagCache's R = x_out - ori_x, reference :297-301) and the per-token
+    gate selection (Wan2.2 TI2V) on every kernel that has them -- since round 5 gemm_bf16_v2 (lean epilogues: what the
+    by-shape dispatch runs), the 8-wave kernel (gemm_kernel = 2: the independent reference) and the 128^2 kernel: against the
+    fp64 product, R == X_new - X0 exactly, and the same bits from all of them."""
+    lib = _lib.load()
+    A = rnd(M, K, seed=61, dtype=torch.bfloat16)
+    Wt = rnd(N, K, seed=62, scale=0.03, dtype=torch.bfloat16)
+    bias = rnd(N, seed=63)
+    gate, gate2 = rnd(N, seed=64), rnd(N, seed=65)
+    sel = (torch.arange(M, device=DEV) % 7 < 3).to(torch.uint8)       # both values inside every 16-row block
+    x_in = rnd(M, N, seed=66)
+    X0 = rnd(M, N, seed=67, dtype=torch.bfloat16)
+    rows = _v2_sample_rows(M) if M == 32768 else torch.arange(M, device=DEV)
+    ref = (A[rows].double() @ Wt.double().t() + bias.double()).float().bfloat16().float()
+    g = torch.where(sel[rows, None].bool(), gate2[None, :], gate[None, :])
+    outs = {}
+    for kern in (0, 2, 4, 1):
+        _lib.check(lib.mc_set_option(b"gemm_kernel", kern))
+        try:
+            X, R = x_in.clone(), torch.zeros(M, N, device=DEV)
+            _lib.check(lib.mc_op_gemm_bf16_resid_sel(H.P(A), K, H.P(Wt), K, H.P(bias), M, N, K, 1, H.P(X), N, H.P(gate), H.P(gate2),
+                                                     H.P(sel), H.P(X0), N, H.P(R), N, H.S()))
+            X2 = x_in.clone()
+            _lib.check(lib.mc_op_gemm_bf16_resid_sel(H.P(A), K, H.P(Wt), K, H.P(bias), M, N, K, 0, H.P(X2), N, H.P(gate), H.P(gate2),
+                                                     H.P(sel), None, 0, None, 0, H.S()))
+            Xc, Rc = x_in.clone(), torch.zeros(M, N, device=DEV)
+            H.gemm(A, Wt, bias, 3, X=Xc, gate=gate, X0=X0, R=Rc)                   # capture without per-token gates
+        finally:
+            _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
+        outs[kern] = (X, R, X2, Xc, Rc)
+        torch.testing.assert_close(X[rows], x_in[rows] + ref * g, rtol=1e-2, atol=2e-2 * math.sqrt(K / 1536))
+        torch.testing.assert_close(Xc[rows], x_in[rows] + ref * gate, rtol=1e-2, atol=2e-2 * math.sqrt(K / 1536))
+        assert torch.equal(R, X - X0.float()) and torch.equal(Rc, Xc - X0.float()) and torch.equal(X, X2)
+    for kern in (2, 4, 1):
+        for a, b in zip(outs[0], outs[kern]):
+            assert torch.equal(a, b), kern
+    if M == 32768:
+        assert lib.mc_op_gemm_bf16_kernel(M, N, K, 3) == 4           # the shipped dispatch runs gemm_bf16_v2 for the capture
+
+
+@pytest.mark.parametrize("M,d", [(1536, 3072), (300, 256), (1024, 1024)], ids=["flux-single-linear1", "small-two-launches", "mid"])
+def test_gemm_bf16_gelu_split_equals_the_two_linears(M, d, kernel_variant):
+    """EPI_BF16_GELU_SPLIT: [q|k|v ; MLP-in] of an MM-DiT single block as ONE launch with two destinations == the two
+    launches it replaces, bit for bit (gemm_bf16_v2 at the FLUX size: 504 tiles in two persistent trips; the small shapes
+    and the forced other kernels take the two-launch fallback), destinations strided like the engine's qkv / am buffers."""
+    lib = _lib.load()
+    N, K, ns = 7 * d, d, 3 * d
+    A = rnd(M, K, seed=51, dtype=torch.bfloat16)
+    Wt = rnd(N, K, seed=52, scale=0.03, dtype=torch.bfloat16)
+    bias = rnd(N, seed=53)
+    qkv = torch.zeros(M, 3 * d, dtype=torch.bfloat16, device=DEV)
+    am = torch.zeros(M, 5 * d, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.mc_op_gemm_bf16_gelu_split(H.P(A), K, H.P(Wt), K, H.P(bias), M, N, K, ns, H.P(qkv), 3 * d,
+                                              H.P(am[:, d:]), 5 * d, H.S()))
+    q2 = torch.zeros_like(qkv)
+    a2 = torch.zeros_like(am)
+    H.gemm(A, Wt[:ns], bias[:ns], 0, Cb=q2)
+    H.gemm(A, Wt[ns:], bias[ns:], 1, Cb=a2[:, d:])
+    assert torch.equal(qkv.view(torch.int16), q2.view(torch.int16))
+    assert torch.equal(am.view(torch.int16), a2.view(torch.int16))
+    assert float(am[:, :d].abs().max()) == 0.0                       # the attention columns of "am" are not touched
+    ref = (A.double() @ Wt.double().t() + bias.double()).float()
+    torch.testing.assert_close(qkv.float(), ref[:, :ns], rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(am[:, d:].float(), F.gelu(ref[:, ns:].bfloat16().float(), approximate="tanh"), rtol=2e-2, atol=2e-2)
+    if M == 1536 and kernel_variant in (0, 4):
+        assert lib.mc_op_gemm_bf16_kernel(M, N, K, 10) == 4         # the one-launch form did run
 
 
 # ----------------------------------------------------------------------------- attention
