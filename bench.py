@@ -67,6 +67,8 @@ def pmc_traffic_live(timeout_s=120):
     import tempfile
     if os.environ.get("MC_BENCH_PMC", "1") == "0":
         return None, "MC_BENCH_PMC=0"
+    if any(k.startswith(("ROCP_", "ROCPROF", "ROCTRACER")) for k in os.environ):
+        return None, "this process is itself running under a profiler"   # (e.g. rocprofv3 --kernel-trace --stats -- python bench.py)
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     kbench = os.path.join(ROOT, "tools", "kbench.bin")
     lib = os.path.join(ROOT, "magcache_amd", "libmagcache_hip.so")

@@ -294,6 +294,15 @@ mc_status mc_op_gemm_bf16_resid_sel(const void* A_dev, long lda, const void* W_d
                                     int N, int K, int capture, float* X_dev, long ldx, const float* gate_dev,
                                     const float* gate2_dev, const unsigned char* gate_sel_dev, const void* X0_dev, long ldx0,
                                     float* R_dev, long ldr, mc_stream stream);
+/* two Linears with the same shapes over two ROW RANGES of the same buffers as one launch: rows [0, m_split) multiply with W
+ * (+ bias, gate), rows [m_split, M) with W_b (+ bias_b, gate_b) -- the text and the image stream of an MM-DiT double block are
+ * row ranges of the joint buffers (MagCache4FLUX/magcache_flux.py:342-387 calls them through diffusers' FluxTransformerBlock).
+ * epi 0 bf16, 1 GELU, 2 gated residual.  One gemm_bf16_v2 launch when m_split is a multiple of 256, otherwise the two launches
+ * it replaces -- the same bits either way (split-K shapes: the same bits as the two split launches only up to summation order). */
+mc_status mc_op_gemm_bf16_rowsplit(const void* A_dev, long lda, const void* W_dev, const void* W_b_dev, long ldw,
+                                   const float* bias_dev, const float* bias_b_dev, int M, int N, int K, int m_split, int epi,
+                                   void* Cb_dev, long ldc, float* X_dev, long ldx, const float* gate_dev, const float* gate_b_dev,
+                                   mc_stream stream);
 /* two Linears over the same rows as one launch: columns [0, n_split) -> Cb = bf16(acc + bias), columns [n_split, N) ->
  * Cb2[m][n - n_split] = bf16(gelu_tanh(bf16(acc + bias))) (the single block of an MM-DiT: q|k|v and MLP-in,
  * MagCache4FLUX/magcache_flux.py:389-421 calls it through diffusers' FluxSingleTransformerBlock).  One gemm_bf16_v2 launch

@@ -85,6 +85,7 @@ SIGNATURES = {
     "mc_op_gemm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l,
                              _i, _vp]),
     "mc_op_gemm_bf16_resid_sel": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp]),
+    "mc_op_gemm_bf16_rowsplit": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp]),
     "mc_op_gemm_bf16_gelu_split": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
     "mc_op_gemm_bf16_kernel": (_i, [_i, _i, _i, _i]),
     "mc_op_gemm_bf16_splitk": (_i, [_i, _i, _i, _i]),

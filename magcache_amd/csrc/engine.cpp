@@ -1444,6 +1444,22 @@ mc_status mc_op_gemm_bf16_resid_sel(const void* A, long lda, const void* W, long
   return MC_OK;
 }
 
+mc_status mc_op_gemm_bf16_rowsplit(const void* A, long lda, const void* W, const void* W_b, long ldw, const float* bias,
+                                   const float* bias_b, int M, int N, int K, int m_split, int epi, void* Cb, long ldc, float* X,
+                                   long ldx, const float* gate, const float* gate_b, mc_stream s) {
+  mc::GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, M, N, K);
+  p.Cb = (bf16_t*)Cb; p.ldc = ldc; p.X = X; p.ldx = ldx; p.gate = gate;
+  p.m_split = m_split; p.W_b = (const bf16_t*)W_b; p.bias_b = bias_b; p.gate_b = gate_b;
+  p.splitk_ws = g_op_splitk_ws; p.splitk_ws_bytes = g_op_splitk_bytes;
+  if (epi != mc::EPI_BF16 && epi != mc::EPI_GELU_BF16 && epi != mc::EPI_RESID_GATE)
+    return fail(MC_EINVAL, "gemm (row split): epi %d (0 bf16, 1 gelu, 2 gated residual)", epi);
+  hipError_t err = mc::launch_gemm_bf16(p, epi, (hipStream_t)s);
+  if (err == hipErrorInvalidValue)
+    return fail(MC_EINVAL, "gemm (row split): unsupported shape M=%d N=%d K=%d m_split=%d epi=%d", M, N, K, m_split, epi);
+  HIP_TRY(err);
+  return MC_OK;
+}
+
 mc_status mc_op_gemm_bf16_gelu_split(const void* A, long lda, const void* W, long ldw, const float* bias, int M, int N, int K,
                                      int n_split, void* Cb, long ldc, void* Cb2, long ldc2, mc_stream s) {
   mc::GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, M, N, K);

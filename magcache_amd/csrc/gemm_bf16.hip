@@ -264,6 +264,30 @@ int gemm_bf16_kernel_for(const GemmParams& p, int epi) {
 }
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+  if (p.m_split > 0) {
+    // two Linears over two row ranges: one gemm_bf16_v2 launch where that kernel can do it, otherwise the two launches
+    if (p.m_split >= p.M || !p.W_b) return hipErrorInvalidValue;
+    const bool one = (g_gemm_kernel == 0 || g_gemm_kernel == 4) && p.K >= 1024 && gemm_bf16_v2_supported(p) &&
+                     gemm_bf16_v2_rowsplit_ok(p, epi);
+    if (one) {
+      const int slices = gemm_splitk_slices(p, epi);
+      return slices > 1 ? launch_gemm_bf16_v2_splitk(p, epi, slices, stream) : launch_gemm_bf16_v2(p, epi, stream);
+    }
+    GemmParams a = p, b = p;
+    a.M = p.m_split;
+    a.m_split = b.m_split = 0;
+    const size_t r = (size_t)p.m_split;
+    b.A = p.A + r * p.lda;
+    b.M = p.M - p.m_split;
+    b.W = p.W_b; b.bias = p.bias_b; b.gate = p.gate_b;
+    if (p.Cb) b.Cb = p.Cb + r * p.ldc;
+    if (p.X) b.X = p.X + r * p.ldx;
+    if (p.X0) b.X0 = p.X0 + r * p.ldx0;
+    if (p.R) b.R = p.R + r * p.ldr;
+    if (p.gate_sel) b.gate_sel = p.gate_sel + r;
+    if (hipError_t e = launch_gemm_bf16(a, epi, stream); e != hipSuccess) return e;
+    return launch_gemm_bf16(b, epi, stream);
+  }
   if (epi == EPI_BF16_GELU_SPLIT && gemm_bf16_kernel_for(p, epi) != 4) {
     // only gemm_bf16_v2 has the two-destination epilogue: everywhere else the two Linears run as two launches (same bits)
     if (p.n_split <= 0 || p.n_split >= p.N || (p.n_split % 4) != 0 || !p.Cb2) return hipErrorInvalidValue;

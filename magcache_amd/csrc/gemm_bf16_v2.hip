@@ -142,11 +142,15 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
       const f32x32& t = cc[e >> 5];
       return f32x4{agpr_read(t[e & 31]), agpr_read(t[(e & 31) + 1]), agpr_read(t[(e & 31) + 2]), agpr_read(t[(e & 31) + 3])};
     };
+    // row-split operands: this tile's bias and gate vectors
+    const bool second = p.m_split > 0 && tm0 >= p.m_split;
+    const float* const bias_v = second ? p.bias_b : p.bias;
+    const float* const gate_v = second ? p.gate_b : p.gate;
     // bias quads of this lane: columns tn0 + 128 wc + 16 nb + 4 g4 + 0..3
     const uint32_t voff_n = (uint32_t)(wc_ * 128 + 4 * g4) * 4u;
     f32x4 bq[8];
-    if (p.bias) {
-      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias + tn0), 0, TB * 4, 0x00020000);
+    if (bias_v) {
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bias_v + tn0), 0, TB * 4, 0x00020000);
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) bq[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, voff_n + nb * 64, 0, 0));
     } else {
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     } else if (RESID) {
       // lane -> columns 4 c16 .. + 3 and 64 + 4 c16 .. + 3 of the wave's 128: every x load / store instruction then covers 256
       // CONTIGUOUS bytes of a row (two whole 128-byte lines), instead of 16 bytes out of every 32 over all four lines
-      if (p.gate) {
-        const float* gp = p.gate + tn0 + wc_ * 128 + c16 * 4;
+      if (gate_v) {
+        const float* gp = gate_v + tn0 + wc_ * 128 + c16 * 4;
         gA = *(const f32x4*)gp;
         gB = *(const f32x4*)(gp + 64);
       }
@@ -465,9 +469,10 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
     const bool more = next_tile < nunits;
     if (more) place(next_tile, nsl, ntl, nm0, nn0);
     const bf16_t* a_tile = p.A + (size_t)m0 * p.lda + (size_t)sl * Ks;
-    const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw + (size_t)sl * Ks;
+    // (row-split operands: the M tiles from m_split on multiply with the second weight matrix)
+    const bf16_t* w_tile = ((p.m_split > 0 && m0 >= p.m_split) ? p.W_b : p.W) + (size_t)n0 * p.ldw + (size_t)sl * Ks;
     const bf16_t* a_next = p.A + (size_t)nm0 * p.lda + (size_t)nsl * Ks;
-    const bf16_t* w_next = p.W + (size_t)nn0 * p.ldw + (size_t)nsl * Ks;
+    const bf16_t* w_next = ((p.m_split > 0 && nm0 >= p.m_split) ? p.W_b : p.W) + (size_t)nn0 * p.ldw + (size_t)nsl * Ks;
     const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
     const uint32_t a_nrec_n = __builtin_amdgcn_readfirstlane(more ? a_nrec_of(nm0) : 0u);
     const uint32_t w_nrec_n = __builtin_amdgcn_readfirstlane(more ? w_nrec_of(nn0) : 0u);
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void gemm_v2_kernel(GemmParams p, int tiles
 #else
   place(blockIdx.x, sl, tl, m0, n0);
   const bf16_t* a_tile = p.A + (size_t)m0 * p.lda + (size_t)sl * Ks;
-  const bf16_t* w_tile = p.W + (size_t)n0 * p.ldw + (size_t)sl * Ks;
+  const bf16_t* w_tile = ((p.m_split > 0 && m0 >= p.m_split) ? p.W_b : p.W) + (size_t)n0 * p.ldw + (size_t)sl * Ks;
   const uint32_t a_nrec = a_nrec_of(m0), w_nrec = w_nrec_of(n0);
   f32x32 c0, c1, c2, c3, c4, c5, c6, c7;
   asm volatile(
@@ -581,6 +586,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ti
   const int wr = wave >> 1, wc = wave & 1;
   const int mrow = lane & 15, ncol = 4 * (lane >> 4);
   const int qd0 = chunk * 16 + qg * RQ;
+  const bool second = p.m_split > 0 && m0 >= p.m_split;          // row-split operands: this tile's bias / gate
+  const float* const bias_v = second ? p.bias_b : p.bias;
+  if (second) p.gate = p.gate_b;                                  // (p is this thread's copy; gemm_epilogue_quad reads p.gate)
   f32x4 acc[RQ];
   int mm[RQ], nn[RQ];
 #pragma unroll
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ti
       const int ml = min(mm[j], p.M - 1);
       in[j] = resid_load<EPI>(p, ml, nn[j]);
       gt[j] = p.gate ? *(const f32x4*)(p.gate + nn[j]) : f32x4{1.f, 1.f, 1.f, 1.f};
-      if (p.bias) acc[j] += *(const f32x4*)(p.bias + nn[j]);
+      if (bias_v) acc[j] += *(const f32x4*)(bias_v + nn[j]);
     }
 #pragma unroll
     for (int j = 0; j < RQ; ++j)
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ti
 #pragma unroll
     for (int j = 0; j < RQ; ++j) {
       if (mm[j] >= p.M) continue;
-      if (p.bias) acc[j] += *(const f32x4*)(p.bias + nn[j]);
+      if (bias_v) acc[j] += *(const f32x4*)(bias_v + nn[j]);
       gemm_epilogue_quad<EPI>(p, mm[j], nn[j], acc[j]);
     }
   }
@@ -659,8 +667,15 @@ bool gemm_bf16_v2_supported(const GemmParams& p) {
          (size_t)TB * (size_t)std::max(p.ldx, p.ldc) * 4 < (1ull << 31);
 }
 
+bool gemm_bf16_v2_rowsplit_ok(const GemmParams& p, int epi) {
+  return p.m_split > 0 && p.m_split < p.M && (p.m_split % TB) == 0 && p.W_b && !p.gate_sel && (!p.bias == !p.bias_b) &&
+         (!p.gate == !p.gate_b) &&
+         (epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE);
+}
+
 hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream) {
   if (!gemm_bf16_v2_supported(p)) return hipErrorInvalidValue;
+  if (p.m_split != 0 && !gemm_bf16_v2_rowsplit_ok(p, epi)) return hipErrorInvalidValue;
   switch (epi) {
     case EPI_BF16: return launch_v2_t<EPI_BF16>(p, stream);
     case EPI_GELU_BF16: return launch_v2_t<EPI_GELU_BF16>(p, stream);
@@ -713,6 +728,7 @@ size_t gemm_splitk_ws_need(int M, int N, int K, int epi) {
 }
 
 hipError_t launch_gemm_bf16_v2_splitk(const GemmParams& p, int epi, int slices, hipStream_t stream) {
+  if (p.m_split != 0 && !gemm_bf16_v2_rowsplit_ok(p, epi)) return hipErrorInvalidValue;
   if (!gemm_bf16_v2_supported(p) || slices < 2 || !p.splitk_ws || p.K % (slices * 128) != 0 || p.K / slices < 256 ||
       (size_t)slices * ((p.M + TB - 1) / TB) * (p.N / TB) * TB * TB * sizeof(float) > p.splitk_ws_bytes)
     return hipErrorInvalidValue;

@@ -661,6 +661,93 @@ mc_status stream_post_attn(const mc_mmdit* e, const Stream& w, const float* mod,
   return MC_OK;
 }
 
+// Both streams of a double block in merged launches (round 5).  The streams are row ranges of the joint buffers, their
+// Linears have the same shapes: with the range boundary on a 256-row tile boundary (FLUX: [text 512 ; image]) the q|k|v, the
+// output projection and MLP-out of BOTH streams are one row-split GEMM each (GemmParams.m_split: 216 / 72 / 72 x 3 tiles at
+// 512^2 instead of 144 + 72 / 48 + 24 / 48 x 4 + 24 x 6 in two launches); LayerNorm (per-stream modulation), head norm
+// (per-stream weights) and MLP-in (192 + 96 tiles separately beat 288 together: two trips of 256 CUs) stay per stream.
+// HunyuanVideo's boundary (118 800 image rows first) is not on a tile boundary: launch_gemm_bf16 then runs the two launches.
+bool double_block_merged(const mc_mmdit* e) {
+  return g_mmdit_two_streams == 0 && e->P == 1 && e->Lt > 0 && e->Li > 0;
+}
+
+// the row-split form of one Linear over both streams: rows [first0, ..) use `a`'s operands, rows [second0, ..) use `b`'s
+struct TwoStreams {
+  const Stream* a; const Stream* b;      // first / second row range
+  const float* moda; const float* modb;  // their modulation vectors
+  int row0, rows_a, rows;                // first row, rows of the first range, rows of both
+};
+TwoStreams two_streams(const mc_mmdit* e, int blk, const float* emod) {
+  const bool txt_first = e->txt0 < e->img0;
+  const Stream* si = &e->dimg[blk];
+  const Stream* st = &e->dtxt[blk];
+  const float* mi = emod + e->mod_double(blk, 0);
+  const float* mt = emod + e->mod_double(blk, 1);
+  TwoStreams t;
+  t.a = txt_first ? st : si; t.b = txt_first ? si : st;
+  t.moda = txt_first ? mt : mi; t.modb = txt_first ? mi : mt;
+  t.row0 = txt_first ? e->txt0 : e->img0;
+  t.rows_a = txt_first ? e->Lt : e->Li;
+  t.rows = e->Li + e->Lt;
+  return t;
+}
+
+mc_status double_pre_merged(const mc_mmdit* e, int blk, const float* emod, hipStream_t s) {
+  const int d = e->d;
+  const TwoStreams t = two_streams(e, blk, emod);
+  float* x = e->buf<float>("x");
+  bf16_t* xn = e->buf<bf16_t>("xn");
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  const int r0 = t.row0, r1 = t.row0 + t.rows_a, nb = t.rows - t.rows_a;
+  HIP_TRY(mc::launch_ln_modulate(x + (size_t)r0 * d, d, nullptr, 0, t.moda + d, t.moda, 0, 1e-6f, xn + (size_t)r0 * d, d, nullptr, 0,
+                                 t.rows_a, d, s));
+  HIP_TRY(mc::launch_ln_modulate(x + (size_t)r1 * d, d, nullptr, 0, t.modb + d, t.modb, 0, 1e-6f, xn + (size_t)r1 * d, d, nullptr, 0,
+                                 nb, d, s));
+  mc::GemmParams p = gp(xn + (size_t)r0 * d, d, t.a->wqkv, d, t.a->bqkv, t.rows, 3 * d, d);
+  p.Cb = qkv + (size_t)r0 * 3 * d; p.ldc = 3 * d;
+  p.m_split = t.rows_a; p.W_b = t.b->wqkv; p.bias_b = t.b->bqkv;
+  HIP_TRY(gemm(e, p, mc::EPI_BF16, s));
+  HIP_TRY(mc::launch_headnorm_rope(qkv + (size_t)r0 * 3 * d, 3 * d, d, t.a->qn, t.a->kn, 1e-6f, e->cs, r0, t.rows_a, e->H, s));
+  HIP_TRY(mc::launch_headnorm_rope(qkv + (size_t)r1 * 3 * d, 3 * d, d, t.b->qn, t.b->kn, 1e-6f, e->cs, r1, nb, e->H, s));
+  return MC_OK;
+}
+
+// capture_to != null (LAST block of a model without single blocks): the MagCache residual R = x_new - x0 over the joint rows
+// (the text rows of R are scratch, as in the single blocks)
+mc_status double_post_merged(const mc_mmdit* e, int blk, const float* emod, hipStream_t s, float* capture_to) {
+  const int d = e->d;
+  const TwoStreams t = two_streams(e, blk, emod);
+  float* x = e->buf<float>("x");
+  bf16_t* xn = e->buf<bf16_t>("xn");
+  bf16_t* am = e->buf<bf16_t>("am");
+  const int r0 = t.row0, r1 = t.row0 + t.rows_a, nb = t.rows - t.rows_a;
+  mc::GemmParams o = gp(am + (size_t)r0 * 5 * d, 5 * d, t.a->wo, d, t.a->bo, t.rows, d, d);
+  o.X = x + (size_t)r0 * d; o.ldx = d; o.gate = t.moda + 2 * d;
+  o.m_split = t.rows_a; o.W_b = t.b->wo; o.bias_b = t.b->bo; o.gate_b = t.modb + 2 * d;
+  HIP_TRY(gemm(e, o, mc::EPI_RESID_GATE, s));
+  HIP_TRY(mc::launch_ln_modulate(x + (size_t)r0 * d, d, nullptr, 0, t.moda + 4 * d, t.moda + 3 * d, 0, 1e-6f, xn + (size_t)r0 * d, d,
+                                 nullptr, 0, t.rows_a, d, s));
+  HIP_TRY(mc::launch_ln_modulate(x + (size_t)r1 * d, d, nullptr, 0, t.modb + 4 * d, t.modb + 3 * d, 0, 1e-6f, xn + (size_t)r1 * d, d,
+                                 nullptr, 0, nb, d, s));
+  mc::GemmParams fa = gp(xn + (size_t)r0 * d, d, t.a->w1, d, t.a->b1, t.rows_a, 4 * d, d);
+  fa.Cb = am + (size_t)r0 * 5 * d + d; fa.ldc = 5 * d;
+  HIP_TRY(gemm(e, fa, mc::EPI_GELU_BF16, s));
+  mc::GemmParams fb = gp(xn + (size_t)r1 * d, d, t.b->w1, d, t.b->b1, nb, 4 * d, d);
+  fb.Cb = am + (size_t)r1 * 5 * d + d; fb.ldc = 5 * d;
+  HIP_TRY(gemm(e, fb, mc::EPI_GELU_BF16, s));
+  mc::GemmParams f2 = gp(am + (size_t)r0 * 5 * d + d, 5 * d, t.a->w2, 4 * d, t.a->b2, t.rows, d, 4 * d);
+  f2.X = x + (size_t)r0 * d; f2.ldx = d; f2.gate = t.moda + 5 * d;
+  f2.m_split = t.rows_a; f2.W_b = t.b->w2; f2.bias_b = t.b->b2; f2.gate_b = t.modb + 5 * d;
+  if (capture_to) {
+    f2.X0 = e->buf<bf16_t>("x0") + (size_t)r0 * d; f2.ldx0 = d;
+    f2.R = capture_to + (size_t)r0 * d; f2.ldr = d;
+    HIP_TRY(gemm(e, f2, mc::EPI_RESID_CAPTURE, s));
+  } else {
+    HIP_TRY(gemm(e, f2, mc::EPI_RESID_GATE, s));
+  }
+  return MC_OK;
+}
+
 // Image stream and text stream of a double block touch disjoint rows of every buffer: with "mmdit_two_streams" the text
 // half runs on the engine's side stream between a fork and a join event (capturable: the side stream joins back).
 template <class FI, class FT>
@@ -781,7 +868,9 @@ mc_status mc_mmdit_block_pre(mc_mmdit* e, int blk, mc_stream stream_) {
     auto img = [&](hipStream_t q, int ph) { return stream_pre_attn(e, e->dimg[blk], mi, e->img0, Li, q, ph); };
     auto txt = [&](hipStream_t q, int ph) { return stream_pre_attn(e, e->dtxt[blk], mt, e->txt0, Lt, q, ph); };
     const int mode = g_mmdit_two_streams;
-    if (mode <= 2) {
+    if (double_block_merged(e)) {
+      MC_TRY(double_pre_merged(e, blk, emod, s));
+    } else if (mode <= 2) {
       MC_TRY(run_two(e, s, mode, [&](hipStream_t q) { return img(q, 3); }, [&](hipStream_t q) { return txt(q, 3); }));
     } else {   // diagnostic splits: which pair of kernels must overlap for the results to change
       mc_status st = MC_OK;
@@ -902,7 +991,9 @@ mc_status mc_mmdit_block_post(mc_mmdit* e, int blk, mc_stream stream_) {
     }
   }
   const bool last = (blk == nb - 1);
-  if (blk < c.n_double) {
+  if (blk < c.n_double && double_block_merged(e)) {
+    MC_TRY(double_post_merged(e, blk, emod, s, last ? e->residual_joint(e->dst) : nullptr));
+  } else if (blk < c.n_double) {
     MC_TRY(run_two(
         e, s, g_mmdit_two_streams > 2 ? 0 : g_mmdit_two_streams,
         [&](hipStream_t q) {

@@ -49,6 +49,11 @@ struct GemmParams {
   // launch sums the slices in index order and applies the epilogue (deterministic; not bit-identical to the unsplit sum).
   // null / too small: no split.  Must not be shared by GEMMs that may run concurrently.
   float* splitk_ws; size_t splitk_ws_bytes;
+  // row-split operands (m_split > 0): rows >= m_split use W_b / bias_b / gate_b instead of W / bias / gate -- two Linears with
+  // the same shapes over two row ranges of the same buffers as ONE launch (the image and the text stream of an MM-DiT double
+  // block are row ranges of the joint buffers).  One gemm_bf16_v2 launch when m_split is a multiple of 256 and the epilogue is
+  // bf16 / GELU / gated residual (+ capture); two launches through the normal dispatch otherwise.  Same bits either way.
+  int m_split; const bf16_t* W_b; const float* bias_b; const float* gate_b;
   // EPI_BF16_GELU_SPLIT: first GELU column (a multiple of 256) and the GELU half's destination
   int n_split; bf16_t* Cb2; long ldc2;
   // fp8 GEMM (launch_gemm_fp8): A / W point to OCP e4m3 bytes, C = (A W^T) * a_scale[m] * w_scale[n] + bias
@@ -70,6 +75,7 @@ hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream
 bool gemm_bf16_big_supported(const GemmParams& p);
 hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream);     // 256x256 tiles, 4 waves, generated stream
 bool gemm_bf16_v2_supported(const GemmParams& p);
+bool gemm_bf16_v2_rowsplit_ok(const GemmParams& p, int epi);   // m_split > 0: can this be ONE gemm_bf16_v2 launch?
 extern int g_gemm_defer;   // (libraries whose gemm_v2 stream was generated with --defer 1 only; the shipped one is not) 0: epilogues in place
 // split-K (gemm_bf16_v2.hip): slices launch_gemm_bf16 would cut this problem's K into (1 = no split) given p.splitk_ws_bytes;
 // bytes of scratch the split it would choose with unlimited scratch needs (0 = it would not split)

@@ -522,6 +522,59 @@ def test_gemm_resid_capture_and_per_token_gates_all_kernels(M, N, K):
         assert lib.mc_op_gemm_bf16_kernel(M, N, K, 3) == 4           # the shipped dispatch runs gemm_bf16_v2 for the capture
 
 
+@pytest.mark.parametrize("N,K,epi,m_split", [(9216, 3072, 0, 512), (3072, 3072, 2, 512), (3072, 12288, 2, 512), (12288, 3072, 1, 512),
+                                             (3072, 3072, 2, 500), (1536, 1024, 0, 256)],
+                         ids=["flux-qkv", "flux-o", "flux-mlp2-splitk", "flux-mlp1-gelu", "unaligned-two-launches", "small"])
+def test_gemm_rowsplit_equals_the_two_linears(N, K, epi, m_split, splitk_ws):
+    """GemmParams.m_split: the text and the image stream of an MM-DiT double block (row ranges [0, m_split) and [m_split, M) of
+    the joint buffers, each with its own weights / bias / gate) as ONE gemm_bf16_v2 launch == the two launches it replaces:
+    bit for bit where neither form splits K, to fp32 summation-order noise where split-K slices differ (the merged MLP-out runs
+    3 slices over both ranges, the separate ones 4 and 6); an unaligned boundary takes the two launches inside the library."""
+    lib = _lib.load()
+    M = 1536 if N >= 3072 else 768
+    A = rnd(M, K, seed=71, dtype=torch.bfloat16)
+    Wa = rnd(N, K, seed=72, scale=0.03, dtype=torch.bfloat16)
+    Wb = rnd(N, K, seed=73, scale=0.03, dtype=torch.bfloat16)
+    ba, bb = rnd(N, seed=74), rnd(N, seed=75)
+    ga, gb = (rnd(N, seed=76), rnd(N, seed=77)) if epi == 2 else (None, None)
+    x_in = rnd(M, N, seed=78)
+
+    def merged():
+        cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV) if epi < 2 else None
+        x = x_in.clone() if epi == 2 else None
+        _lib.check(lib.mc_op_gemm_bf16_rowsplit(H.P(A), K, H.P(Wa), H.P(Wb), K, H.P(ba), H.P(bb), M, N, K, m_split, epi,
+                                                H.P(cb), N, H.P(x), N, H.P(ga), H.P(gb), H.S()))
+        return cb if epi < 2 else x
+
+    def separate():
+        if epi < 2:
+            cb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            H.gemm(A[:m_split], Wa, ba, epi, Cb=cb[:m_split])
+            H.gemm(A[m_split:], Wb, bb, epi, Cb=cb[m_split:])
+            return cb
+        x = x_in.clone()
+        H.gemm(A[:m_split], Wa, ba, 2, X=x[:m_split], gate=ga)
+        H.gemm(A[m_split:], Wb, bb, 2, X=x[m_split:], gate=gb)
+        return x
+    got, want = merged(), separate()
+    splits_k = K == 12288
+    if splits_k:
+        assert lib.mc_op_gemm_bf16_splitk(M, N, K, 2) == 3
+        torch.testing.assert_close(got, want, rtol=1e-2, atol=2e-2)
+        assert rel_l2(got - x_in, want - x_in) < 1e-3
+        assert torch.equal(got, merged())                                   # deterministic
+    else:
+        assert torch.equal(got.view(torch.int16 if epi < 2 else torch.int32), want.view(torch.int16 if epi < 2 else torch.int32))
+    ref = torch.cat([A[:m_split].double() @ Wa.double().t() + ba.double(), A[m_split:].double() @ Wb.double().t() + bb.double()]).float()
+    if epi == 0:
+        torch.testing.assert_close(got.float(), ref, rtol=1e-2, atol=1e-2)
+    elif epi == 1:
+        torch.testing.assert_close(got.float(), F.gelu(ref.bfloat16().float(), approximate="tanh"), rtol=2e-2, atol=2e-2)
+    else:
+        g = torch.cat([ga.expand(m_split, N), gb.expand(M - m_split, N)])
+        torch.testing.assert_close(got, x_in + ref.bfloat16().float() * g, rtol=1e-2, atol=2e-2 * math.sqrt(K / 1536))
+
+
 @pytest.mark.parametrize("M,d", [(1536, 3072), (300, 256), (1024, 1024)], ids=["flux-single-linear1", "small-two-launches", "mid"])
 def test_gemm_bf16_gelu_split_equals_the_two_linears(M, d, kernel_variant):
     """EPI_BF16_GELU_SPLIT: [q|k|v ; MLP-in] of an MM-DiT single block as ONE launch with two destinations == the two

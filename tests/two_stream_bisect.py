@@ -133,6 +133,9 @@ def main():
         torch.cuda.synchronize()
         return snaps if sync_between else out.clone()
 
+    # (round 5: the one-stream default merges the streams' Linears into row-split launches whose split-K slicing differs from
+    #  the per-stream launches; with split-K off both forms give the same bits, which is what this bisect compares)
+    _lib.check(lib.mc_set_option(b"gemm_splitk", 0))
     _lib.check(lib.mc_set_option(b"mmdit_two_streams", 0))   # the references are one-stream runs
     run(False)          # warm-up: every buffer holds the end state of a forward from here on
     ref = run(True)

@@ -20,7 +20,7 @@ def last_json(path):
 
 
 bench_log = sys.argv[1] if len(sys.argv) > 1 else "profiles/r05/bench_steps20_kernels_live_first.json.log"
-fx_log, hy_log, w_log = (f"profiles/r05/{n}" for n in ("flux_512_splitk_fused_linear1.json.log", "mmdit_hunyuan_720p_129f.json.log",
+fx_log, hy_log, w_log = (f"profiles/r05/{n}" for n in ("flux_512_final.json.log", "mmdit_hunyuan_720p_129f.json.log",
                                                        "wan14b_720p_single_gpu.json.log"))
 fx, hy, w, b = last_json(fx_log), last_json(hy_log), last_json(w_log), last_json(bench_log)
 out = {
@@ -34,7 +34,7 @@ out = {
             "frac": fx["model_tflops_per_s_nocache"] / 2500,
             "round_4": {"steps_per_s_nocache": 26.54, "steps_per_s_magcache": 72.6, "frac": 0.228, "log": "profiles/r04/final2/bench_mmdit.log"},
             "what_changed": "split-K for the M <= 1536 projections back to d, [q|k|v ; MLP-in] of a single block as one launch, "
-                            "head-norm + RoPE over head groups, LDS-staged GEMV"},
+                            "head-norm + RoPE over head groups, LDS-staged GEMV, both streams of a double block as row-split launches"},
         "1 Wan2.1-T2V-1.3B 480p 81 f (headline: bench.py)": {
             "log": bench_log, "steps_per_s_magcache": b["value"], "steps_per_s_nocache": b["nocache_steps_per_s"],
             "seconds_per_forward": 0.5 / b["nocache_steps_per_s"], "model_tflops_per_s": b["model_tflops_per_s_nocache"],
