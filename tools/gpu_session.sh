@@ -10,7 +10,7 @@
 #   pytest_slow        the slow-marked full-size parity runs
 #   smoke              __graft_entry__.smoke()
 #   bench[:args]       python bench.py <args, ':'-separated>  (default: --steps 20 --warmup 5)
-#   stats[:steps]      rocprofv3 --kernel-trace --stats over a short bench run (summary csv kept)
+#   stats[:steps]      rocprofv3 --kernel-trace --stats over a short bench run WITHOUT the back-to-back table (its 1 s pre-heats would swamp the summary); summary csv kept
 #   py:<script>[:args] python <script> args (tools/*.py probes)
 set -u
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
@@ -95,7 +95,7 @@ for step in "$@"; do
       ;;
     stats)
       steps=${a[1]:-6}
-      (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_$tag -o s -- python "$R/bench.py" --steps $steps --warmup 1 --no_cpu_baseline > "$out/stats_run.log" 2>&1; echo "rocprof exit: $?" >> "$out/stats_run.log")
+      (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_$tag -o s -- python "$R/bench.py" --steps $steps --warmup 1 --no_cpu_baseline --no_table > "$out/stats_run.log" 2>&1; echo "rocprof exit: $?" >> "$out/stats_run.log")
       f=$(find /tmp/stats_$tag -name "*kernel_stats.csv" | head -1)
       [ -n "$f" ] && cp "$f" "$out/kernel_stats_bench_steps$steps.csv" && head -25 "$out/kernel_stats_bench_steps$steps.csv"
       tail -2 "$out/stats_run.log"
