@@ -45,6 +45,20 @@
 // tools/build_gemm_v2_variants.py to a COPY of this file when an A/B library is built: the lines tagged [abl:...] below are
 // their anchors.)
 
+// M tiles per group of the tile order (v2_place): an XCD's 32 CUs work on 32 consecutive virtual tiles = GROUP_M M tiles x
+// 32 / GROUP_M N tiles, whose A / W tiles they share through the XCD's L2.  Tuning knobs (same results for every value):
+#ifndef MC_V2_GROUP_M_NARROW
+#define MC_V2_GROUP_M_NARROW 2   // ... problems with at most 8 N tiles (the d x d and FFN-2 projections back to d): all 6 N tiles
+                                 // of an M tile run on one XCD at the same time, A is fetched once.  FFN-2 (K = 8960) +3.0-3.8 %
+                                 // over 8 in three interleaved kbench runs, O / cross-O neutral (profiles/r05/kbench_gemm_group_m*.log)
+#endif
+#ifndef MC_V2_GROUP_M_MID
+#define MC_V2_GROUP_M_MID 8      // ... 9..31 N tiles (QKV)
+#endif
+#ifndef MC_V2_GROUP_M_WIDE
+#define MC_V2_GROUP_M_WIDE 4     // ... 32 N tiles and more (FFN-1)
+#endif
+
 namespace mc {
 
 int g_gemm_defer = 1;   // only read when the stream was generated with --defer 1: mc_set_option("gemm_defer", 0) = epilogues in place
@@ -625,6 +639,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int ti
   }
 }
 
+inline int v2_group_m(int tilesN) { return tilesN >= 32 ? MC_V2_GROUP_M_WIDE : tilesN > 8 ? MC_V2_GROUP_M_MID : MC_V2_GROUP_M_NARROW; }
+
 template <int EPI>
 hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream, int slices = 1) {
   const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
@@ -647,7 +663,7 @@ hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream, int slices = 1) 
 #endif
 #endif
   hipLaunchKernelGGL((gemm_v2_kernel<EPI>), dim3(grid), dim3(256), V2_LDS_BYTES, stream, p, tilesM, tilesN,
-                     tilesN >= 32 ? 4 : 8, scratch, slices);
+                     v2_group_m(tilesN), scratch, slices);
   return hipGetLastError();
 }
 
@@ -655,7 +671,7 @@ template <int EPI>
 hipError_t launch_reduce_t(const GemmParams& p, int slices, hipStream_t stream) {
   const int tilesM = (p.M + TB - 1) / TB, tilesN = p.N / TB;
   hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(tilesM * tilesN * 16), dim3(256), 0, stream, p, tilesM, tilesN,
-                     tilesN >= 32 ? 4 : 8, slices);
+                     v2_group_m(tilesN), slices);
   return hipGetLastError();
 }
 

@@ -85,7 +85,9 @@ def main(specs):
         if abl:                                    # WRONG-result timing ablations: a transformed COPY of the product source
             src = os.path.join(out, "gemm_bf16_v2_ablated.hip")
             open(src, "w").write(ablate(open(os.path.join(B.CSRC, "gemm_bf16_v2.hip")).read(), kv))
-        defs = [f'-DMC_GEMM_V2_BODY="{out}/gemm_v2_body.inc"', f'-DMC_GEMM_V2_CLOBBERS="{out}/gemm_v2_clobbers.inc"',
+        # correct-result tuning knobs: M tiles per group of the tile order, by the problem's number of N tiles
+        extra_defs = [f"-DMC_V2_GROUP_M_{k.upper()}=" + kv["gm" + k] for k in ("narrow", "mid", "wide") if kv.get("gm" + k)]
+        defs = extra_defs + [f'-DMC_GEMM_V2_BODY="{out}/gemm_v2_body.inc"', f'-DMC_GEMM_V2_CLOBBERS="{out}/gemm_v2_clobbers.inc"',
                 f'-DMC_GEMM_V2_CONFIG="{out}/gemm_v2_config.h"', "-I" + B.CSRC]
         subprocess.check_call([B.HIPCC] + B.FLAGS + defs + ["-c", src, "-o", obj])
         objs = [os.path.join(B.CSRC, "build", s + ".o") for s in B.SOURCES if s != "gemm_bf16_v2.hip"] + [obj]
