@@ -629,6 +629,8 @@ def bench_main():
                        "parallelism": "single GPU" if world == 1 else layout.describe()},
             "forwards_skipped": skipped, "forwards_total": 2 * args.steps,
             "speedup_bound": (2 * args.steps) / max(ran, 1),
+            "speedup_note": "bound = forwards total / forwards run, for equal forward times in both timed regions; the measured ratio "
+                            "can pass it by a few 1e-4 (the no-cache region carries the hipEvent pairs and runs second)",
             "nocache_steps_per_s": (args.steps / t_nc) if t_nc else None,
             "speedup_vs_nocache": (t_nc / t_mc) if t_nc else None,
             "psnr_vs_nocache_db": psnr,
