@@ -53,7 +53,7 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def pmc_traffic_live(timeout_s=120):
+def pmc_traffic_live(timeout_s=60):
     """HBM bytes per self-attention launch measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE -- the TCC
     block cannot hold both in one pass; --kernel-trace only, no other trace domain, as the MI355X guide prescribes) over
     tools/kbench.bin attn1 (the bench's self-attention shape through the C ABI, torch-free) in a child process.  Units: the
