@@ -226,16 +226,20 @@ def kernel_rooflines(cfg, device):
     return res
 
 
-def kernels_live(cfg, steps, wall_s, classes):
-    """Per-class LIVE kernel times of `steps` no-cache steps (2 forwards each): hipEvent pairs around every launch class inside
-    the engine (mc_profile_read_classes).  ms = average per event pair; frac against the class's bound (algorithmic FLOPs /
-    bytes, no padding); the last three fields reconcile the sum of the classes with the wall time of a forward."""
+def kernels_live(cfg, steps, wall_s, classes, sp=1, fwd_per_step=2):
+    """Per-class LIVE kernel times of `steps` no-cache steps: hipEvent pairs around every launch class inside the engine
+    (mc_profile_read_classes).  ms = average per event pair; frac against the class's bound (algorithmic FLOPs / bytes, no
+    padding); the last three fields reconcile the sum of the classes with the wall time of a forward.
+    N > 1 (rank 0's view): sp = ranks sharing the token axis -- this rank's rows are SEQ / sp, its self-attention is TWO pairs
+    per layer (local shard, remote shards: half of the rank's attention FLOPs each on average, so per-pair fractions are only
+    indicative) --, fwd_per_step = forwards this rank runs per step (1 when the CFG branches sit on two halves of the node)."""
     d, ffn, nl = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
-    fwd = 2 * steps
-    fl = {"attn_self": 4.0 * SEQ * SEQ * d, "gemm_qkv": 2.0 * SEQ * 3 * d * d, "gemm_o": 2.0 * SEQ * d * d,
-          "gemm_cross_q": 2.0 * SEQ * d * d, "gemm_cross_o": 2.0 * SEQ * d * d, "gemm_ffn1": 2.0 * SEQ * ffn * d,
-          "gemm_ffn2": 2.0 * SEQ * ffn * d}
-    by = {"attn_cross": (2 * SEQ * d + 2 * 512 * d) * 2.0, "ln_modulate": SEQ * d * 6.0}
+    fwd = fwd_per_step * steps
+    Lr = SEQ / sp
+    fl = {"attn_self": 4.0 * Lr * SEQ * d / (2 if sp > 1 else 1), "gemm_qkv": 2.0 * Lr * 3 * d * d, "gemm_o": 2.0 * Lr * d * d,
+          "gemm_cross_q": 2.0 * Lr * d * d, "gemm_cross_o": 2.0 * Lr * d * d, "gemm_ffn1": 2.0 * Lr * ffn * d,
+          "gemm_ffn2": 2.0 * Lr * ffn * d}
+    by = {"attn_cross": (2 * Lr * d + 2 * 512 * d) * 2.0, "ln_modulate": Lr * d * 6.0}
     out, total = {}, 0.0
     for name, (ms, n) in classes.items():
         if n == 0:
@@ -250,7 +254,7 @@ def kernels_live(cfg, steps, wall_s, classes):
         out[name] = ent
     gemm_ms = sum(classes[c][0] for c in fl if c.startswith("gemm"))
     gemm_fl = sum(fl[c] * classes[c][1] for c in fl if c.startswith("gemm"))
-    return {"measured": f"{steps} no-cache steps ({fwd} forwards x {nl} layers) after the timed regions, hipEvent pairs around "
+    return {"measured": f"{steps} no-cache steps ({fwd} forwards x {nl} layers{', rank 0 of sp ' + str(sp) if sp > 1 or fwd_per_step == 1 else ''}) after the timed regions, hipEvent pairs around "
                         "every launch class on the launch stream (mc_profile_enable level 2); 'pairs' that cover several "
                         "launches: rmsnorm_rope in front of the self-attention (q and k), embed, head",
             "classes": out,
@@ -597,7 +601,7 @@ def bench_main():
     # self-attention kernel has.  Kept out of region 2 so that `nocache_steps_per_s` stays comparable with rounds 1-4
     # (~14 pairs per layer instead of one).
     live = None
-    if world == 1 and not args.no_nocache and not args.no_kernels:
+    if not args.no_nocache and not args.no_kernels:     # (N > 1: every rank runs the region -- it holds collectives --, rank 0 reports)
         stage("live kernel classes")
         ls = max(1, min(args.steps, 3))
         model.engine.profile(2)
@@ -672,6 +676,10 @@ def bench_main():
                 line["kernels"] = k
             if live:
                 line["kernels_live"] = kernels_live(cfg, *live)
+        if world > 1 and live:
+            # rank 0's launch classes (the K|V all-gather runs on RCCL's own stream and is NOT in any class: what the classes
+            # leave of the wall time is gather wait + host): the first thing to read in an N-GPU profile
+            line["kernels_live_rank0"] = kernels_live(cfg, *live, sp=layout.sp_size, fwd_per_step=1 if layout.cfg_size == 2 else 2)
         if world > 1 and attn_live and attn_live[1] > 0:
             # N > 1: rank 0's self-attention launches of the timed no-cache region (cfg2: one full-sequence launch per
             # layer; sequence parallel: local-shard + remote-shards launch per layer), algorithmic FLOPs of its share

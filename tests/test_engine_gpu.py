@@ -446,7 +446,9 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
     is the layout of the driver's 4- and 8-GPU runs: CFG branches on two halves, sequence parallel inside a half
     (sub-groups, pair exchange, local-shard-first attention with the log-sum-exp merge)."""
     env = dict(os.environ, PYTHONPATH=ROOT, MC_BENCH_BACKEND="gloo")
-    base = [os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "0", "--no_cpu_baseline", "--no_kernels"]
+    base = [os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "0", "--no_cpu_baseline", "--no_table"]
+    if nproc == 4:
+        base.append("--no_kernels")
     if steps not in _BENCH_REF:
         one = subprocess.run([sys.executable] + base + ["--gpus", "1"], env=env, capture_output=True, text=True, timeout=900)
         assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
@@ -471,6 +473,14 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
         abl = got["layout_ablation_nocache_steps_per_s"]
         assert set(abl) == {"sp", "cfg2sp"} and all(v > 0 for v in abl.values())
         assert got["layout"] == max(abl, key=abl.get)
+    if nproc == 2:
+        # rank 0's live launch classes of the sharded engine (N > 1 lines carry them for the first multi-GPU profile)
+        k = got["kernels_live_rank0"]
+        sp = 2 if got["layout"] == "sp" else 1
+        forwards = 3 * (2 if sp == 2 else 1)        # 3 live steps; cfg2: one CFG branch per rank, sp: both on every rank
+        assert k["classes"]["attn_self"]["pairs"] == forwards * 30 * sp      # sp 2: local-shard + remote-shards launch per layer
+        assert k["classes"]["gemm_ffn1"]["pairs"] == forwards * 30
+        assert 0.0 < k["sum_classes_ms_per_forward"] <= k["wall_ms_per_forward"] * 1.02
     if got["layout"] == "sp" or nproc > 2 or par is None:
         # overlapped (local-shard attention beside the K/V all-gather) vs serialised sequence-parallel forward
         assert got["sp_selfcheck_rel"] <= 3e-3 and got["sp_overlap"] is True
