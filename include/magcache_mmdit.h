@@ -18,6 +18,13 @@
  * Conventions as in magcache_hip.h: *_dev pointers are caller-owned device memory, the engine owns its weight copies,
  * all scratch and the residual cache live in one caller-provided workspace, nothing allocates or synchronises during
  * a forward, calls are asynchronous on the given hipStream_t, status codes + mc_last_error().
+ *
+ * GEMM launches of a block (round 5; policy in csrc/gemm_bf16_v2.hip, switches "gemm_splitk" / "mmdit_two_streams" of
+ * mc_set_option): the two streams of a double block are row ranges of the joint buffers, so their q|k|v, output projection and
+ * MLP-out run as ONE row-split launch each when the range boundary sits on a 256-row tile boundary (FLUX; HunyuanVideo's does
+ * not: two launches); a single block's [q|k|v ; MLP-in] is one launch with two destinations; the projections back to d at small
+ * image sizes (<= 128 tiles of 256 x 256) are cut along K into slices summed by a second launch -- their scratch is the
+ * workspace's "splitk0" / "splitk1" (mc_mmdit_buffer_info), sized at create time from the geometry (absent at HunyuanVideo's).
  */
 #ifndef MAGCACHE_MMDIT_H
 #define MAGCACHE_MMDIT_H
