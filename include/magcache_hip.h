@@ -94,6 +94,8 @@ const char* mc_version(void);
  *                   and A/B runs compare gemm_bf16_v2 with --, 4 = gemm_bf16_v2 wherever it applies.  All give the same bits.
  *   "gemm_splitk"   1 (default) = split-K by shape (see mc_op_set_splitk_workspace below), 0 = never, 2..16 = that many
  *                   slices wherever K divides (parity tests).
+ *   "gemm_v2_max_grid"  0 (default) = gemm_bf16_v2 runs one persistent workgroup per CU; n = at most n (leaves CUs to a
+ *                   kernel of another stream: tools/cfg_overlap_probe.py).  Same results.
  *   "gemm_defer"    no effect in the shipped library.  (A/B libraries whose gemm_bf16_v2 stream was generated with
  *                   tools/gen_gemm_v2.py --defer 1 apply a gated-residual epilogue inside the next output tile's main
  *                   loop -- bit-identical, measured 1.5-4 % slower, DESIGN 3.2 -- and 0 switches that off at run time.)

@@ -1645,6 +1645,9 @@ mc_status mc_set_option(const char* key, int value) {
   } else if (k == "gemm_splitk") {
     if (value < 0 || value > 16) return fail(MC_EINVAL, "gemm_splitk must be 0 (never), 1 (by shape) or 2..16 (that many K slices wherever valid)");
     mc::g_gemm_splitk = value;
+  } else if (k == "gemm_v2_max_grid") {
+    if (value < 0 || value > 4096) return fail(MC_EINVAL, "gemm_v2_max_grid must be 0 (= the CUs) or a workgroup count");
+    mc::g_gemm_v2_max_grid = value;
   } else if (k == "gemm_defer") {
     if (value != 0 && value != 1) return fail(MC_EINVAL, "gemm_defer must be 0 (residual epilogues in place) or 1 (deferred into the next tile's main loop)");
     mc::g_gemm_defer = value;

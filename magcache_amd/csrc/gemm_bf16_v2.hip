@@ -61,6 +61,7 @@
 
 namespace mc {
 
+int g_gemm_v2_max_grid = 0;   // mc_set_option("gemm_v2_max_grid"): 0 = one persistent workgroup per CU (default)
 int g_gemm_defer = 1;   // only read when the stream was generated with --defer 1: mc_set_option("gemm_defer", 0) = epilogues in place
 
 namespace {
@@ -657,6 +658,7 @@ hipError_t launch_v2_t(const GemmParams& p, hipStream_t stream, int slices = 1) 
     if (n_cu <= 0) n_cu = 256;
   }
   if (grid > n_cu) grid = n_cu;
+  if (g_gemm_v2_max_grid > 0 && grid > g_gemm_v2_max_grid) grid = g_gemm_v2_max_grid;   // (co-execution experiments: leave CUs free)
 #if MC_GEMM_V2_DEFER
   // (a workgroup with one tile gains nothing from deferring; the scratch tile is indexed by blockIdx.x < n_cu)
   if (EPI == EPI_RESID_GATE && tilesM * tilesN > grid && g_gemm_defer) scratch = v2_scratch(stream, n_cu);

@@ -82,6 +82,7 @@ extern int g_gemm_defer;   // (libraries whose gemm_v2 stream was generated with
 int gemm_splitk_slices(const GemmParams& p, int epi);
 size_t gemm_splitk_ws_need(int M, int N, int K, int epi);
 hipError_t launch_gemm_bf16_v2_splitk(const GemmParams& p, int epi, int slices, hipStream_t stream);
+extern int g_gemm_v2_max_grid;  // 0 = grid of gemm_bf16_v2 = CUs; n = at most n persistent workgroups (probe: two forwards side by side)
 extern int g_gemm_splitk;  // mc_set_option("gemm_splitk"): 1 = by shape (default), 0 = never, 2..16 = force that many slices where valid
 extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported, 4: generation 2 where supported
 // fp8 (e4m3) operands, 256x256 tiles, v_mfma_f32_32x32x64_f8f6f4; K (fp8 elements) a multiple of 256
