@@ -226,17 +226,24 @@ def kernel_rooflines(cfg, device):
     return res
 
 
+def latent_probe(lat):
+    flat = lat.detach().float().reshape(-1)
+    idx = torch.linspace(0, flat.numel() - 1, 16, device=flat.device).long()
+    return {"l2": float(flat.norm()), "rms": float(flat.pow(2).mean().sqrt()), "samples": [float(v) for v in flat[idx].cpu()]}
+
+
 def kernels_live(cfg, steps, wall_s, classes, sp=1, fwd_per_step=2):
     """Per-class LIVE kernel times of `steps` no-cache steps: hipEvent pairs around every launch class inside the engine
     (mc_profile_read_classes).  ms = average per event pair; frac against the class's bound (algorithmic FLOPs / bytes, no
     padding); the last three fields reconcile the sum of the classes with the wall time of a forward.
-    N > 1 (rank 0's view): sp = ranks sharing the token axis -- this rank's rows are SEQ / sp, its self-attention is TWO pairs
-    per layer (local shard, remote shards: half of the rank's attention FLOPs each on average, so per-pair fractions are only
-    indicative) --, fwd_per_step = forwards this rank runs per step (1 when the CFG branches sit on two halves of the node)."""
+    N > 1 (rank 0's view): sp = ranks sharing the token axis -- this rank's rows are SEQ / sp; its self-attention is 1 + R
+    pairs per layer (local shard + one per gather round) and its q|k|v Linear two (k|v first, then q), so the MFMA classes are
+    rated per LAYER (summed time of the class / layers run) --, fwd_per_step = forwards this rank runs per step (1 when the
+    CFG branches sit on two halves of the node)."""
     d, ffn, nl = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
     fwd = fwd_per_step * steps
     Lr = SEQ / sp
-    fl = {"attn_self": 4.0 * Lr * SEQ * d / (2 if sp > 1 else 1), "gemm_qkv": 2.0 * Lr * 3 * d * d, "gemm_o": 2.0 * Lr * d * d,
+    fl = {"attn_self": 4.0 * Lr * SEQ * d, "gemm_qkv": 2.0 * Lr * 3 * d * d, "gemm_o": 2.0 * Lr * d * d,
           "gemm_cross_q": 2.0 * Lr * d * d, "gemm_cross_o": 2.0 * Lr * d * d, "gemm_ffn1": 2.0 * Lr * ffn * d,
           "gemm_ffn2": 2.0 * Lr * ffn * d}
     by = {"attn_cross": (2 * Lr * d + 2 * 512 * d) * 2.0, "ln_modulate": Lr * d * 6.0}
@@ -248,12 +255,14 @@ def kernels_live(cfg, steps, wall_s, classes, sp=1, fwd_per_step=2):
         ent = {"ms": ms / n, "pairs": n, "ms_per_forward": ms / fwd}
         t = ms / n * 1e-3
         if name in fl:
-            ent.update(bound="mfma", achieved=fl[name] / t / 1e12, unit="TFLOP/s", frac=fl[name] / t / 2.5e15)
+            t = ms / (fwd * nl) * 1e-3          # per layer (== per pair on one GPU)
+            ent.update(bound="mfma", achieved=fl[name] / t / 1e12, unit="TFLOP/s", frac=fl[name] / t / 2.5e15,
+                       ms_per_layer=t * 1e3)
         elif name in by:
             ent.update(bound="hbm", achieved=by[name] / t / 1e9, unit="GB/s", frac=by[name] / t / 8e12)
         out[name] = ent
     gemm_ms = sum(classes[c][0] for c in fl if c.startswith("gemm"))
-    gemm_fl = sum(fl[c] * classes[c][1] for c in fl if c.startswith("gemm"))
+    gemm_fl = sum(fl[c] * fwd * nl for c in fl if c.startswith("gemm") and classes[c][1])
     return {"measured": f"{steps} no-cache steps ({fwd} forwards x {nl} layers{', rank 0 of sp ' + str(sp) if sp > 1 or fwd_per_step == 1 else ''}) after the timed regions, hipEvent pairs around "
                         "every launch class on the launch stream (mc_profile_enable level 2); 'pairs' that cover several "
                         "launches: rmsnorm_rope in front of the self-attention (q and k), embed, head",
@@ -501,23 +510,19 @@ def bench_main():
             names = [args.layout]
         stage("process groups")
         layouts = {n: PAR.ParallelLayout(cfg_parallel=(n == "cfg2sp")) for n in names}   # every rank builds every group
-        models = {}
-        # memory: --layout auto holds one engine per candidate layout on every GPU until the ablation has chosen
-        # (weights + this rank's share of the workspace each, engine_bytes_estimate); refuse early, with the numbers, rather
-        # than fail in hipMalloc.  (Ranks sharing one device -- the one-GPU tests -- each see the same free figure.)
         free_b, total_b = torch.cuda.mem_get_info()
-        need_b = sum(engine_bytes_estimate(cfg, layouts[n].sp_size) for n in names)
         extra["hbm_free_gb_at_start"] = round(free_b / 1e9, 1)
+        # ONE engine at a time (round 5 built one per candidate layout and kept them all until the ablation had chosen: twice
+        # the ways to fail before a single number exists): build a candidate, check it, time it, drop it before the next
+        need_b = max(engine_bytes_estimate(cfg, layouts[n].sp_size) for n in names)
         if free_b < need_b:
-            raise RuntimeError(f"{len(names)} engines need ~{need_b / 1e9:.0f} GB, {free_b / 1e9:.1f} GB free of {total_b / 1e9:.0f} GB "
-                               "(use --layout sp or --layout cfg2sp to build one)")
-        # ---- sequence-parallel self-check: the overlapped forward (local-shard attention beside the K/V all-gather)
-        # must agree with the serialised one; otherwise run without the overlap
-        check_name = next((n for n in names if layouts[n].sp_size > 1), None)
-        if check_name is not None:
-            stage("sequence-parallel self-check")
-            models[check_name] = make_model(layouts[check_name], check_name)
-            m = M.disable_magcache(models[check_name])
+            raise RuntimeError(f"the engine needs ~{need_b / 1e9:.0f} GB, {free_b / 1e9:.1f} GB free of {total_b / 1e9:.0f} GB")
+
+        def selfcheck(model, name):
+            """sequence-parallel self-check: the overlapped forward (q Linear, local-shard attention and the attention over
+            landed rounds beside the chunked K/V all-gather) must agree with the serialised one; otherwise run without"""
+            stage(f"sequence-parallel self-check ({name})")
+            m = M.disable_magcache(model)
             tt = torch.tensor([500.0], device=device)
             saved = PAR.SP_OVERLAP
             outs = []
@@ -531,21 +536,30 @@ def bench_main():
             if not (rel <= 3e-3):
                 PAR.SP_OVERLAP = False
             extra["sp_overlap"] = bool(PAR.SP_OVERLAP)
-            sp = getattr(models[check_name], "_sp", None)
-            # RCCL only: did the in-place all-gather (send chunk = own slot of the receive buffer) pass its start-up
-            # self-test on every rank (parallel.inplace_gather_selftest)?  false = the run uses the out-of-place form
-            extra["rccl_inplace_gather"] = getattr(sp, "inplace_checked", None)
-        # ---- layout ablation: 2 no-cache steps of every candidate after 1 untimed step; the faster one is benchmarked
-        if len(names) > 1:
-            stage("layout ablation")
-            abl = {}
-            for n in names:
-                if n not in models:
-                    models[n] = make_model(layouts[n], n)
-                m = M.disable_magcache(models[n])
+            sp = getattr(model, "_sp", None)
+            extra["sp_chunks"] = getattr(sp, "C", None)          # rounds of the per-layer K|V all-gather
+            extra["sp_rounds"] = getattr(sp, "R", None)          # ... of which carry valid keys
+            extra["sp_collective"] = ("RCCL communicator inside the library (mc_forward_sp_rccl: one C call per forward): "
+                                      + model.engine.rccl_info(sp.rccl)) if getattr(sp, "rccl", None) is not None else \
+                "torch.distributed from the gather callback of mc_blocks_sp (" + str(dist.get_backend()) + ")"
+
+        model, built, abl = None, None, {}
+        for n in names:
+            if model is not None:
+                del model
+                torch.cuda.empty_cache()
+            stage(f"build engine ({n})")
+            model, built = make_model(layouts[n], n), n
+            if layouts[n].sp_size > 1 and "sp_selfcheck_rel" not in extra:
+                selfcheck(model, n)
+            if len(names) > 1:
+                # ---- layout ablation: 2 no-cache steps of every candidate after 1 untimed step; the faster one is benchmarked
+                stage(f"layout ablation ({n})")
+                m = M.disable_magcache(model)
                 run(m, layouts[n], 1)
                 dt, _ = timed(lambda: run(m, layouts[n], 2), sync, barrier)
                 abl[n] = 2.0 / max_over_ranks(dt)
+        if len(names) > 1:
             extra["layout_ablation_nocache_steps_per_s"] = abl
             chosen = max(abl, key=abl.get)
             ch = torch.tensor([names.index(chosen)], device=device)
@@ -554,11 +568,11 @@ def bench_main():
         else:
             chosen = names[0]
         layout = layouts[chosen]
-        model = models.get(chosen) or make_model(layout, chosen)
-        for n in list(models):
-            if n != chosen:
-                del models[n]
-        torch.cuda.empty_cache()
+        if built != chosen:
+            del model
+            torch.cuda.empty_cache()
+            stage(f"build engine ({chosen}, chosen)")
+            model = make_model(layout, chosen)
         extra["layout"] = chosen
     else:
         model = make_model(None, "single")
@@ -638,6 +652,9 @@ def bench_main():
             "nocache_steps_per_s": (args.steps / t_nc) if t_nc else None,
             "speedup_vs_nocache": (t_nc / t_mc) if t_nc else None,
             "psnr_vs_nocache_db": psnr,
+            # fingerprints of the final latents (identical seeds => an N-rank run must reproduce the single-GPU values up to
+            # the bf16 rounding of the partial attention results): l2 norm + 16 values at fixed flat indices
+            "final_latent_probe": {"magcache": latent_probe(lat_mc), "nocache": latent_probe(lat_nc) if t_nc else None},
             "lpips_vs_nocache": "unavailable offline (magcache_amd.metrics.LPIPSAlex needs AlexNet + lpips weights, none ship "
                                 "here; it raises rather than invent a number)",
             "model_tflops_per_s_nocache": (2 * args.steps * fl / t_nc / 1e12 / world) if t_nc else None,
@@ -677,14 +694,25 @@ def bench_main():
             if live:
                 line["kernels_live"] = kernels_live(cfg, *live)
         if world > 1 and live:
-            # rank 0's launch classes (the K|V all-gather runs on RCCL's own stream and is NOT in any class: what the classes
-            # leave of the wall time is gather wait + host): the first thing to read in an N-GPU profile
-            line["kernels_live_rank0"] = kernels_live(cfg, *live, sp=layout.sp_size, fwd_per_step=1 if layout.cfg_size == 2 else 2)
+            # rank 0's launch classes.  The K|V all-gather runs on RCCL's own stream and is in no class; what the launch stream
+            # IDLED waiting for a gather round is class "sp_wait" (hipEvent pairs around every wait): the exposed
+            # communication, the first thing to read in an N-GPU profile
+            fps = 1 if layout.cfg_size == 2 else 2
+            line["kernels_live_rank0"] = kernels_live(cfg, *live, sp=layout.sp_size, fwd_per_step=fps)
+            w_ms, w_n = live[2].get("sp_wait", (0.0, 0))
+            if w_n:
+                nl = cfg["num_layers"]
+                line["sp_gather_wait"] = {"ms_per_layer": w_ms / (fps * live[0] * nl), "ms_per_forward": w_ms / (fps * live[0]),
+                                          "waits_per_layer": w_n / (fps * live[0] * nl),
+                                          "frac_of_forward_wall": w_ms / (live[1] * 1e3),
+                                          "measured": "rank 0, hipEvent pairs on the launch stream around every wait for a "
+                                                      "K|V gather round (MC_PROF_SP_WAIT): time the stream idled for the "
+                                                      "collective = exposed communication"}
         if world > 1 and attn_live and attn_live[1] > 0:
             # N > 1: rank 0's self-attention launches of the timed no-cache region (cfg2: one full-sequence launch per
-            # layer; sequence parallel: local-shard + remote-shards launch per layer), algorithmic FLOPs of its share
+            # layer; sequence parallel: local-shard launch + one per gather round per layer), algorithmic FLOPs of its share
             sp = layout.sp_size
-            pairs = attn_live[1] // (2 if sp > 1 else 1)
+            pairs = attn_live[1] // ((1 + extra.get("sp_rounds", 1)) if sp > 1 else 1)      # layers run
             fl_attn = 4.0 * (SEQ / sp) * SEQ * cfg["dim"] * pairs
             rate = fl_attn / (attn_live[0] * 1e-3)
             line["roofline"] = {"bound": "mfma", "achieved": rate / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
@@ -693,7 +721,7 @@ def bench_main():
                                 "measured": "rank 0, hipEvent pairs around every self-attention launch of the timed "
                                             "no-cache region; per-GPU rate",
                                 "kernel": "self-attention, attn_fwd_v5_kernel (32x32x16 lazy / pipelined stream) for every form of "
-                                          "the call: one key shard, and the sequence-parallel local-shard + remote-shards "
+                                          "the call: one key shard, and the sequence-parallel local-shard + per-round "
                                           "launches with the log-sum-exp merge"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)

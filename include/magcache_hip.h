@@ -78,6 +78,10 @@ typedef struct {
                            mc_use_context then fail with MC_ESTATE and every forward takes its context argument */
   int no_token_timesteps; /* 1: do not reserve the second modulation set and the per-token selector of
                            mc_set_token_timesteps (Wan2.2 TI2V); the call then fails with MC_ESTATE */
+  int sp_phases;        /* 1: build the sequence-parallel buffers ("kv_local", "kv_gather", "attn_lse") and take the phase
+                           path (mc_blocks_sp, mc_forward_sp_rccl) even with sp_size 1 -- a world of ONE: the collective
+                           path, RCCL included, exercised on a single GPU (tests/test_rccl_gpu.py).  mc_forward refuses
+                           such an engine like any sharded one. */
 } mc_config;
 
 const char* mc_last_error(void);
@@ -124,7 +128,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out);
 /* ABI rule for mc_config: it only grows at its END and a zero in a new field means "as before".  mc_create reads
  * sizeof(mc_config) of THIS header; a caller compiled against an older header (a shorter struct) must call
  * mc_create_sized(cfg, sizeof(mc_config) as IT knows it, out): the missing tail is taken as zeros.  History: 0.1 ends at
- * vace_in_dim, 0.2 adds fp8_linear, 0.3 no_context_cache and no_token_timesteps; mc_version() names the library's. */
+ * vace_in_dim, 0.2 adds fp8_linear, 0.3 no_context_cache and no_token_timesteps, 0.5 sp_phases; mc_version() names the library's. */
 mc_status mc_create_sized(const mc_config* cfg, size_t cfg_bytes, mc_engine** out);
 void mc_destroy(mc_engine* e);
 size_t mc_workspace_bytes(const mc_engine* e);
@@ -202,7 +206,9 @@ typedef enum {
   MC_PROF_EMBED = 10,       /* patch / time / text embeds of a forward */
   MC_PROF_HEAD = 11,        /* head LayerNorm (+ the skip add) + Linear + unpatchify */
   MC_PROF_OTHER = 12,       /* uncached text K|V, I2V image branch, calibration statistics */
-  MC_PROF_NCLASS = 13
+  MC_PROF_SP_WAIT = 13,     /* sequence parallel (mc_blocks_sp): what the launch stream idled waiting for a K|V gather round
+                               = the EXPOSED communication of a forward; 0 launches on one GPU */
+  MC_PROF_NCLASS = 14
 } mc_prof_class;
 mc_status mc_profile_enable(mc_engine* e, int level);
 mc_status mc_profile_read(mc_engine* e, double* attn_ms_total, int* attn_launches);
@@ -213,23 +219,70 @@ mc_status mc_profile_read_classes(mc_engine* e, double ms_total[MC_PROF_NCLASS],
 mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, double t_host,
                    const void* context_dev, mc_dtype ctx_dtype, int ctx_len, mc_stream stream);
 mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream);  /* LN+mod, QKV, qk-norm, RoPE */
-/* optional, sp_size > 1 only: self-attention over THIS rank's K/V shard (already in place after pre_attn), to be
- * launched while the all-gather of the other shards is in flight; the following mc_block_post_attn of the same
- * layer then attends the remaining shards only and merges both parts (log-sum-exp weights) */
+/* sp_size > 1: mc_block_pre_attn in two halves.  pre_kv = LayerNorm + the k|v Linear into "kv_local" [Lp][2 dim] + k norm /
+ * RoPE -- everything the OTHER ranks wait for; pre_q = the q Linear + q norm / RoPE.  A caller that starts its all-gather
+ * between the two hides it behind the q Linear as well. */
+mc_status mc_block_pre_kv(mc_engine* e, int layer, mc_stream stream);
+mc_status mc_block_pre_q(mc_engine* e, int layer, mc_stream stream);
+/* The K|V all-gather of a layer, in C rounds (mc_sp_set_chunks; default 1).  Layout: "kv_local" [Lp][2 dim] bf16 = this
+ * rank's rows (Lp = tokens per rank rounded up to 256); "kv_gather" [C][P][Lp / C][2 dim]: round c is ONE out-of-place
+ * all-gather of rows [c Lp / C, (c + 1) Lp / C) of every rank's "kv_local" (contiguous send chunk, contiguous receive block).
+ * The self-attention of a layer is a chain of launches merged by their log2-sum-exp in the kernel epilogue: this rank's own
+ * shard first (mc_block_attn_local, needs no communication), then one launch per round as it lands (mc_block_attn_round) --
+ * the attention over round c runs while round c + 1 is on the wire.  Rounds that hold padding rows only (mc_sp_round_info:
+ * n_rounds < C) are neither gathered nor attended.  Lp / C must be a multiple of 64. */
+mc_status mc_sp_set_chunks(mc_engine* e, int chunks);
+mc_status mc_sp_round_info(const mc_engine* e, int round, int* n_rounds, int* chunk_rows, int* valid);
+/* optional, sp_size > 1 only: self-attention over THIS rank's K/V shard ("kv_local", complete after pre_kv), to be
+ * launched while the all-gather of the other shards is in flight; the following mc_block_attn_round / mc_block_post_attn of
+ * the same layer then attend the other ranks' shards only and merge (log-sum-exp weights) */
 mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream);
+/* self-attention over gather round `round` (in order 0 .. n_rounds - 1), merged into the layer's result */
+mc_status mc_block_attn_round(mc_engine* e, int layer, int round, mc_stream stream);
+/* attends whatever rounds the caller has not (all of them for a caller that gathered everything first), then the rest of
+ * the block */
 mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, mc_stream stream);
-/* The same layer loop in ONE call (sp_size > 1): for every layer in [layer_begin, layer_end) the engine runs pre_attn, calls
- * gather(user, layer, 0, stream) -- the caller STARTS the all-gather of "kv_gather" on its own communicator, ordered behind
- * the work `stream` already holds --, runs the local-shard attention beside it, calls gather(user, layer, 1, stream) -- the
- * caller makes `stream` wait for that gather, no host sync; with overlap == 0 this call comes before the local-shard
- * attention, so that nothing runs beside the collective --, then post_attn; a VACE control block follows
- * its main layer in the same two phases with its own gather.  The callback returns 0 on success; anything else aborts the
- * loop with MC_ESTATE.  Replaces 3 calls per layer (5 with VACE) by two re-entries for the collective; a C / C++ host
- * calls ncclAllGather + hipStreamWaitEvent in the callback, the Python shim torch.distributed (magcache_amd/parallel.py).
- * Reference counterpart: the USP flags of MagCache4Wan2.1/magcache_generate.py:813-829,891 (xfuser). */
+/* The same layer loop in ONE call (sp_size > 1).  For every layer in [layer_begin, layer_end) the engine runs pre_kv, calls
+ * gather(user, layer, 2 c, stream) for every round c -- the caller STARTS round c of the all-gather on its own communicator,
+ * ordered behind the work `stream` already holds --, runs pre_q and the local-shard attention beside them, then per round
+ * gather(user, layer, 2 c + 1, stream) -- the caller makes `stream` wait for round c, no host sync -- and the attention over
+ * that round; with overlap == 0 every wait comes right after the starts, so that nothing runs beside the collective; then
+ * post_attn.  A VACE control block follows its main layer in the same phases with its own gather.  With C = 1 the phase
+ * argument is 0 (start) / 1 (wait).  The callback returns 0 on success; anything else aborts the loop with MC_ESTATE.  The
+ * waits are logged as MC_PROF_SP_WAIT.  A C / C++ host calls ncclAllGather + hipStreamWaitEvent in the callback
+ * (mc_blocks_sp_rccl below does exactly that), the Python shim torch.distributed (magcache_amd/parallel.py: the gloo / test
+ * path).  Reference counterpart: the USP flags of MagCache4Wan2.1/magcache_generate.py:813-829,891 (xfuser). */
 typedef int (*mc_sp_gather_fn)(void* user, int layer, int phase, mc_stream stream);
 mc_status mc_blocks_sp(mc_engine* e, int layer_begin, int layer_end, int branch, mc_mode mode, int overlap,
                        mc_sp_gather_fn gather, void* user, mc_stream stream);
+/* geometry a host of the sequence-parallel calls needs (NULL outputs are skipped): layers, tokens of the whole sequence,
+ * tokens of this rank, row stride of "head_tokens" (fp32 elements), model width, sp_size; and the workspace address given to
+ * mc_set_workspace (mc_buffer_info's offsets are relative to it) */
+mc_status mc_sp_geometry(const mc_engine* e, int* num_layers, int* seq_len, int* rows_per_rank, int* head_stride, int* dim,
+                         int* sp_size);
+void* mc_workspace_base(const mc_engine* e);
+
+/* ---- the collective inside the library (csrc/sp_rccl.cpp): an RCCL communicator held by the C side, bound at run time
+ * (dlopen of the librccl already mapped into the process, else the system one: no link dependency, single-GPU users never
+ * load it).  Bootstrap like any NCCL program: ONE rank calls mc_sp_comm_id, the MC_SP_ID_BYTES bytes reach the others by
+ * whatever channel the host has (the Python shim: broadcast_object_list over its existing process group), every rank calls
+ * mc_sp_comm_create (collective; on the calling thread's current device).  The communicator owns a high-priority stream on
+ * which the gather rounds run beside the launch stream, and the events that order the two.
+ * mc_blocks_sp_rccl = mc_blocks_sp with ncclAllGather + hipStreamWaitEvent as the callback;
+ * mc_forward_sp_rccl = the whole sharded evaluation in ONE call: mc_embed, the layer loop, (MC_MODE_CALIB) the all-reduce
+ * of "calib_sums" + mc_calib_finalize, mc_head, the all-gather of every rank's head tokens into tokens_full_dev
+ * (fp32 [seq_len][head_stride], caller-owned) and mc_unpatchify -> out_dev [out_dim, F, H, W] on every rank. */
+#define MC_SP_ID_BYTES 128
+typedef struct mc_sp_comm mc_sp_comm;
+mc_status mc_sp_comm_id(void* id_out);
+mc_status mc_sp_comm_create(const void* id, int nranks, int rank, mc_sp_comm** out);
+void mc_sp_comm_destroy(mc_sp_comm* c);
+const char* mc_sp_comm_info(const mc_sp_comm* c); /* "rccl <version> from <library>; N ranks, rank r" */
+mc_status mc_blocks_sp_rccl(mc_engine* e, mc_sp_comm* c, int layer_begin, int layer_end, int branch, mc_mode mode,
+                            int overlap, mc_stream stream);
+mc_status mc_forward_sp_rccl(mc_engine* e, mc_sp_comm* c, const float* latent_dev, const float* t_dev, double t_host,
+                             const void* context_dev, mc_dtype ctx_dtype, int ctx_len, int branch, mc_mode mode,
+                             int overlap, float* tokens_full_dev, float* out_dev, mc_stream stream);
 /* VACE under sequence parallelism: control block i in the same two phases (K/V all-gather between them); call them
  * after mc_block_post_attn of main layer i * vace_stride, vace_block_post adds the hint to the main stream */
 mc_status mc_vace_block_pre(mc_engine* e, int i, mc_stream stream);

@@ -17,7 +17,7 @@ MC_F32, MC_BF16 = 0, 1
 MC_MODE_FULL, MC_MODE_SKIP, MC_MODE_CALIB = 0, 1, 2
 # mc_prof_class, in enum order (include/magcache_hip.h)
 PROF_CLASSES = ("attn_self", "attn_cross", "gemm_qkv", "gemm_o", "gemm_cross_q", "gemm_cross_o", "gemm_ffn1", "gemm_ffn2",
-                "ln_modulate", "rmsnorm_rope", "embed", "head", "other")
+                "ln_modulate", "rmsnorm_rope", "embed", "head", "other", "sp_wait")
 RULE_VARIANTS = {"wan21": 0, "hunyuan": 1, "flux": 2, "wan22_t2v": 3, "wan22_i2v": 4, "wan22_ti2v": 5, "framepack": 6,
                  "omnigen2": 7, "qwen": 8, "eval_wan": 9, "eval_opensora": 10}
 
@@ -28,7 +28,7 @@ class McConfig(C.Structure):
                [("eps", C.c_float)] + \
                [(n, C.c_int) for n in ("sp_rank", "sp_size", "n_branches", "calibration", "clip_dim", "vace_layers",
                                          "vace_stride", "vace_in_dim", "fp8_linear", "no_context_cache",
-                                         "no_token_timesteps")]
+                                         "no_token_timesteps", "sp_phases")]
 
 
 class MagCacheHipError(RuntimeError):
@@ -65,7 +65,20 @@ SIGNATURES = {
     "mc_profile_read_classes": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
     "mc_embed": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _vp]),
     "mc_block_pre_attn": (_i, [_vp, _i, _vp]),
+    "mc_block_pre_kv": (_i, [_vp, _i, _vp]),
+    "mc_block_pre_q": (_i, [_vp, _i, _vp]),
+    "mc_sp_set_chunks": (_i, [_vp, _i]),
+    "mc_sp_round_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "mc_sp_geometry": (_i, [_vp] + [C.POINTER(_i)] * 6),
+    "mc_workspace_base": (_vp, [_vp]),
     "mc_block_attn_local": (_i, [_vp, _i, _vp]),
+    "mc_block_attn_round": (_i, [_vp, _i, _i, _vp]),
+    "mc_sp_comm_id": (_i, [_vp]),
+    "mc_sp_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "mc_sp_comm_destroy": (None, [_vp]),
+    "mc_sp_comm_info": (C.c_char_p, [_vp]),
+    "mc_blocks_sp_rccl": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mc_forward_sp_rccl": (_i, [_vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mc_block_post_attn": (_i, [_vp, _i, _i, _i, _vp]),
     "mc_blocks_sp": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mc_vace_block_pre": (_i, [_vp, _i, _vp]),

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmagcache_hip.so")
 SOURCES = ["gemm_bf16.hip", "gemm_bf16_big.hip", "gemm_bf16_v2.hip", "gemm_fp8_big.hip", "gemm_mxfp8.hip", "attention_v3.hip", "attention_v5.hip", "elementwise.hip",
-           "magcache_ops.hip", "engine.cpp", "mmdit_engine.cpp", "rule.cpp"]
+           "magcache_ops.hip", "engine.cpp", "mmdit_engine.cpp", "rule.cpp", "sp_rccl.cpp"]
 # the attention kernel's hand-interleaved VALU stream must stay scalar: the SLP vectoriser packs the row-sum
 # adds into v_pk_add_f32 and moves them out of the MFMA shadow
 EXTRA_FLAGS = {"attention_v3.hip": ["-fno-slp-vectorize"]}
@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

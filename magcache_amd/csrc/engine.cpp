@@ -92,7 +92,14 @@ struct mc_engine {
         *ln_img4_b = nullptr;
   int img_rows = 0;     // 257 image tokens padded to a multiple of 64
   bool have_clip = false;
-  int local_attn_layer = -1;  // layer whose local-shard attention already ran (two-phase SP attention)
+  // sequence parallel (P > 1): the gathered K|V of a layer arrive in sp_chunks rounds (mc_sp_set_chunks); the self-attention
+  // of a layer is a chain of launches merged by their log2-sum-exp: [this rank's shard] + one launch per round
+  bool sp = false;             // sp_size > 1, or sp_phases: the phase path with its buffers on a world of one
+  int sp_chunks = 1;
+  int attn_layer = -2;         // whose attention chain is open: main layer >= 0, a VACE block -1, none -2
+  int attn_launches = 0;       // launches of that chain so far ("ao" / "attn_lse" hold their merged result)
+  bool attn_local_done = false;
+  int attn_rounds_done = 0;
   // text context cache (mc_set_context): per slot the embedded context and every block's normalised cross-attention
   // K|V; a forward called with context_dev == NULL reads slot ctx_active instead of recomputing them
   bool ctx_valid[2] = {false, false};
@@ -249,7 +256,7 @@ extern int g_mmdit_two_streams;   // mmdit_engine.cpp: mc_set_option("mmdit_two_
 extern "C" {
 
 const char* mc_last_error(void) { return g_err; }
-const char* mc_version(void) { return "magcache_hip 0.4 (gfx950)"; }
+const char* mc_version(void) { return "magcache_hip 0.5 (gfx950)"; }
 
 // mc_config only ever grows at its END, and a zero in a new field keeps the behaviour older callers had: a caller built
 // against an older header passes ITS sizeof(mc_config) and the tail reads as zeros (instead of being read past the end of
@@ -294,6 +301,7 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   e->d = c.dim; e->ffn = c.ffn_dim; e->H = c.num_heads; e->NL = c.num_layers;
   e->L = c.latent_f * (c.latent_h / 2) * (c.latent_w / 2);
   e->P = c.sp_size; e->rank = c.sp_rank;
+  e->sp = c.sp_size > 1 || c.sp_phases != 0;
   if (e->L % e->P) {
     const int seq_len = e->L;
     delete e;
@@ -497,7 +505,10 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
   }
   add_buf(e, cur, "ehead", 2 * 2 * d * 4);
   add_buf(e, cur, "head_tokens", (size_t)Lp * e->HT * 4);
-  add_buf(e, cur, "kv_gather", e->P > 1 ? (size_t)e->P * Lp * 2 * d * 2 : 256);
+  // sequence parallel: "kv_local" [Lp][2d] = this rank's post-norm, post-RoPE K|V rows (the send buffer of the gather);
+  // "kv_gather" [C][P][Lp / C][2d] = round c of the gather holds rows [c Lp / C, (c + 1) Lp / C) of EVERY rank's shard
+  add_buf(e, cur, "kv_local", e->sp ? Lp * 2 * d * 2 : 256);
+  add_buf(e, cur, "kv_gather", e->sp ? (size_t)e->P * Lp * 2 * d * 2 : 256);
   add_buf(e, cur, "residual0", Lp * d * 4);
   add_buf(e, cur, "residual1", c.n_branches > 1 ? Lp * d * 4 : 256);
   add_buf(e, cur, "residual2", c.calibration ? Lp * d * 4 : 256);
@@ -512,18 +523,11 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_buf(e, cur, "ckv_img", ir * 2 * d * 2);
     add_buf(e, cur, "ao2", Lp * d * 2);
   }
-  if (e->P > 1) add_buf(e, cur, "attn_lse", (size_t)e->H * Lp * 4);
+  if (e->sp) add_buf(e, cur, "attn_lse", (size_t)e->H * Lp * 4);
   add_buf(e, cur, "calib_partial", (2048 * 4 + 2) * 8);   // + the arrival ticket of calib_stats_kernel
   add_buf(e, cur, "calib_sums", 4 * 8);
   add_buf(e, cur, "calib_stats", 2 * 3 * 4);
   e->ws_need = cur;
-  // "kv_local": this rank's slice of the gather buffer
-  if (e->P > 1) {
-    Buf b = e->bufs["kv_gather"];
-    b.off += (size_t)e->rank * Lp * 2 * d * 2;
-    b.bytes = Lp * 2 * d * 2;
-    e->bufs["kv_local"] = b;
-  }
   *out = e;
   return MC_OK;
 }
@@ -840,7 +844,21 @@ static const float* second_set(const mc_engine* e, const float* em) {
 }
 static const uint8_t* tok_sel(const mc_engine* e) { return e->tok_t ? e->buf<uint8_t>("tok_sel") : nullptr; }
 
-static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float* x, hipStream_t s) {
+// ---- sequence-parallel geometry of the gather rounds (mc_sp_set_chunks)
+static int sp_chunk_rows(const mc_engine* e) { return e->Lp / e->sp_chunks; }
+static int sp_round_valid(const mc_engine* e, int c) {   // valid keys at the start of every shard's chunk c
+  const int lc = sp_chunk_rows(e);
+  return std::max(0, std::min(lc, e->Lr - c * lc));
+}
+static int sp_rounds(const mc_engine* e) {               // rounds that carry at least one valid key
+  const int lc = sp_chunk_rows(e);
+  return (e->Lr + lc - 1) / lc;
+}
+
+// LayerNorm + modulate -> "xn"; one device: q|k|v Linear -> "qkv", RMSNorm + RoPE of q and k (everything before attention).
+// Sequence parallel: only what the OTHER ranks wait for -- the [k|v] Linear into "kv_local" and the k norm / RoPE --, so that
+// the caller can start the all-gather before this rank's q exists (block_pre_q).
+static mc_status block_pre_kv(mc_engine* e, const Layer& l, const float* em, float* x, hipStream_t s) {
   const int d = e->d, Lp = e->Lp;
   bf16_t* xn = e->buf<bf16_t>("xn");
   bf16_t* qkv = e->buf<bf16_t>("qkv");
@@ -849,11 +867,11 @@ static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float*
   bool fused = false;
   {
     Prof pr(e, MC_PROF_LN_MODULATE, s);
-    mc_status st = ln_for_gemm(e, e->P == 1 && l.q_wqkv, l.m_wqkv != nullptr, x, em + d, em, 0, em2 ? em2 + d : nullptr, em2,
+    mc_status st = ln_for_gemm(e, !e->sp && l.q_wqkv, l.m_wqkv != nullptr, x, em + d, em, 0, em2 ? em2 + d : nullptr, em2,
                                sel, s, &fused);
     if (st != MC_OK) return st;
   }
-  if (e->P == 1) {
+  if (!e->sp) {
     mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, 3 * d, d);
     p.Cb = qkv; p.ldc = 3 * d;
     {
@@ -869,52 +887,170 @@ static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float*
     HIP_TRY(mc::launch_rmsnorm_rope(qkv, 3 * d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
     HIP_TRY(mc::launch_rmsnorm_rope(qkv + d, 3 * d, l.nk, e->cfg.eps, e->cs_table, 0, Lp, d, s));
   } else {
-    // q -> qkv[:, :d] (ld d) ; [k|v] -> this rank's rows of the gather buffer (ld 2d)
+    // [k|v] -> "kv_local" (ld 2d): the rows every other rank needs, first
     bf16_t* kvl = e->buf<bf16_t>("kv_local");
     {
       Prof pr(e, MC_PROF_GEMM_QKV, s);
-      mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, d, d);
-      p.Cb = qkv; p.ldc = d;
-      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
       mc::GemmParams q = gp(xn, d, l.wqkv + (size_t)d * d, d, l.bqkv + d, Lp, 2 * d, d);
       q.Cb = kvl; q.ldc = 2 * d;
       HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
     }
     Prof pr(e, MC_PROF_RMSNORM_ROPE, s);
-    HIP_TRY(mc::launch_rmsnorm_rope(qkv, d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
     HIP_TRY(mc::launch_rmsnorm_rope(kvl, 2 * d, l.nk, e->cfg.eps, e->cs_table, 0, Lp, d, s));
   }
+  e->attn_layer = -2;   // a new layer: no attention chain open
+  return MC_OK;
+}
+
+// sequence parallel only: q Linear of the rows block_pre_kv normalised ("xn") -> "qkv"[:, :d] (ld d), q norm / RoPE; runs
+// beside the all-gather the caller started in between
+static mc_status block_pre_q(mc_engine* e, const Layer& l, hipStream_t s) {
+  const int d = e->d, Lp = e->Lp;
+  if (!e->sp) return MC_OK;
+  bf16_t* xn = e->buf<bf16_t>("xn");
+  bf16_t* qkv = e->buf<bf16_t>("qkv");
+  {
+    Prof pr(e, MC_PROF_GEMM_QKV, s);
+    mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, d, d);
+    p.Cb = qkv; p.ldc = d;
+    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+  }
+  Prof pr(e, MC_PROF_RMSNORM_ROPE, s);
+  HIP_TRY(mc::launch_rmsnorm_rope(qkv, d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
+  return MC_OK;
+}
+
+static mc_status block_pre(mc_engine* e, const Layer& l, const float* em, float* x, hipStream_t s) {
+  mc_status st = block_pre_kv(e, l, em, x, s);
+  return st != MC_OK ? st : block_pre_q(e, l, s);
+}
+
+static mc_status check_layer_call(mc_engine* e, int layer) {
+  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
+  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
   return MC_OK;
 }
 
 mc_status mc_block_pre_attn(mc_engine* e, int layer, mc_stream stream_) {
-  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
-  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
+  if (mc_status st = check_layer_call(e, layer); st != MC_OK) return st;
   return block_pre(e, e->layers[layer], e->buf<float>("emod") + (size_t)layer * 6 * e->d, e->buf<float>("x"),
                    (hipStream_t)stream_);
 }
 
-// Self-attention over this rank's own K/V shard (slot `rank` of "kv_gather"): normalised partial result -> "ao",
-// log2-sum-exp -> "attn_lse".  Needs nothing from the other ranks, so the caller overlaps it with the all-gather.
-mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream_) {
-  hipStream_t s = (hipStream_t)stream_;
-  if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
-  if (layer < 0 || layer >= e->NL) return fail(MC_EINVAL, "layer %d out of range", layer);
-  if (e->P < 2) return fail(MC_ESTATE, "mc_block_attn_local needs sp_size > 1");
+// The two halves of mc_block_pre_attn (sp_size > 1): a caller that starts its all-gather between them overlaps it with the q
+// Linear as well.  mc_block_pre_attn == mc_block_pre_kv + mc_block_pre_q.
+mc_status mc_block_pre_kv(mc_engine* e, int layer, mc_stream stream_) {
+  if (mc_status st = check_layer_call(e, layer); st != MC_OK) return st;
+  if (!e->sp) return fail(MC_ESTATE, "mc_block_pre_kv needs a sequence-parallel engine (sp_size > 1 or sp_phases) (one GPU: mc_block_pre_attn / mc_forward)");
+  return block_pre_kv(e, e->layers[layer], e->buf<float>("emod") + (size_t)layer * 6 * e->d, e->buf<float>("x"),
+                      (hipStream_t)stream_);
+}
+
+mc_status mc_block_pre_q(mc_engine* e, int layer, mc_stream stream_) {
+  if (mc_status st = check_layer_call(e, layer); st != MC_OK) return st;
+  if (!e->sp) return fail(MC_ESTATE, "mc_block_pre_q needs a sequence-parallel engine (sp_size > 1 or sp_phases)");
+  return block_pre_q(e, e->layers[layer], (hipStream_t)stream_);
+}
+
+// One launch of a layer's self-attention chain (sp_size > 1).  round < 0: this rank's own shard ("kv_local", needs nothing
+// from the other ranks); round c >= 0: chunk c of the gathered shards ("kv_gather"[c] = [P][Lp / C][2d]), without this
+// rank's shard when the local launch already covered it.  The first launch of a chain writes "ao" and the log2-sum-exp of
+// the keys it visited ("attn_lse"); every later one merges into both in the kernel epilogue (in place).
+static mc_status sp_attn_launch(mc_engine* e, int layer, int round, hipStream_t s) {
   const int d = e->d, Lp = e->Lp;
-  bf16_t* kvl = e->buf<bf16_t>("kv_local");
+  if (e->attn_layer != layer) {
+    e->attn_layer = layer; e->attn_launches = 0; e->attn_local_done = false; e->attn_rounds_done = 0;
+  }
+  const int n_rounds = sp_rounds(e);
   mc::AttnParams a;
   memset(&a, 0, sizeof(a));
   a.O = e->buf<bf16_t>("ao"); a.ldo = d; a.Lq_pad = Lp; a.n_heads = e->H; a.scale = 1.0f / std::sqrt(128.0f);
   a.Q = e->buf<bf16_t>("qkv"); a.ldq = d;
-  a.K = kvl; a.ldk = 2 * d; a.V = kvl + d; a.ldv = 2 * d;
-  a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
-  a.lse_out = e->buf<float>("attn_lse");
+  bool more;   // does another launch of this chain follow?
+  if (round < 0) {
+    if (e->attn_launches) return fail(MC_ESTATE, "the local-shard attention must be the first launch of a layer's chain");
+    bf16_t* kvl = e->buf<bf16_t>("kv_local");
+    a.K = kvl; a.ldk = 2 * d; a.V = kvl + d; a.ldv = 2 * d;
+    a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
+    more = true;
+  } else {
+    if (round != e->attn_rounds_done || round >= n_rounds)
+      return fail(MC_ESTATE, "attention round %d out of order (rounds done %d of %d)", round, e->attn_rounds_done, n_rounds);
+    const int lc = sp_chunk_rows(e);
+    bf16_t* kvg = e->buf<bf16_t>("kv_gather") + (size_t)round * e->P * lc * 2 * d;
+    a.K = kvg; a.ldk = 2 * d; a.k_shard_stride = (long)lc * 2 * d;
+    a.V = kvg + d; a.ldv = 2 * d; a.v_shard_stride = (long)lc * 2 * d;
+    a.shard_rows = lc; a.shard_valid = sp_round_valid(e, round); a.n_shards = e->P;
+    if (e->attn_local_done) a.skip_shard_p1 = e->rank + 1;
+    more = round + 1 < n_rounds;
+    if (e->attn_local_done && e->P == 1) {   // a world of one (sp_phases): the local launch covered every key
+      e->attn_rounds_done++;
+      return MC_OK;
+    }
+  }
+  if (e->attn_launches) a.lse_in = e->buf<float>("attn_lse");
+  if (more) a.lse_out = e->buf<float>("attn_lse");
   {
     Prof pr(e, MC_PROF_ATTN_SELF, s);   // measurement hook, see mc_profile_enable
     HIP_TRY(mc::launch_attention(a, s));
   }
-  e->local_attn_layer = layer;
+  e->attn_launches++;
+  if (round < 0) e->attn_local_done = true; else e->attn_rounds_done++;
+  return MC_OK;
+}
+
+// Self-attention over this rank's own K/V shard ("kv_local"): normalised partial result -> "ao", log2-sum-exp ->
+// "attn_lse".  Needs nothing from the other ranks, so the caller overlaps it with the all-gather.
+mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream_) {
+  if (mc_status st = check_layer_call(e, layer); st != MC_OK) return st;
+  if (!e->sp) return fail(MC_ESTATE, "mc_block_attn_local needs a sequence-parallel engine (sp_size > 1 or sp_phases)");
+  return sp_attn_launch(e, layer, -1, (hipStream_t)stream_);
+}
+
+// Self-attention over round `round` of the gathered shards (rounds in order 0 .. mc_sp_rounds - 1; the caller has made
+// `stream` wait for that round of its all-gather).  mc_block_post_attn attends whatever rounds are still missing.
+mc_status mc_block_attn_round(mc_engine* e, int layer, int round, mc_stream stream_) {
+  if (mc_status st = check_layer_call(e, layer); st != MC_OK) return st;
+  if (!e->sp) return fail(MC_ESTATE, "mc_block_attn_round needs a sequence-parallel engine (sp_size > 1 or sp_phases)");
+  if (round < 0) return fail(MC_EINVAL, "round %d", round);
+  return sp_attn_launch(e, layer, round, (hipStream_t)stream_);
+}
+
+// Rounds of the K|V all-gather per layer: round c moves rows [c Lp / C, (c + 1) Lp / C) of every rank's "kv_local" into
+// "kv_gather"[c] ([P][Lp / C][2 dim] bf16), and the attention over it runs while round c + 1 is on the wire.  C = 1 is one
+// all-gather of whole shards.  Lp / C must be a multiple of 64 (Lp is a multiple of 256: 1, 2 and 4 always work).
+mc_status mc_sp_set_chunks(mc_engine* e, int chunks) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (!e->sp) return fail(MC_ESTATE, "mc_sp_set_chunks needs a sequence-parallel engine (sp_size > 1 or sp_phases)");
+  if (chunks < 1 || chunks > 64 || e->Lp % chunks || (e->Lp / chunks) % 64)
+    return fail(MC_EINVAL, "sp chunks %d: rows per shard %d / chunks must be a multiple of 64", chunks, e->Lp);
+  e->sp_chunks = chunks;
+  e->attn_layer = -2;
+  return MC_OK;
+}
+
+mc_status mc_sp_geometry(const mc_engine* e, int* num_layers, int* seq_len, int* rows_per_rank, int* head_stride, int* dim,
+                         int* sp_size) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (num_layers) *num_layers = e->NL;
+  if (seq_len) *seq_len = e->L;
+  if (rows_per_rank) *rows_per_rank = e->Lr;
+  if (head_stride) *head_stride = e->HT;
+  if (dim) *dim = e->d;
+  if (sp_size) *sp_size = e->P;
+  return MC_OK;
+}
+
+void* mc_workspace_base(const mc_engine* e) { return e ? (void*)e->ws : nullptr; }
+
+// geometry of round `round` (NULL outputs are skipped): rows per shard chunk, valid keys at the start of each, and the
+// number of rounds that carry valid keys (later rounds hold padding only: neither gathered nor attended)
+mc_status mc_sp_round_info(const mc_engine* e, int round, int* n_rounds, int* chunk_rows, int* valid) {
+  if (!e) return fail(MC_EINVAL, "null engine");
+  if (round < 0 || round >= e->sp_chunks) return fail(MC_EINVAL, "round %d of %d", round, e->sp_chunks);
+  if (n_rounds) *n_rounds = e->sp ? sp_rounds(e) : 0;
+  if (chunk_rows) *chunk_rows = sp_chunk_rows(e);
+  if (valid) *valid = sp_round_valid(e, round);
   return MC_OK;
 }
 
@@ -932,29 +1068,24 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
   const uint8_t* sel = tok_sel(e);
 
   // ---- self attention over the full sequence
-  {
+  if (!e->sp) {
     mc::AttnParams a;
     memset(&a, 0, sizeof(a));
     a.O = ao; a.ldo = d; a.Lq_pad = Lp; a.n_heads = e->H; a.scale = scale;
-    if (e->P == 1) {
-      a.Q = qkv; a.ldq = 3 * d;
-      a.K = qkv + d; a.ldk = 3 * d; a.k_shard_stride = 0;
-      a.V = qkv + 2 * d; a.ldv = 3 * d; a.v_shard_stride = 0;
-      a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
-    } else {
-      bf16_t* kvg = e->buf<bf16_t>("kv_gather");
-      a.Q = qkv; a.ldq = d;
-      a.K = kvg; a.ldk = 2 * d; a.k_shard_stride = (long)Lp * 2 * d;
-      a.V = kvg + d; a.ldv = 2 * d; a.v_shard_stride = (long)Lp * 2 * d;
-      a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = e->P;
-      if (layer >= 0 && e->local_attn_layer == layer) {  // the local shard is done: the others only, merged into ao
-        a.skip_shard_p1 = e->rank + 1;
-        a.lse_in = e->buf<float>("attn_lse");
-      }
-      e->local_attn_layer = -1;
-    }
+    a.Q = qkv; a.ldq = 3 * d;
+    a.K = qkv + d; a.ldk = 3 * d; a.k_shard_stride = 0;
+    a.V = qkv + 2 * d; a.ldv = 3 * d; a.v_shard_stride = 0;
+    a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
     Prof pr(e, MC_PROF_ATTN_SELF, s);
     HIP_TRY(mc::launch_attention(a, s));
+  } else {
+    // whatever the caller has not attended yet (mc_block_attn_local / mc_block_attn_round): the remaining gather rounds
+    if (e->attn_layer != layer) { e->attn_layer = layer; e->attn_launches = 0; e->attn_local_done = false; e->attn_rounds_done = 0; }
+    while (e->attn_rounds_done < sp_rounds(e)) {
+      mc_status st = sp_attn_launch(e, layer, e->attn_rounds_done, s);
+      if (st != MC_OK) return st;
+    }
+    e->attn_layer = -2;
   }
   {  // x = x + o(attn) * e[2]
     Prof pr(e, MC_PROF_GEMM_O, s);
@@ -1121,7 +1252,7 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
 
 // VACE: control block i on the stream c, then x += after_proj(c) * context_scale (the "hint" of main layer
 // i * vace_stride; upstream VaceWanAttentionBlock / BaseWanAttentionBlock, reference call site :544-549)
-static mc_status vace_pre(mc_engine* e, int i, hipStream_t s) {
+static mc_status vace_pre_kv(mc_engine* e, int i, hipStream_t s) {
   const int d = e->d, Lp = e->Lp;
   float* xc = e->buf<float>("xc");
   if (i == 0) {
@@ -1132,7 +1263,12 @@ static mc_status vace_pre(mc_engine* e, int i, hipStream_t s) {
     p.X = xc; p.ldx = d; p.gate = nullptr;
     HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_RESID_GATE, s));
   }
-  return block_pre(e, e->vlayers[i], e->buf<float>("emod") + (size_t)(e->NL + i) * 6 * d, xc, s);
+  return block_pre_kv(e, e->vlayers[i], e->buf<float>("emod") + (size_t)(e->NL + i) * 6 * d, xc, s);
+}
+
+static mc_status vace_pre(mc_engine* e, int i, hipStream_t s) {
+  mc_status st = vace_pre_kv(e, i, s);
+  return st != MC_OK ? st : block_pre_q(e, e->vlayers[i], s);
 }
 
 static mc_status vace_post(mc_engine* e, int i, int branch, mc_mode mode, hipStream_t s) {
@@ -1171,39 +1307,65 @@ mc_status mc_vace_block_post(mc_engine* e, int i, int branch, mc_mode mode, mc_s
   return vace_post(e, i, branch, mode, (hipStream_t)stream);
 }
 
-// Sequence parallel, the layer loop in ONE call: for every layer in [layer_begin, layer_end)
-//   pre_attn -> gather(user, layer, 0)  [the caller STARTS its all-gather of "kv_gather", ordered behind what `stream` holds]
-//            -> attn_local              [this rank's shard, beside the gather]
-//            -> gather(user, layer, 1)  [the caller makes `stream` wait for the gather: no host sync; overlap == 0: this
-//                                        call comes BEFORE attn_local, nothing runs beside the collective]
-//            -> post_attn (+ the VACE control block of that layer in the same two phases, with its own gather)
-// i.e. exactly the sequence parallel.py issued phase by phase (mc_block_pre_attn / _attn_local / _post_attn stay exported:
-// same code underneath).  The host is re-entered only for the collective, twice per layer.
+// Sequence parallel, the layer loop in ONE call.  With C = mc_sp_set_chunks rounds (R of them carry valid keys), for every
+// layer in [layer_begin, layer_end):
+//   pre_kv                                  [LayerNorm, k|v Linear -> "kv_local", k norm / RoPE: what the peers wait for]
+//   gather(user, layer, 2 c, stream)        c = 0 .. R-1: the caller STARTS round c of its all-gather (rows
+//                                           [c Lp/C, (c+1) Lp/C) of "kv_local" -> "kv_gather"[c]) on its own communicator,
+//                                           ordered behind what `stream` holds
+//   pre_q, attn_local                       [q Linear + norm / RoPE, this rank's shard: beside the gather]
+//   gather(user, layer, 2 c + 1, stream)    the caller makes `stream` wait for round c (no host sync) ...
+//   attn_round c                            ... and the attention over it runs while round c + 1 is on the wire
+//   post_attn                               (+ the VACE control block of that layer in the same phases, with its own gather)
+// overlap == 0: every wait comes right after the starts -- nothing runs beside the collective (the A/B baseline).
+// The phase argument of C = 1 is the 0 / 1 (start / wait) of the unchunked protocol.  The waits are bracketed as
+// MC_PROF_SP_WAIT: with mc_profile_enable(2) their summed time is what the launch stream idled for the collective.
+// mc_block_pre_kv / _pre_q / _attn_local / _attn_round / _post_attn stay exported: same code underneath.
 mc_status mc_blocks_sp(mc_engine* e, int layer_begin, int layer_end, int branch, mc_mode mode, int overlap,
                        mc_sp_gather_fn gather, void* user, mc_stream stream) {
   if (!e || !e->embedded) return fail(MC_ESTATE, "mc_embed must run first");
   if (!gather) return fail(MC_EINVAL, "null gather callback");
-  if (e->P < 2) return fail(MC_ESTATE, "mc_blocks_sp needs sp_size > 1 (one GPU: mc_forward)");
+  if (!e->sp) return fail(MC_ESTATE, "mc_blocks_sp needs a sequence-parallel engine (sp_size > 1 or sp_phases) (one GPU: mc_forward)");
   if (layer_begin < 0 || layer_end > e->NL || layer_begin > layer_end)
     return fail(MC_EINVAL, "layers [%d, %d) out of range (num_layers %d)", layer_begin, layer_end, e->NL);
   if (mode == MC_MODE_SKIP) return fail(MC_EINVAL, "a skipped forward runs no blocks (mc_embed -> mc_head)");
+  hipStream_t s = (hipStream_t)stream;
+  const int R = sp_rounds(e);
   auto coll = [&](int layer, int phase) -> mc_status {
     const int rc = gather(user, layer, phase, stream);
     return rc == 0 ? MC_OK : fail(MC_ESTATE, "gather callback failed (layer %d, phase %d, code %d)", layer, phase, rc);
   };
+  auto wait_round = [&](int layer, int c) -> mc_status {
+    Prof pr(e, MC_PROF_SP_WAIT, s);
+    return coll(layer, 2 * c + 1);
+  };
+  // one attention chain: starts, [waits], q, local shard, ([wait] round) x R
+  auto attend = [&](int l, const Layer& ly, int chain) -> mc_status {
+    mc_status st;
+    for (int c = 0; c < R; ++c)
+      if ((st = coll(l, 2 * c)) != MC_OK) return st;
+    if (!overlap)
+      for (int c = 0; c < R; ++c)
+        if ((st = wait_round(l, c)) != MC_OK) return st;
+    if ((st = block_pre_q(e, ly, s)) != MC_OK) return st;
+    if ((st = sp_attn_launch(e, chain, -1, s)) != MC_OK) return st;
+    for (int c = 0; c < R; ++c) {
+      if (overlap && (st = wait_round(l, c)) != MC_OK) return st;
+      if ((st = sp_attn_launch(e, chain, c, s)) != MC_OK) return st;
+    }
+    return MC_OK;
+  };
+  const int d = e->d;
   for (int l = layer_begin; l < layer_end; ++l) {
-    mc_status st = mc_block_pre_attn(e, l, stream);
+    mc_status st = block_pre_kv(e, e->layers[l], e->buf<float>("emod") + (size_t)l * 6 * d, e->buf<float>("x"), s);
     if (st != MC_OK) return st;
-    if ((st = coll(l, 0)) != MC_OK) return st;
-    if (!overlap && (st = coll(l, 1)) != MC_OK) return st;     // serialised: nothing runs beside the collective
-    if ((st = mc_block_attn_local(e, l, stream)) != MC_OK) return st;
-    if (overlap && (st = coll(l, 1)) != MC_OK) return st;
+    if ((st = attend(l, e->layers[l], l)) != MC_OK) return st;
     if ((st = mc_block_post_attn(e, l, branch, mode, stream)) != MC_OK) return st;
     if (e->NV > 0 && l % e->cfg.vace_stride == 0 && l / e->cfg.vace_stride < e->NV) {
       const int i = l / e->cfg.vace_stride;
-      if ((st = mc_vace_block_pre(e, i, stream)) != MC_OK) return st;
-      if ((st = coll(l, 0)) != MC_OK) return st;
-      if ((st = coll(l, 1)) != MC_OK) return st;
+      if (!e->have_vace) return fail(MC_ESTATE, "mc_set_vace_context must run first");
+      if ((st = vace_pre_kv(e, i, s)) != MC_OK) return st;
+      if ((st = attend(l, e->vlayers[i], -1)) != MC_OK) return st;
       if ((st = mc_vace_block_post(e, i, branch, mode, stream)) != MC_OK) return st;
     }
   }
@@ -1271,7 +1433,7 @@ mc_status mc_forward(mc_engine* e, const float* latent_dev, const float* t_dev, 
                      const void* context_dev, mc_dtype ctx_dtype, int ctx_len, int branch, mc_mode mode,
                      float* out_dev, mc_stream stream) {
   if (!e) return fail(MC_EINVAL, "null engine");
-  if (e->P != 1) return fail(MC_ESTATE, "mc_forward is single-GPU; drive a sharded engine through the phase calls");
+  if (e->sp) return fail(MC_ESTATE, "mc_forward is single-GPU; drive a sharded engine through the phase calls");
   if (!out_dev) return fail(MC_EINVAL, "null output");
   if (e->NV > 0 && mode != MC_MODE_SKIP && !e->have_vace)
     return fail(MC_ESTATE, "VACE model: mc_set_vace_context must run before a non-skipped forward");

@@ -96,7 +96,8 @@ def synthetic_weights(cfg, seed=0, std=0.02, device="cuda"):
 class Engine:
     """One DiT engine on one device (one per process).  latent grid = (F, H, W) of the VAE latent."""
 
-    def __init__(self, cfg, latent_grid, device="cuda:0", sp_rank=0, sp_size=1, n_branches=2, calibration=False):
+    def __init__(self, cfg, latent_grid, device="cuda:0", sp_rank=0, sp_size=1, n_branches=2, calibration=False,
+                 sp_phases=False):
         if not torch.cuda.is_available():
             raise RuntimeError("magcache_amd.Engine needs a ROCm device; there is no CPU fallback")
         self.lib = _lib.load()
@@ -114,9 +115,10 @@ class Engine:
                      vace_in_dim=cfg.get("vace_in_dim", 0) if vace_geometry(cfg)[0] else 0,
                      fp8_linear=int(cfg.get("fp8_linear", 0) or 0),
                      no_context_cache=int(bool(cfg.get("no_context_cache", 0))),
-                     no_token_timesteps=int(bool(cfg.get("no_token_timesteps", 0))))
+                     no_token_timesteps=int(bool(cfg.get("no_token_timesteps", 0))), sp_phases=int(bool(sp_phases)))
         self.context_cache = not cfg.get("no_context_cache", 0)
         self.sp_rank, self.sp_size, self.n_branches = sp_rank, sp_size, n_branches
+        self.sharded = sp_size > 1 or bool(sp_phases)     # driven through the phase calls (parallel.SequenceParallelForward)
         self.vace_layers, self.vace_stride = vace_geometry(cfg)
         h = C.c_void_p()
         check(self.lib.mc_create_sized(C.byref(c), C.sizeof(c), C.byref(h)))
@@ -136,6 +138,9 @@ class Engine:
         try:
             if getattr(self, "h", None):
                 torch.cuda.synchronize(self.device)
+                for comm in getattr(self, "_rccl", []):
+                    self.lib.mc_sp_comm_destroy(comm)
+                self._rccl = []
                 self.lib.mc_destroy(self.h)
                 self.h = None
         except Exception:
@@ -252,7 +257,7 @@ class Engine:
         """latent fp32 [C,F,H,W]; t python float or 1-element tensor on the device; context
         [ctx_len, text_dim] or None (cached slot).  Returns fp32 [out_dim, F, H, W].  Asynchronous on the current
         stream."""
-        assert self.sp_size == 1, "use magcache_amd.parallel.SequenceParallelForward for sp_size > 1"
+        assert not self.sharded, "use magcache_amd.parallel.SequenceParallelForward for a sharded engine"
         latent = latent.float().contiguous()
         ctx, cdt, clen = self._ctx_args(context)
         if out is None:
@@ -281,16 +286,67 @@ class Engine:
     def block_pre_attn(self, layer):
         check(self.lib.mc_block_pre_attn(self.h, layer, _stream()))
 
+    def block_pre_kv(self, layer):
+        check(self.lib.mc_block_pre_kv(self.h, layer, _stream()))
+
+    def block_pre_q(self, layer):
+        check(self.lib.mc_block_pre_q(self.h, layer, _stream()))
+
     def block_attn_local(self, layer):
         check(self.lib.mc_block_attn_local(self.h, layer, _stream()))
+
+    def block_attn_round(self, layer, rnd):
+        check(self.lib.mc_block_attn_round(self.h, layer, rnd, _stream()))
+
+    def sp_set_chunks(self, chunks):
+        """rounds of the per-layer K|V all-gather (mc_sp_set_chunks)"""
+        check(self.lib.mc_sp_set_chunks(self.h, int(chunks)))
+
+    def sp_round_info(self, rnd=0):
+        """(rounds that carry valid keys, rows per shard chunk, valid keys of round `rnd`)"""
+        n, rows, valid = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.mc_sp_round_info(self.h, rnd, C.byref(n), C.byref(rows), C.byref(valid)))
+        return n.value, rows.value, valid.value
+
+    # ---- the collective inside the library (csrc/sp_rccl.cpp)
+    def rccl_attach(self, group=None):
+        """Create the engine-side RCCL communicator of the ranks of `group` (collective: every rank of the group calls it).
+        The 128-byte unique id travels from the group's first rank over the existing torch.distributed group."""
+        import torch.distributed as dist
+        rank, n = dist.get_rank(group), dist.get_world_size(group)
+        assert n == self.sp_size and rank == self.sp_rank, (n, rank, self.sp_size, self.sp_rank)
+        box = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            check(self.lib.mc_sp_comm_id(buf))
+            box[0] = buf.raw
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        comm = C.c_void_p()
+        check(self.lib.mc_sp_comm_create(C.c_char_p(box[0]), n, rank, C.byref(comm)))
+        self._rccl = getattr(self, "_rccl", [])
+        self._rccl.append(comm)
+        return comm
+
+    def rccl_info(self, comm):
+        return self.lib.mc_sp_comm_info(comm).decode()
+
+    def forward_sp_rccl(self, comm, latent, t, context, branch, mode, overlap, tokens_full, out):
+        """the whole sharded evaluation in one C call (mc_forward_sp_rccl)"""
+        latent = latent.float().contiguous()
+        ctx, cdt, clen = self._ctx_args(context)
+        t_dev, t_host = self._t(t)
+        check(self.lib.mc_forward_sp_rccl(self.h, comm, _ptr(latent), _ptr(t_dev), t_host, _ptr(ctx), cdt, clen, branch, mode,
+                                          int(bool(overlap)), _ptr(tokens_full), _ptr(out), _stream()))
+        self._keep = (latent, ctx, t_dev)
 
     def block_post_attn(self, layer, branch, mode):
         check(self.lib.mc_block_post_attn(self.h, layer, branch, mode, _stream()))
 
     def blocks_sp(self, layer_begin, layer_end, branch, mode, overlap, gather):
-        """the sequence-parallel layer loop in one C call (mc_blocks_sp): gather(layer, phase) is called back twice per
-        layer -- phase 0: start the K|V all-gather, phase 1: make the launch stream wait for it.  An exception raised
-        inside the callback aborts the loop and is re-raised here."""
+        """the sequence-parallel layer loop in one C call (mc_blocks_sp): gather(layer, phase) is called back for the
+        collective only -- phase 2 c: start round c of the K|V all-gather, phase 2 c + 1: make the launch stream wait for
+        it (one round: 0 / 1).  An exception raised inside the callback aborts the loop and is re-raised here."""
         from ._lib import SP_GATHER_FN
         err = []
 

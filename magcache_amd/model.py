@@ -219,7 +219,7 @@ class WanModelHIP:
             ctx = None
         else:
             ctx = context[0].to(self.device)
-        if self.engine.sp_size > 1:
+        if getattr(self.engine, "sharded", self.engine.sp_size > 1):
             if getattr(self, "_sp", None) is None:
                 from .parallel import SequenceParallelForward
                 self._sp = SequenceParallelForward(self.engine, group=self.sp_group)
@@ -231,29 +231,49 @@ class WanModelHIP:
             # timesteps it modulated with -- asynchronously (pinned buffer + event, no sync here); it is looked at when it
             # has arrived (next per-token forward) and, blocking, by check_token_timesteps() at the end of sampling
             self._tok_trusted = False
-            if getattr(self, "_tok_rec", None) is None:
-                self._tok_rec = torch.zeros(3, dtype=torch.float32).pin_memory()
-                self._tok_ev = torch.cuda.Event()
-            self._tok_rec.copy_(self.engine.buffer("tok_t2", torch.float32)[:3], non_blocking=True)
-            self._tok_ev.record()
-            self._tok_pending = True
+            # a RING of pinned slots + events (with one slot the host, which runs ahead of the GPU, overwrote the
+            # record of forward i with forward i + 1's before it was ever looked at, so only a run's LAST forward was
+            # verified): every trusted forward gets its own slot; a slot is examined before it is reused
+            if getattr(self, "_tok_ring", None) is None:
+                self._tok_ring = [[torch.zeros(3, dtype=torch.float32).pin_memory(), torch.cuda.Event(), False]
+                                  for _ in range(16)]
+                self._tok_next = 0
+            slot = self._tok_ring[self._tok_next]
+            if slot[2]:
+                slot[1].synchronize()                  # 16 forwards behind: it has long arrived
+                self._tok_examine(slot)
+            slot[0].copy_(self.engine.buffer("tok_t2", torch.float32)[:3], non_blocking=True)
+            slot[1].record()
+            slot[2] = True
+            self._tok_next = (self._tok_next + 1) % len(self._tok_ring)
         return [out.float()]
 
-    def check_token_timesteps(self, block=True):
-        """Raise if a forward that was TRUSTED to carry at most two distinct per-token timesteps (t._mc_two_valued,
-        MAGCACHE_VALIDATE_TOKEN_T=0) did not: the engine counted tokens that were neither max t nor min t (it modulated
-        them as one of the two).  block=False only looks if the record has already arrived."""
-        if not getattr(self, "_tok_pending", False):
-            return
-        if block:
-            self._tok_ev.synchronize()
-        elif not self._tok_ev.query():
-            return
-        self._tok_pending = False
-        tmax, tmin, neither = (float(v) for v in self._tok_rec)
+    @staticmethod
+    def _tok_examine(slot):
+        slot[2] = False
+        tmax, tmin, neither = (float(v) for v in slot[0])
         if neither > 0:
             raise ValueError(f"per-token timesteps: {int(neither)} tokens carried neither t = {tmax:g} nor t = {tmin:g} in a "
                              "forward whose tensor was tagged two-valued (the engine supports at most two distinct values)")
+
+    def check_token_timesteps(self, block=True):
+        """Raise if ANY forward that was TRUSTED to carry at most two distinct per-token timesteps (t._mc_two_valued,
+        MAGCACHE_VALIDATE_TOKEN_T=0) did not: the engine counted tokens that were neither max t nor min t (it modulated
+        them as one of the two).  Every pending record is examined; block=False only those that have already arrived."""
+        err = None
+        for slot in getattr(self, "_tok_ring", None) or []:
+            if not slot[2]:
+                continue
+            if block:
+                slot[1].synchronize()
+            elif not slot[1].query():
+                continue
+            try:
+                self._tok_examine(slot)
+            except ValueError as ex:           # keep draining: the remaining records must not fire later, out of context
+                err = err or ex
+        if err is not None:
+            raise err
 
     def __call__(self, *args, **kwargs):
         # dispatch through the CLASS attribute so that `Model.__class__.forward = fn` takes effect,

@@ -10,16 +10,19 @@ The reference has no MagCache-under-SP behaviour to match (SURVEY.md section 2b 
 forward is bound on the instance and shadows the class-level MagCache patch), so parity here is
 "N ranks == 1 rank", tested on CPU (gloo, fake engine) and on one GPU (2 ranks, real kernels).
 
-Gather layout: "kv_gather" = [P][Lp][2*dim] bf16; rank r's pre_attn writes rows [k | v] of its own
-tokens into slot r; after the all-gather the attention kernel walks P shards of Lp rows of which
-the first L/P are valid.
+Gather layout: "kv_local" = [Lp][2*dim] bf16, this rank's [k | v] rows (Lp = tokens per rank rounded up to 256);
+"kv_gather" = [C][P][Lp/C][2*dim]: round c of the gather is ONE out-of-place all-gather of rows [c*Lp/C, (c+1)*Lp/C) of
+every rank's kv_local -- a contiguous send chunk into a contiguous receive block, no copy.
 
-Overlap: the all-gather is issued asynchronously (RCCL runs it on its own stream) and, while the other
-shards cross xGMI, the attention kernel already runs over the LOCAL shard (engine.block_attn_local:
-1/P of the layer's attention, which is about what one peer's shard needs on its link); block_post_attn
-then attends the P-1 remote shards and merges the two partial softmaxes by their log-sum-exp in the
-kernel epilogue.  Nothing else in a layer is independent of the gathered K/V, so this is the overlap
-the data flow allows.
+Overlap (C = MAGCACHE_SP_CHUNKS rounds, default 4):
+    LayerNorm, k|v Linear, k norm / RoPE       what the peers wait for comes FIRST
+    start round 0 .. C-1 of the all-gather     asynchronous: RCCL runs them in order on its own stream
+    q Linear, q norm / RoPE                    beside the gather
+    attention over this rank's own shard       beside the gather (1/P of the layer's attention), log2-sum-exp out
+    per round c: wait for round c, attend it   round c+1 is on the wire meanwhile; merged by log-sum-exp in the epilogue
+With C = 1 only the q Linear and the local-shard attention hide communication -- 1/P of the attention, i.e. less the
+more ranks there are while the bytes received grow with (P-1)/P; with C rounds everything but the first round's latency
+can hide (DESIGN.md section 5 has the per-layer timeline).  Nothing else in a layer is independent of the gathered K/V.
 """
 import os
 
@@ -30,8 +33,13 @@ from ._lib import MC_MODE_CALIB, MC_MODE_SKIP
 
 # MAGCACHE_SP_OVERLAP=0: wait for the K/V all-gather before the local-shard attention (no kernel runs beside RCCL)
 SP_OVERLAP = os.environ.get("MAGCACHE_SP_OVERLAP", "1") != "0"
-# MAGCACHE_SP_C_LOOP=0: issue the per-layer phases from Python (three engine calls per layer) instead of one mc_blocks_sp call
+# MAGCACHE_SP_C_LOOP=0: issue the per-layer phases from Python (engine calls per phase) instead of one mc_blocks_sp call
 SP_C_LOOP = os.environ.get("MAGCACHE_SP_C_LOOP", "1") != "0"
+# rounds of the per-layer K|V all-gather (1 = one all-gather of whole shards); lowered to what the shard geometry allows
+SP_CHUNKS = int(os.environ.get("MAGCACHE_SP_CHUNKS", "4"))
+# MAGCACHE_SP_RCCL=0: keep the collective in torch.distributed even on the nccl backend (default there: the engine's own
+# RCCL communicator, mc_forward_sp_rccl -- one C call per forward)
+SP_RCCL = os.environ.get("MAGCACHE_SP_RCCL", "1") != "0"
 
 
 class ParallelLayout:
@@ -90,7 +98,7 @@ class ParallelLayout:
 
 
 def inplace_gather_selftest(P, rank, group, device, n=4096):
-    """RCCL's in-place all-gather (send chunk = this rank's slot of the receive buffer) is what the K/V join uses, on a
+    """RCCL's in-place all-gather (send chunk = this rank's slot of the receive buffer) is what the MM-DiT K/V join (mmdit.MMDiTSequenceParallel) uses, on a
     view of the engine workspace; it cannot be exercised without P GPUs, so every rank checks it once at start-up on a
     small tensor and falls back to the out-of-place form if the result is not what the ranks sent.  Collective: every
     rank of `group` must call it."""
@@ -106,79 +114,121 @@ def inplace_gather_selftest(P, rank, group, device, n=4096):
     return bool(ok.item() > 0.5)
 
 
+def usable_chunks(Lp, want):
+    """largest C <= want with Lp / C a multiple of 64 (the attention kernel's key tile)"""
+    c = max(1, int(want))
+    while c > 1 and (Lp % c or (Lp // c) % 64):
+        c -= 1
+    return c
+
+
 class SequenceParallelForward:
-    def __init__(self, engine, group=None):
+    """One sharded DiT evaluation.  The collective runs either inside the engine (RCCL communicator held by the C side:
+    `rccl` is not None -- ONE ctypes call per forward) or through torch.distributed from the gather callback (gloo, the
+    one-GPU multi-rank tests, MAGCACHE_SP_RCCL=0)."""
+
+    def __init__(self, engine, group=None, chunks=None):
         self.e = engine
         self.group = group
         self.P = engine.sp_size
         self.rank = engine.sp_rank
         assert dist.is_initialized() and dist.get_world_size(group) == self.P, (dist.get_world_size(group), self.P)
-        self.inplace = dist.get_backend(group) == "nccl"
-        self.inplace_checked = None
-        if self.inplace:
-            self.inplace_checked = self.inplace = inplace_gather_selftest(self.P, self.rank, group, engine.device)
+        self.nccl = dist.get_backend(group) == "nccl"
         cfg = engine.cfg
         self.d, self.NL = cfg["dim"], cfg["num_layers"]
         self.L = engine.seq_len
         self.Lr = self.L // self.P
-        self.kv = engine.buffer("kv_gather", torch.bfloat16).view(self.P, -1, 2 * self.d)   # [P, Lp, 2d]
+        self.kv_local = engine.buffer("kv_local", torch.bfloat16).view(-1, 2 * self.d)          # [Lp, 2d]
+        self.Lp = self.kv_local.shape[0]
+        self.set_chunks(SP_CHUNKS if chunks is None else chunks)
         self.HT = getattr(engine, "head_stride", 64)
-        self.tokens_full = torch.empty(self.L, self.HT, dtype=torch.float32, device=self.kv.device)
+        self.tokens_full = torch.empty(self.L, self.HT, dtype=torch.float32, device=self.kv_local.device)
+        self.rccl = None
+        if self.nccl and SP_RCCL and hasattr(engine, "rccl_attach"):
+            self.rccl = engine.rccl_attach(group)        # collective: every rank of the group
 
-    def _all_gather_kv(self):
-        """Start the K/V all-gather; returns a work handle to wait on (None: already complete)."""
-        mine = self.kv[self.rank]
-        if self.inplace:
-            # RCCL in-place all-gather: the send chunk is this rank's slot of the receive buffer
-            return dist.all_gather_into_tensor(self.kv.view(-1), mine.reshape(-1), group=self.group, async_op=True)
-        if dist.get_backend(self.group) == "nccl":
-            # the in-place form failed its start-up self-test on this stack: gather out of place from a copy of the slot
-            return dist.all_gather_into_tensor(self.kv.view(-1), mine.reshape(-1).clone(), group=self.group, async_op=True)
-        dist.all_gather([self.kv[r] for r in range(self.P)], mine.clone(), group=self.group)
+    def set_chunks(self, chunks):
+        e = self.e
+        self.C = usable_chunks(self.Lp, chunks)
+        if hasattr(e, "sp_set_chunks"):
+            e.sp_set_chunks(self.C)
+        self.Lc = self.Lp // self.C
+        self.R = -(-self.Lr // self.Lc)                                                          # rounds that carry valid keys
+        self.kv = e.buffer("kv_gather", torch.bfloat16).view(self.C, self.P, self.Lc, 2 * self.d)
+
+    def _start_round(self, c):
+        """Start round c of the K/V all-gather; returns a work handle to wait on (None: already complete)."""
+        send = self.kv_local[c * self.Lc:(c + 1) * self.Lc]
+        if self.nccl:
+            return dist.all_gather_into_tensor(self.kv[c].view(-1), send.reshape(-1), group=self.group, async_op=True)
+        dist.all_gather([self.kv[c, r] for r in range(self.P)], send, group=self.group)
         return None
 
+    def _attend(self, layer, pending, local, rnd):
+        """starts, [waits], local shard, ([wait] round) x R -- the order mc_blocks_sp issues"""
+        for c in range(self.R):
+            pending[c] = self._start_round(c)
+        if not SP_OVERLAP:
+            self._wait(pending, range(self.R))
+        local()
+        for c in range(self.R):
+            if SP_OVERLAP:
+                self._wait(pending, (c,))
+            rnd(c)
+
+    @staticmethod
+    def _wait(pending, rounds):
+        for c in rounds:
+            if pending[c] is not None:
+                pending[c].wait()                  # stream dependency, no host sync
+                pending[c] = None
+
     def _layers_by_phase(self, branch, mode):
-        """the layer loop issued phase by phase from Python (MAGCACHE_SP_C_LOOP=0, and engines without blocks_sp: the CPU
-        stand-in of the gloo tests); mc_blocks_sp runs exactly this sequence"""
+        """the layer loop issued phase by phase from Python (MAGCACHE_SP_C_LOOP=0, and engines without blocks_sp);
+        mc_blocks_sp runs exactly this sequence"""
         e = self.e
+        pending = [None] * self.C
         for layer in range(self.NL):
-            e.block_pre_attn(layer)
-            work = self._all_gather_kv()
-            if work is not None and not SP_OVERLAP:
-                work.wait()
-                work = None
-            e.block_attn_local(layer)          # overlaps the gather: needs only this rank's shard
-            if work is not None:
-                work.wait()                    # stream dependency, no host sync
+            e.block_pre_kv(layer)
+
+            def local(layer=layer):
+                e.block_pre_q(layer)
+                e.block_attn_local(layer)
+            self._attend(layer, pending, local, lambda c, layer=layer: e.block_attn_round(layer, c))
             e.block_post_attn(layer, branch, mode)
             nv, stride = getattr(e, "vace_layers", 0), getattr(e, "vace_stride", 0)
             if nv and layer % stride == 0 and layer // stride < nv:
-                # VACE control block of this layer: same two phases on the control stream, then the hint
+                # VACE control block of this layer: gather everything, then the block (its post phase attends all rounds)
                 i = layer // stride
                 e.vace_block_pre(i)
-                work = self._all_gather_kv()
-                if work is not None:
-                    work.wait()
+                for c in range(self.R):
+                    pending[c] = self._start_round(c)
+                self._wait(pending, range(self.R))
                 e.vace_block_post(i, branch, mode)
 
     def forward(self, latent, t, context, branch, mode, out=None):
         e = self.e
         if out is None:
-            out = torch.empty((e.cfg["out_dim"],) + tuple(e.grid), dtype=torch.float32, device=self.kv.device)
+            out = torch.empty((e.cfg["out_dim"],) + tuple(e.grid), dtype=torch.float32, device=self.kv_local.device)
+        if self.rccl is not None:
+            # the whole sharded forward -- embeds, layer loop with the chunked all-gather, calibration all-reduce, head,
+            # token all-gather, unpatchify -- is ONE call; RCCL is driven from C (csrc/sp_rccl.cpp)
+            e.forward_sp_rccl(self.rccl, latent, t, context, branch, mode, SP_OVERLAP, self.tokens_full, out)
+            return out
         e.embed(latent, t, context)
         if mode != MC_MODE_SKIP:
             if SP_C_LOOP and hasattr(e, "blocks_sp"):
                 # ONE call into the engine for the whole layer loop (mc_blocks_sp); it calls back for the collective only:
-                # phase 0 = start the gather (asynchronous: RCCL runs it on its own stream, ordered behind pre_attn),
-                # phase 1 = the launch stream waits for it (stream dependency, no host sync)
-                pending = [None]
+                # phase 2c = start round c (asynchronous: RCCL runs it on its own stream, ordered behind pre_kv),
+                # phase 2c+1 = the launch stream waits for round c (stream dependency, no host sync)
+                pending = [None] * self.C
 
                 def gather(layer, phase):
-                    if phase == 0:
-                        pending[0] = self._all_gather_kv()
-                    elif pending[0] is not None:
-                        pending[0].wait()
-                        pending[0] = None
+                    c = phase >> 1
+                    if phase & 1:
+                        self._wait(pending, (c,))
+                    else:
+                        pending[c] = self._start_round(c)
                 e.blocks_sp(0, self.NL, branch, mode, SP_OVERLAP, gather)
             else:
                 self._layers_by_phase(branch, mode)
@@ -190,7 +240,7 @@ class SequenceParallelForward:
                     e.calib_finalize(branch)
         e.head(branch, mode)
         local = e.buffer("head_tokens", torch.float32).view(-1, self.HT)[:self.Lr]
-        if self.inplace:
+        if self.nccl:
             dist.all_gather_into_tensor(self.tokens_full.view(-1), local.reshape(-1), group=self.group)
         else:
             dist.all_gather([self.tokens_full[r * self.Lr:(r + 1) * self.Lr] for r in range(self.P)],

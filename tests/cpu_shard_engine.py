@@ -22,13 +22,32 @@ class CpuShardEngine:
         self.Lp = (self.Lr + 255) // 256 * 256
         self.tok0 = sp_rank * self.Lr
         d = oracle.dim
-        self.bufs = {"kv_gather": torch.zeros(sp_size * self.Lp * 2 * d, dtype=torch.bfloat16),
+        # poisoned: a row the orchestration failed to gather shows up as NaN in the output
+        self.bufs = {"kv_local": torch.zeros(self.Lp * 2 * d, dtype=torch.bfloat16),
+                     "kv_gather": torch.full((sp_size * self.Lp * 2 * d,), float("nan"), dtype=torch.bfloat16),
                      "head_tokens": torch.zeros(self.Lp * 64),
                      "calib_sums": torch.zeros(4, dtype=torch.float64)}
         self.res = [None, None]
         self.stats = [None, None]
         self._has = [False, False]
-        self.log = []            # call order: ("pre" | "local" | "post", layer)
+        self.log = []            # call order: ("pre_kv" | "pre_q" | "local" | ("round", layer, c) | "post", layer)
+        self.C = 1
+        self._chain = None       # (layer, o [Lr, n, dh] fp32, lse [Lr, n], local_done, rounds_done)
+
+    # ---- gather rounds (csrc/engine.cpp: mc_sp_set_chunks / sp_chunk_rows / sp_round_valid / sp_rounds)
+    def sp_set_chunks(self, chunks):
+        assert self.Lp % chunks == 0 and (self.Lp // chunks) % 64 == 0, (self.Lp, chunks)
+        self.C = chunks
+
+    @property
+    def Lc(self):
+        return self.Lp // self.C
+
+    def rounds(self):
+        return -(-self.Lr // self.Lc)
+
+    def round_valid(self, c):
+        return max(0, min(self.Lc, self.Lr - c * self.Lc))
 
     def buffer(self, name, dtype=None):
         return self.bufs[name]
@@ -50,35 +69,86 @@ class CpuShardEngine:
             self.e0 = kw["e"]
             self.ctx = kw["context"]
 
-    def block_pre_attn(self, layer):
-        self.log.append(("pre", layer))
+    def block_pre_kv(self, layer):
+        self.log.append(("pre_kv", layer))
         b = self.o.blocks[layer]
         n, dh = self.o.num_heads, self.o.dim // self.o.num_heads
         with torch.no_grad():
             e = (b.modulation + self.e0).chunk(6, dim=1)
-            y = b.norm1(self.x) * (1 + e[1][0]) + e[0][0]
+            self._y = b.norm1(self.x) * (1 + e[1][0]) + e[0][0]
             a = b.self_attn
-            self.q = self._rope(a.norm_q(a.q(y)).view(self.Lr, n, dh))
-            k = self._rope(a.norm_k(a.k(y)).view(self.Lr, n, dh)).reshape(self.Lr, -1)
-            v = a.v(y)
-            kv = self.bufs["kv_gather"].view(self.sp_size, self.Lp, -1)
-            kv[self.sp_rank, :self.Lr] = torch.cat([k, v], dim=-1).to(torch.bfloat16)
-            self._kv_exact = torch.cat([k, v], dim=-1)
+            k = self._rope(a.norm_k(a.k(self._y)).view(self.Lr, n, dh)).reshape(self.Lr, -1)
+            v = a.v(self._y)
+            kv = self.bufs["kv_local"].view(self.Lp, -1)
+            kv[:self.Lr] = torch.cat([k, v], dim=-1).to(torch.bfloat16)
+        self._chain = None
+
+    def block_pre_q(self, layer):
+        self.log.append(("pre_q", layer))
+        b = self.o.blocks[layer]
+        n, dh = self.o.num_heads, self.o.dim // self.o.num_heads
+        with torch.no_grad():
+            a = b.self_attn
+            self.q = self._rope(a.norm_q(a.q(self._y)).view(self.Lr, n, dh))
+
+    def block_pre_attn(self, layer):
+        self.block_pre_kv(layer)
+        self.block_pre_q(layer)
+
+    def _attend(self, layer, kv_rows):
+        """one launch of the layer's attention chain over the [rows, 2d] bf16 keys / values given, merged by log-sum-exp
+        into the chain's running result (what the kernel epilogue does with lse_in / lse_out)"""
+        n, dh, d = self.o.num_heads, self.o.dim // self.o.num_heads, self.o.dim
+        kv = kv_rows.float()
+        assert not torch.isnan(kv).any(), "a K|V row was attended before the gather delivered it"
+        k, v = kv[:, :d].view(-1, n, dh), kv[:, d:].view(-1, n, dh)
+        q = self.q.to(torch.bfloat16).float()
+        sc = torch.einsum("qhd,khd->qhk", q, k) / math.sqrt(dh)
+        lse = torch.logsumexp(sc, dim=-1)                              # [Lr, n]
+        o = torch.einsum("qhk,khd->qhd", torch.softmax(sc, dim=-1), v)
+        if self._chain is None or self._chain[0] != layer:
+            self._chain = [layer, o, lse, False, 0]
+        else:
+            _, o0, lse0, _, _ = self._chain
+            m = torch.maximum(lse, lse0)
+            wa, wb = torch.exp(lse0 - m), torch.exp(lse - m)
+            self._chain[1] = (o0 * wa[..., None] + o * wb[..., None]) / (wa + wb)[..., None]
+            self._chain[2] = m + torch.log(wa + wb)
 
     def block_attn_local(self, layer):
-        self.local_calls = getattr(self, "local_calls", 0) + 1   # the stand-in attends all shards in post_attn
         self.log.append(("local", layer))
+        assert self._chain is None, "the local shard must be the first launch of a layer's chain"
+        with torch.no_grad():
+            self._attend(layer, self.bufs["kv_local"].view(self.Lp, -1)[:self.Lr])
+        self._chain[3] = True
+
+    def block_attn_round(self, layer, c):
+        self.log.append(("round", layer, c))
+        done = self._chain[4] if self._chain is not None and self._chain[0] == layer else 0
+        assert c == done and c < self.rounds(), (c, done)
+        local_done = self._chain is not None and self._chain[3]
+        kv = self.bufs["kv_gather"].view(self.C, self.sp_size, self.Lc, -1)[c, :, :self.round_valid(c)]
+        shards = [r for r in range(self.sp_size) if not (local_done and r == self.sp_rank)]
+        with torch.no_grad():
+            self._attend(layer, kv[shards].reshape(-1, kv.shape[-1]))
+        self._chain[4] = c + 1
 
     def blocks_sp(self, layer_begin, layer_end, branch, mode, overlap, gather):
         """mc_blocks_sp restated (csrc/engine.cpp): the call order the C loop issues, with the same callback protocol"""
+        R = self.rounds()
         for layer in range(layer_begin, layer_end):
-            self.block_pre_attn(layer)
-            gather(layer, 0)
+            self.block_pre_kv(layer)
+            for c in range(R):
+                gather(layer, 2 * c)
             if not overlap:
-                gather(layer, 1)
+                for c in range(R):
+                    gather(layer, 2 * c + 1)
+            self.block_pre_q(layer)
             self.block_attn_local(layer)
-            if overlap:
-                gather(layer, 1)
+            for c in range(R):
+                if overlap:
+                    gather(layer, 2 * c + 1)
+                self.block_attn_round(layer, c)
             self.block_post_attn(layer, branch, mode)
 
     def block_post_attn(self, layer, branch, mode):
@@ -88,10 +158,12 @@ class CpuShardEngine:
         n, dh, d = o.num_heads, o.dim // o.num_heads, o.dim
         with torch.no_grad():
             e = (b.modulation + self.e0).chunk(6, dim=1)
-            kv = self.bufs["kv_gather"].view(self.sp_size, self.Lp, -1)[:, :self.Lr].reshape(-1, 2 * d).float()
-            k, v = kv[:, :d].view(-1, n, dh), kv[:, d:].view(-1, n, dh)
-            att = W.attention_ref_fp32(self.q.to(torch.bfloat16).float().unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0))
-            self.x = self.x + b.self_attn.o(att[0].reshape(self.Lr, d)) * e[2][0]
+            # whatever rounds the caller has not attended yet (mc_block_post_attn does the same)
+            while self._chain is None or self._chain[0] != layer or self._chain[4] < self.rounds():
+                self.block_attn_round(layer, self._chain[4] if self._chain is not None and self._chain[0] == layer else 0)
+            att = self._chain[1]
+            self._chain = None
+            self.x = self.x + b.self_attn.o(att.reshape(self.Lr, d)) * e[2][0]
             c = b.cross_attn
             cq = c.norm_q(c.q(b.norm3(self.x))).view(self.Lr, n, dh)
             ck = c.norm_k(c.k(self.ctx[0])).view(-1, n, dh)

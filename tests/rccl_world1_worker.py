@@ -38,7 +38,7 @@ def main():
 
     # 2. in-place all_gather_into_tensor on a view of the ENGINE WORKSPACE, asynchronous, beside a running attention
     #    kernel on the compute stream; then a kernel that reads the gathered rows.  Same call shapes as
-    #    SequenceParallelForward._all_gather_kv / forward.
+    #    the MM-DiT K|V join (mmdit.MMDiTSequenceParallel).
     cfg = W.tiny_config(num_layers=2, num_heads=2, ffn_dim=512, text_len=64, text_dim=128, freq_dim=64)
     e = Engine(cfg, (3, 40, 48), device=dev, n_branches=2, calibration=True)
     e.load_weights(W.init_synthetic_(W.WanModel(**cfg), seed=3, std=0.05).state_dict())
@@ -75,6 +75,50 @@ def main():
     sums = torch.arange(4, dtype=torch.float64, device=dev)
     dist.all_reduce(sums)
     res["calib_allreduce_ok"] = bool(torch.equal(sums.cpu(), torch.arange(4, dtype=torch.float64)))
+    # 4. the collective INSIDE the library (csrc/sp_rccl.cpp): an engine on the sequence-parallel phase
+    #    path with a world of one (sp_phases), its own RCCL communicator bootstrapped over this process group, and the whole
+    #    sharded forward -- chunked all-gather rounds on the communicator's stream, calibration all-reduce, head-token gather
+    #    -- as ONE C call per forward.  Same weights on a plain engine: the results must agree (same kernels; the q|k|v
+    #    Linear runs as k|v + q launches, the attention as local shard + empty rounds).
+    from magcache_amd._lib import MC_MODE_CALIB, MC_MODE_FULL, MC_MODE_SKIP
+    grid = (3, 40, 48)
+    sd = W.init_synthetic_(W.WanModel(**cfg), seed=3, std=0.05).state_dict()
+    lat = torch.randn(16, *grid, generator=g, device=dev)
+    ctx = torch.randn(29, cfg["text_dim"], generator=g, device=dev)
+    e_sp = Engine(cfg, grid, device=dev, n_branches=2, calibration=True, sp_phases=True)
+    e_sp.load_weights(sd)
+    sp = PAR.SequenceParallelForward(e_sp)
+    res["c_path_attached"] = sp.rccl is not None
+    res["c_path_info"] = e_sp.rccl_info(sp.rccl) if sp.rccl is not None else None
+    res["c_path_chunks"] = [sp.C, sp.R]
+    calls = []
+    real = e_sp.lib.mc_forward_sp_rccl
+    e1 = Engine(cfg, grid, device=dev, n_branches=2, calibration=True)
+    e1.load_weights(sd)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    errs = {}
+    for name, (x, tt, br, mode) in {"full": (lat, 700.0, 0, MC_MODE_FULL), "skip": (lat * 1.01, 650.0, 0, MC_MODE_SKIP),
+                                    "calib0": (lat, 700.0, 1, MC_MODE_CALIB), "calib1": (lat * 0.9, 600.0, 1, MC_MODE_CALIB)}.items():
+        a = sp.forward(x, tt, ctx, br, mode).clone()
+        b = e1.forward(x, tt, ctx, br, mode).clone()
+        errs[name] = rel(a, b)
+    res["c_path_rel"] = errs
+    st, st1 = e_sp.calib_stats(1), e1.calib_stats(1)
+    res["c_path_calib_err"] = max(abs(x - y) for x, y in zip(st, st1))
+    # the torch.distributed callback path on the same engine (MAGCACHE_SP_RCCL=0's route) gives the same bits
+    sp.rccl, keep = None, sp.rccl
+    a = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()
+    sp.rccl = keep
+    b = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()
+    res["c_path_equals_callback_path"] = bool(torch.equal(a, b))
+    # exposed-communication class: waits are logged (a world of one: ~0 ms, but the pairs are there)
+    e_sp.profile(2)
+    sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL)
+    cls = e_sp.profile_read_classes()
+    e_sp.profile(False)
+    res["sp_wait_pairs"] = cls["sp_wait"][1]
+    torch.cuda.synchronize()
+    del sp, e_sp
     dist.barrier()
     dist.destroy_process_group()
     json.dump(res, open(out_path, "w"))

@@ -51,16 +51,16 @@ def main():
     PAR.SP_C_LOOP = True
     c_loop_equal = bool(torch.equal(full, full_by_phase))
     # an exception inside the gather callback surfaces as that exception, the engine stays usable
-    def boom():
+    def boom(c):
         raise RuntimeError("gather failed on purpose")
-    real = sp._all_gather_kv
-    sp._all_gather_kv = boom
+    real = sp._start_round
+    sp._start_round = boom
     try:
         sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL)
         cb_error = "no exception"
     except RuntimeError as ex:
         cb_error = str(ex)
-    sp._all_gather_kv = real
+    sp._start_round = real
     again_equal = bool(torch.equal(sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL), full))
     torch.cuda.synchronize()
     gathered = [torch.zeros_like(res.cpu()) for _ in range(world)]

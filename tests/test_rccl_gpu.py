@@ -25,6 +25,14 @@ def test_rccl_world_of_one_runs_the_sequence_parallel_collectives(tmp_path):
     assert res["inplace_selftest"] is True
     assert res["inplace_async_gather_beside_attention_bit_identical"] is True
     assert res["head_token_gather_ok"] and res["calib_allreduce_ok"]
+    # the collective inside the library: ONE C call per sharded forward on the engine's own RCCL communicator
+    assert res["c_path_attached"] and "rccl" in res["c_path_info"] and "1 ranks" in res["c_path_info"], res
+    assert res["c_path_chunks"] == [4, 4]
+    for name, err in res["c_path_rel"].items():
+        assert err < 1e-3, (name, err)               # same kernels; the attention output takes one extra lse round trip
+    assert res["c_path_calib_err"] < 5e-4
+    assert res["c_path_equals_callback_path"] is True
+    assert res["sp_wait_pairs"] == 2 * 4             # layers x rounds
 
 
 def test_bench_line_through_rccl_at_world_one():
