@@ -232,6 +232,48 @@ def latent_probe(lat):
     return {"l2": float(flat.norm()), "rms": float(flat.pow(2).mean().sqrt()), "samples": [float(v) for v in flat[idx].cpu()]}
 
 
+def contract_line(args, world, parallelism, t_mc, t_nc, skipped, fl, psnr, probes, skipped_steps):
+    """The driver's JSON line from the timed regions' results -- host arithmetic only, so that the CPU suite can check the
+    contract on bench.py's OWN assembly code with stubbed timings (tests/test_bench_contract.py).
+    t_mc / t_nc: seconds of the MagCache / no-cache region of args.steps steps (max over ranks); skipped: forwards served
+    from the residual cache; fl: model FLOPs of one forward."""
+    ran = 2 * args.steps - skipped
+    line = {
+        "metric": "denoising steps/sec (MagCache on), Wan2.1-T2V-1.3B 480p 81f",
+        "value": args.steps / t_mc, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": t_mc / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": (f"bf16 + {'MX block-scaled ' if args.fp8_linear >= 2 else ''}fp8(e4m3) {'all six' if args.fp8_linear == 3 else 'QKV/FFN'} Linears (reduced precision: NOT the headline)"
+                  if args.fp8_linear else "bf16"),
+        "data": "synthetic",
+        "config": {"workload": "Wan2.1-T2V-1.3B 832x480 81 frames: latent 16x21x60x104, 32760 tokens, "
+                               "30 layers d=1536 12 heads ffn=8960; cond+uncond per step, CFG 5.0, flow-Euler; "
+                               "synthetic latents/contexts, random-init weights",
+                   "magcache_thresh": args.magcache_thresh, "magcache_K": args.magcache_K,
+                   "retention_ratio": args.retention_ratio, "sampling_steps": args.steps,
+                   "parallelism": parallelism},
+        "forwards_skipped": skipped, "forwards_total": 2 * args.steps,
+        "speedup_bound": (2 * args.steps) / max(ran, 1),
+        "speedup_note": "bound = forwards total / forwards run, for equal forward times in both timed regions; the measured ratio "
+                        "can pass it by a few 1e-4 (the no-cache region carries the hipEvent pairs and runs second)",
+        "nocache_steps_per_s": (args.steps / t_nc) if t_nc else None,
+        "speedup_vs_nocache": (t_nc / t_mc) if t_nc else None,
+        "psnr_vs_nocache_db": psnr,
+        # step indices whose cond / uncond forward was served from the residual cache (BASELINE.md section 2 lists the
+        # reference's for 50 steps); None at N > 1 with the CFG branches on different ranks
+        "skipped_steps": skipped_steps,
+        # fingerprints of the final latents (identical seeds => an N-rank run must reproduce the single-GPU values up to
+        # the bf16 rounding of the partial attention results): l2 norm + 16 values at fixed flat indices
+        "final_latent_probe": probes,
+        "lpips_vs_nocache": "unavailable offline (magcache_amd.metrics.LPIPSAlex needs AlexNet + lpips weights, none ship "
+                            "here; it raises rather than invent a number)",
+        "model_tflops_per_s_nocache": (2 * args.steps * fl / t_nc / 1e12 / world) if t_nc else None,
+        "model_tflops_per_s_magcache_ran": ran * fl / t_mc / 1e12 / world,
+        "model_flops_note": "per forward, text K/V projections excluded (cached per prompt by mc_set_context)",
+    }
+    return line
+
+
 def kernels_live(cfg, steps, wall_s, classes, sp=1, fwd_per_step=2):
     """Per-class LIVE kernel times of `steps` no-cache steps: hipEvent pairs around every launch class inside the engine
     (mc_profile_read_classes).  ms = average per event pair; frac against the class's bound (algorithmic FLOPs / bytes, no
@@ -410,7 +452,7 @@ def main():
         raise SystemExit(1 if not isinstance(e, SystemExit) else e.code)
 
 
-def bench_main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -433,7 +475,11 @@ def bench_main():
                          "inside a half (SURVEY 8e's alternative); 'auto' = both are timed on 2 no-cache steps before "
                          "the timed region (reported as layout_ablation) and the faster one runs the benchmark")
     ap.add_argument("--no_cfg_parallel", action="store_true", help="same as --layout sp")
-    args = ap.parse_args()
+    return ap
+
+
+def bench_main():
+    args = build_parser().parse_args()
     if args.no_cfg_parallel:
         args.layout = "sp"
 
@@ -591,6 +637,11 @@ def bench_main():
     t_mc, lat_mc = timed(lambda: run(model, layout, args.steps), sync, barrier)
     model._run = fwd
     skipped = int(sum(1 for m in modes if m == 1))
+    # the sampler calls cond then uncond in every step on a rank that evaluates both branches
+    skipped_steps = None
+    if layout is None or layout.cfg_size == 1:
+        skipped_steps = {"cond": [i // 2 for i, m in enumerate(modes) if m == 1 and i % 2 == 0],
+                         "uncond": [i // 2 for i, m in enumerate(modes) if m == 1 and i % 2 == 1]}
     if world > 1:
         # one count per CFG branch / per job: the first rank of every sequence-parallel group reports
         first = layout.sp_rank == 0 and (layout.cfg_size == 2 or rank == 0)
@@ -630,37 +681,9 @@ def bench_main():
     if rank == 0:
         # the shim caches the text context per prompt (mc_set_context): its K / V projections are not in the forwards
         fl = flops_forward(cfg, SEQ, ctx_cached=True)
-        ran = 2 * args.steps - skipped
-        line = {
-            "metric": "denoising steps/sec (MagCache on), Wan2.1-T2V-1.3B 480p 81f",
-            "value": args.steps / t_mc, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": t_mc / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
-            "dtype": (f"bf16 + {'MX block-scaled ' if args.fp8_linear >= 2 else ''}fp8(e4m3) {'all six' if args.fp8_linear == 3 else 'QKV/FFN'} Linears (reduced precision: NOT the headline)"
-                      if args.fp8_linear else "bf16"),
-            "data": "synthetic",
-            "config": {"workload": "Wan2.1-T2V-1.3B 832x480 81 frames: latent 16x21x60x104, 32760 tokens, "
-                                   "30 layers d=1536 12 heads ffn=8960; cond+uncond per step, CFG 5.0, flow-Euler; "
-                                   "synthetic latents/contexts, random-init weights",
-                       "magcache_thresh": args.magcache_thresh, "magcache_K": args.magcache_K,
-                       "retention_ratio": args.retention_ratio, "sampling_steps": args.steps,
-                       "parallelism": "single GPU" if world == 1 else layout.describe()},
-            "forwards_skipped": skipped, "forwards_total": 2 * args.steps,
-            "speedup_bound": (2 * args.steps) / max(ran, 1),
-            "speedup_note": "bound = forwards total / forwards run, for equal forward times in both timed regions; the measured ratio "
-                            "can pass it by a few 1e-4 (the no-cache region carries the hipEvent pairs and runs second)",
-            "nocache_steps_per_s": (args.steps / t_nc) if t_nc else None,
-            "speedup_vs_nocache": (t_nc / t_mc) if t_nc else None,
-            "psnr_vs_nocache_db": psnr,
-            # fingerprints of the final latents (identical seeds => an N-rank run must reproduce the single-GPU values up to
-            # the bf16 rounding of the partial attention results): l2 norm + 16 values at fixed flat indices
-            "final_latent_probe": {"magcache": latent_probe(lat_mc), "nocache": latent_probe(lat_nc) if t_nc else None},
-            "lpips_vs_nocache": "unavailable offline (magcache_amd.metrics.LPIPSAlex needs AlexNet + lpips weights, none ship "
-                                "here; it raises rather than invent a number)",
-            "model_tflops_per_s_nocache": (2 * args.steps * fl / t_nc / 1e12 / world) if t_nc else None,
-            "model_tflops_per_s_magcache_ran": ran * fl / t_mc / 1e12 / world,
-            "model_flops_note": "per forward, text K/V projections excluded (cached per prompt by mc_set_context)",
-        }
+        line = contract_line(args, world, "single GPU" if world == 1 else layout.describe(), t_mc, t_nc, skipped, fl, psnr,
+                             {"magcache": latent_probe(lat_mc), "nocache": latent_probe(lat_nc) if t_nc else None},
+                             skipped_steps)
         line.update(extra)
         if world == 1 and not args.no_kernels:
             if args.no_table:        # (A/B runs: tools/live_ab.sh) only the live figures

@@ -1637,6 +1637,11 @@ int mc_op_gemm_bf16_kernel(int M, int N, int K, int epi) {
   mc::GemmParams p = gp(nullptr, K, nullptr, K, nullptr, M, N, K);
   p.ldc = N; p.ldx = N;
   if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0) return 0;
+  // the operands an epilogue form needs, as the engines pass them (never dereferenced here): the dispatch asks whether
+  // gemm_bf16_v2 can run THIS form (gemm_bf16_v2_epi_ok), not only the shape
+  static char dummy[16];
+  if (epi == mc::EPI_RESID_CAPTURE) { p.X0 = (const bf16_t*)dummy; p.ldx0 = N; p.R = (float*)dummy; p.ldr = N; }
+  if (epi == mc::EPI_BF16_GELU_SPLIT) { p.n_split = N > 256 ? (N / 2) / 256 * 256 : 0; p.Cb2 = (bf16_t*)dummy; p.ldc2 = N; }
   return mc::gemm_bf16_kernel_for(p, epi);
 }
 
@@ -1803,6 +1808,11 @@ mc_status mc_set_option(const char* key, int value) {
   if (k == "gemm_kernel") {
     if ((value < 0 || value > 2) && value != 4)
       return fail(MC_EINVAL, "gemm_kernel must be 0 (by shape), 1 (128x128), 2 (256x256, 8 waves) or 4 (256x256, 4 waves, generated stream)");
+#ifndef MC_WITH_REF_GEMM
+    if (value == 2)
+      return fail(MC_EINVAL, "gemm_kernel 2: the 8-wave reference kernel is not in this library (round 6: it lives in the "
+                             "test-only libmagcache_hip_ref.so, magcache_amd.build.build_ref())");
+#endif
     mc::g_gemm_kernel = value;
   } else if (k == "gemm_splitk") {
     if (value < 0 || value > 16) return fail(MC_EINVAL, "gemm_splitk must be 0 (never), 1 (by shape) or 2..16 (that many K slices wherever valid)");

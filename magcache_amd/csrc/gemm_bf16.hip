@@ -238,11 +238,17 @@ static bool prefer_256(const GemmParams& p) {
   return t256 <= t128;
 }
 
-// 1 = the 128x128 kernel, 2 = the 8-wave 256x256 kernel, 4 = gemm_bf16_v2
+// shapes a 256 x 256 tile kernel takes: N a 256-multiple, an even number (>= 4) of 64-wide K tiles, 16-byte rows, 32-bit
+// byte offsets for the DMA sources (gemm_bf16_v2's own limits on top: gemm_bf16_v2_supported)
+static bool shape_256_ok(const GemmParams& p) {
+  return p.M > 0 && p.N > 0 && (p.N % 256) == 0 && (p.K % 128) == 0 && p.K >= 256 && (p.lda % 8) == 0 && (p.ldw % 8) == 0 &&
+         (size_t)p.M * (size_t)p.lda < (1ull << 31) && (size_t)p.N * (size_t)p.ldw < (1ull << 31);
+}
+
+// 1 = the 128x128 kernel, 2 = the 8-wave 256x256 kernel (reference library only), 4 = gemm_bf16_v2
 int gemm_bf16_kernel_for(const GemmParams& p, int epi) {
   bool big = false;
-  if (g_gemm_kernel != 1 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 &&
-      gemm_bf16_big_supported(p)) {
+  if (g_gemm_kernel != 1 && epi != EPI_EMBED && epi != EPI_GELU_ERF_BF16 && epi != EPI_SILU_BF16 && shape_256_ok(p)) {
     if (g_gemm_kernel == 2) {
       big = true;
     } else if (p.K >= 1024) {
@@ -257,10 +263,15 @@ int gemm_bf16_kernel_for(const GemmParams& p, int epi) {
   // the (cold) fp32 store takes its generic epilogue: the by-shape dispatch no longer launches the 8-wave kernel at all --
   // gemm_bf16_big.hip stays in the library as gemm_kernel = 2, the independent implementation the parity tests and A/B runs
   // compare gemm_bf16_v2 with bit for bit.
-  const bool v2_epi = epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE ||
-                      epi == EPI_BF16_GELU_SPLIT || epi == EPI_F32;
-  if (gemm_bf16_v2_supported(p) && v2_epi && ((g_gemm_kernel == 0 && big) || g_gemm_kernel == 4)) return 4;
-  return big ? 2 : 1;
+  // Round 6: the 8-wave kernel left the shipped library (gemm_bf16_big.hip -> the test-only libmagcache_hip_ref.so, built
+  // with MC_WITH_REF_GEMM); a large shape whose epilogue form gemm_bf16_v2 lacks (gemm_bf16_v2_epi_ok) runs on the 128^2 kernel.
+  if (gemm_bf16_v2_supported(p) && gemm_bf16_v2_epi_ok(p, epi) && ((g_gemm_kernel == 0 && big) || g_gemm_kernel == 4)) return 4;
+#ifdef MC_WITH_REF_GEMM
+  if (big && g_gemm_kernel == 2 && gemm_bf16_big_supported(p) &&
+      (epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE || epi == EPI_F32))
+    return 2;
+#endif
+  return 1;
 }
 
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
@@ -308,7 +319,9 @@ hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
   }
   switch (gemm_bf16_kernel_for(p, epi)) {
     case 4: return launch_gemm_bf16_v2(p, epi, stream);
+#ifdef MC_WITH_REF_GEMM
     case 2: return launch_gemm_bf16_big(p, epi, stream);
+#endif
     default: return launch_gemm_bf16_small(p, epi, stream);
   }
 }

@@ -592,7 +592,9 @@ bf16_t* v2_scratch(hipStream_t stream, int n_wg) {
 // (the first version, 4 blocks per tile and 16 serial quads per thread, ran at 2.8 TB/s: 34 us for FLUX's 72 x 3 partials).
 constexpr int RQ = 4;    // quads per thread
 template <int EPI>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M, int slices) {
+// plain VALU kernel reachable from the two-stream double block (the image stream's O / FFN-2 reduce beside the text stream's
+// 128x128 MFMA GEMM): no packed fp32 (common.h, MC_NO_PK_F32) -- like every non-MFMA kernel run_two can make co-resident
+MC_NO_PK_F32 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int tilesM, int tilesN, int GROUP_M, int slices) {
   const int ntiles = tilesM * tilesN;
   const int tile = blockIdx.x >> 4, wave = (blockIdx.x >> 2) & 3, chunk = blockIdx.x & 3;
   const int lane = threadIdx.x & 63, qg = threadIdx.x >> 6;
@@ -691,9 +693,25 @@ bool gemm_bf16_v2_rowsplit_ok(const GemmParams& p, int epi) {
          (epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_GATE || epi == EPI_RESID_CAPTURE);
 }
 
+// can gemm_bf16_v2 run THIS epilogue on these operands?  (the dispatcher asks before it picks the kernel, so that forms the
+// kernel lacks -- a split point off the 256-column grid, strides beyond its 32-bit epilogue offsets -- take the launches they
+// replace instead of failing: ADVICE r05)
+bool gemm_bf16_v2_epi_ok(const GemmParams& p, int epi) {
+  switch (epi) {
+    case EPI_BF16: case EPI_GELU_BF16: case EPI_F32: return true;
+    case EPI_RESID_GATE: return !p.gate_sel || (p.gate && p.gate2);
+    case EPI_RESID_CAPTURE:
+      return p.X0 && p.R && (size_t)TB * (size_t)p.ldr * 4 < (1ull << 31) && (!p.gate_sel || (p.gate && p.gate2));
+    case EPI_BF16_GELU_SPLIT:
+      return p.n_split > 0 && p.n_split < p.N && (p.n_split % TB) == 0 && p.Cb2 && (size_t)TB * (size_t)p.ldc2 * 4 < (1ull << 31);
+    default: return false;
+  }
+}
+
 hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream) {
   if (!gemm_bf16_v2_supported(p)) return hipErrorInvalidValue;
   if (p.m_split != 0 && !gemm_bf16_v2_rowsplit_ok(p, epi)) return hipErrorInvalidValue;
+  if (p.gate_sel && (!p.gate || !p.gate2)) return hipErrorInvalidValue;   // the per-token epilogues read both gate vectors
   switch (epi) {
     case EPI_BF16: return launch_v2_t<EPI_BF16>(p, stream);
     case EPI_GELU_BF16: return launch_v2_t<EPI_GELU_BF16>(p, stream);
@@ -750,6 +768,7 @@ hipError_t launch_gemm_bf16_v2_splitk(const GemmParams& p, int epi, int slices, 
   if (!gemm_bf16_v2_supported(p) || slices < 2 || !p.splitk_ws || p.K % (slices * 128) != 0 || p.K / slices < 256 ||
       (size_t)slices * ((p.M + TB - 1) / TB) * (p.N / TB) * TB * TB * sizeof(float) > p.splitk_ws_bytes)
     return hipErrorInvalidValue;
+  if (epi == EPI_RESID_CAPTURE && (!p.X0 || !p.R)) return hipErrorInvalidValue;
   if (hipError_t e = launch_v2_t<EPI_SPLITK_PARTIAL>(p, stream, slices); e != hipSuccess) return e;
   switch (epi) {
     case EPI_BF16: return launch_reduce_t<EPI_BF16>(p, slices, stream);

@@ -71,10 +71,14 @@ struct GemmParams {
 hipError_t launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);        // picks a kernel
 int gemm_bf16_kernel_for(const GemmParams& p, int epi);                               // ... this one: 1 small, 2 8-wave 256^2, 4 v2
 hipError_t launch_gemm_bf16_small(const GemmParams& p, int epi, hipStream_t stream);  // 128x128 tiles
-hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);    // 256x256 tiles, 8 waves
+// 256x256 tiles, 8 waves (rounds 1-3's kernel): NOT in libmagcache_hip.so since round 6 -- gemm_bf16_big.hip is built into
+// the test-only libmagcache_hip_ref.so (MC_WITH_REF_GEMM), where gemm_kernel = 2 selects it as the independent
+// implementation gemm_bf16_v2 is compared with bit for bit
+hipError_t launch_gemm_bf16_big(const GemmParams& p, int epi, hipStream_t stream);
 bool gemm_bf16_big_supported(const GemmParams& p);
 hipError_t launch_gemm_bf16_v2(const GemmParams& p, int epi, hipStream_t stream);     // 256x256 tiles, 4 waves, generated stream
 bool gemm_bf16_v2_supported(const GemmParams& p);
+bool gemm_bf16_v2_epi_ok(const GemmParams& p, int epi);         // this epilogue on these operands?
 bool gemm_bf16_v2_rowsplit_ok(const GemmParams& p, int epi);   // m_split > 0: can this be ONE gemm_bf16_v2 launch?
 extern int g_gemm_defer;   // (libraries whose gemm_v2 stream was generated with --defer 1 only; the shipped one is not) 0: epilogues in place
 // split-K (gemm_bf16_v2.hip): slices launch_gemm_bf16 would cut this problem's K into (1 = no split) given p.splitk_ws_bytes;
@@ -84,7 +88,7 @@ size_t gemm_splitk_ws_need(int M, int N, int K, int epi);
 hipError_t launch_gemm_bf16_v2_splitk(const GemmParams& p, int epi, int slices, hipStream_t stream);
 extern int g_gemm_v2_max_grid;  // 0 = grid of gemm_bf16_v2 = CUs; n = at most n persistent workgroups (probe: two forwards side by side)
 extern int g_gemm_splitk;  // mc_set_option("gemm_splitk"): 1 = by shape (default), 0 = never, 2..16 = force that many slices where valid
-extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported, 4: generation 2 where supported
+extern int g_gemm_kernel;  // 0 by shape, 1 small, 2 big where supported (reference library only), 4: generation 2 where supported
 // fp8 (e4m3) operands, 256x256 tiles, v_mfma_f32_32x32x64_f8f6f4; K (fp8 elements) a multiple of 256
 hipError_t launch_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);
 bool gemm_fp8_supported(const GemmParams& p);

@@ -258,13 +258,11 @@ def test_wan22_i2v_a14b_two_experts_fp8_at_width():
     assert ps >= 35.0, ps
 
 
-@pytest.mark.slow
-@pytest.mark.skipif(os.environ.get("MC_RUN_SLOW") != "1", reason="2.5 minutes on one MI355X: set MC_RUN_SLOW=1 (tools/gpu_session.sh "
-                    "pytest_slow); its last run is profiles/r04/fullsize_parity.json")
 def test_wan14_forty_layers_720p_full_length_error_growth():
     """BASELINE.json config 3's model at full depth AND full length on one GPU: Wan2.1-T2V-14B, 40 layers, 720p 81 frames
     = 75 600 tokens (reference call path MagCache4Wan2.1/magcache_generate.py:297-305), per-layer error growth against
-    the fp32 checker; same bars as the 1.3B case."""
+    the fp32 checker; same bars as the 1.3B case.  2.5 minutes on one MI355X; in the default run since round 6 (VERDICT r05
+    item 3: every BASELINE configuration's full-size parity belongs to the suite the driver runs)."""
     res = run_wan_layers(WAN_T2V_14B, (21, 90, 160), seed=5, q_scale=4.0, ctx_valid=512, tag="wan14B_40layers_L75600_qx4")
     check(res)
 
@@ -327,6 +325,13 @@ def test_hunyuan_full_depth_reduced_length():
     """(iv b) all 20 double + 40 single blocks of HunyuanVideo (13 B parameters) on a 9 x 32 x 48 latent (3 456 image + 256
     text tokens): the error growth over 60 blocks that the one-block case at full length cannot show."""
     _hunyuan_case(dict(HR.HUNYUAN_VIDEO), (9, 32, 48), 256, 77, seed=13, key="hunyuan_full_depth_L3456", q_mul=3.0)
+
+
+def test_hunyuan_full_depth_half_length_720p_65f():
+    """BASELINE.json config 2's model at FULL DEPTH (20 double + 40 single blocks) on half of its sequence: 720p, 65 frames
+    = 17 x 45 x 80 = 61 200 image + 256 text tokens -- the full-depth HunyuanVideo case of the default run (the 129-frame one
+    below takes 9 minutes and stays slow-marked).  Reference forward MagCache4HunyuanVideo/magcache_sample_video.py:105-140."""
+    _hunyuan_case(dict(HR.HUNYUAN_VIDEO), (17, 90, 160), 256, 143, seed=19, key="hunyuan_full_depth_720p65f", q_mul=3.0)
 
 
 @pytest.mark.slow

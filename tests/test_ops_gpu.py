@@ -28,17 +28,15 @@ def rel_l2(a, b):
     return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20))
 
 
-@pytest.fixture(params=[1, 2, 4, 0], ids=["gemm-128", "gemm-256", "gemm-256-v2", "gemm-by-shape"])
+@pytest.fixture(params=[1, 4, 0], ids=["gemm-128", "gemm-256-v2", "gemm-by-shape"])
 def kernel_variant(request):
-    """Every GEMM test runs with the 128x128 kernel forced, with the 8-wave 256x256 counted-vmcnt kernel
-    (gemm_bf16_big.hip) forced wherever the shape allows, with the 4-wave 256x256 kernel (generated stream,
+    """Every GEMM test runs with the 128x128 kernel forced, with the 4-wave 256x256 kernel (generated stream,
     gemm_bf16_v2.hip) forced wherever ITS shape and epilogue rules allow, and with the shipped by-shape dispatch (which
-    picks gemm_bf16_v2 for every epilogue of large shapes -- since round 5 also the residual capture, per-token gates and the
-    fp32 store: the 8-wave kernel is reachable through gemm_kernel = 2 only)."""
-    lib = _lib.load()
-    _lib.check(lib.mc_set_option(b"gemm_kernel", request.param))
-    yield request.param
-    _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
+    picks gemm_bf16_v2 for every epilogue of large shapes).  Round 6: the 8-wave 256x256 kernel (gemm_bf16_big.hip) left the
+    shipped library and this fixture; it lives in the test-only reference library (H.gemm_kernel(2)) and is the independent
+    implementation of the bit-equality tests below (full-shape epilogues, residual capture / per-token gates)."""
+    with H.gemm_kernel(request.param):
+        yield request.param
 
 
 @pytest.fixture(params=[3, 5], ids=["attn-8x32", "attn-4x64"])
@@ -352,8 +350,8 @@ def test_gemm_v2_full_shape_epilogues_rows(N, K, epi):
     headline M = 32768, where a workgroup walks 3 (O), 9 (QKV), 17.5 (FFN-1: 35 x 128 tiles on 256 CUs) or 3 (FFN-2) tiles
     persistently: the hand-over "epilogue strip in LDS while the next tile's K tiles 0, 1 are already prefetched" runs in every
     trip but the last.  (a) sampled rows x ALL columns against the fp32 product A Wt^T with the tolerances of
-    test_gemm_bf16_epilogues; (b) the whole output bit-identical to the 8-wave kernel (gemm_kernel = 2), which has no
-    persistent loop and no strip."""
+    test_gemm_bf16_epilogues; (b) the whole output bit-identical to the 8-wave kernel (the reference library's
+    gemm_kernel = 2), which has no persistent loop and no strip."""
     lib = _lib.load()
     M = 32768
     A = rnd(M, K, seed=21, dtype=torch.bfloat16)
@@ -364,16 +362,13 @@ def test_gemm_v2_full_shape_epilogues_rows(N, K, epi):
     gate = rnd(N, seed=25) if epi == "resid_gate" else None
 
     def run(kernel):
-        _lib.check(lib.mc_set_option(b"gemm_kernel", kernel))
-        try:
+        with H.gemm_kernel(kernel):
             if epi in ("bf16", "gelu"):
                 out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
                 H.gemm(A, Wt, bias, 0 if epi == "bf16" else 1, Cb=out)
             else:
                 out = rnd(M, N, seed=24)
                 H.gemm(A, Wt, bias, 2, X=out, gate=gate)
-        finally:
-            _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
         return out
 
     got = run(0)
@@ -499,18 +494,15 @@ def test_gemm_resid_capture_and_per_token_gates_all_kernels(M, N, K):
     g = torch.where(sel[rows, None].bool(), gate2[None, :], gate[None, :])
     outs = {}
     for kern in (0, 2, 4, 1):
-        _lib.check(lib.mc_set_option(b"gemm_kernel", kern))
-        try:
+        with H.gemm_kernel(kern) as kl:
             X, R = x_in.clone(), torch.zeros(M, N, device=DEV)
-            _lib.check(lib.mc_op_gemm_bf16_resid_sel(H.P(A), K, H.P(Wt), K, H.P(bias), M, N, K, 1, H.P(X), N, H.P(gate), H.P(gate2),
-                                                     H.P(sel), H.P(X0), N, H.P(R), N, H.S()))
+            H.check_on(kl, kl.mc_op_gemm_bf16_resid_sel(H.P(A), K, H.P(Wt), K, H.P(bias), M, N, K, 1, H.P(X), N, H.P(gate), H.P(gate2),
+                                                        H.P(sel), H.P(X0), N, H.P(R), N, H.S()))
             X2 = x_in.clone()
-            _lib.check(lib.mc_op_gemm_bf16_resid_sel(H.P(A), K, H.P(Wt), K, H.P(bias), M, N, K, 0, H.P(X2), N, H.P(gate), H.P(gate2),
-                                                     H.P(sel), None, 0, None, 0, H.S()))
+            H.check_on(kl, kl.mc_op_gemm_bf16_resid_sel(H.P(A), K, H.P(Wt), K, H.P(bias), M, N, K, 0, H.P(X2), N, H.P(gate), H.P(gate2),
+                                                        H.P(sel), None, 0, None, 0, H.S()))
             Xc, Rc = x_in.clone(), torch.zeros(M, N, device=DEV)
             H.gemm(A, Wt, bias, 3, X=Xc, gate=gate, X0=X0, R=Rc)                   # capture without per-token gates
-        finally:
-            _lib.check(lib.mc_set_option(b"gemm_kernel", 0))
         outs[kern] = (X, R, X2, Xc, Rc)
         torch.testing.assert_close(X[rows], x_in[rows] + ref * g, rtol=1e-2, atol=2e-2 * math.sqrt(K / 1536))
         torch.testing.assert_close(Xc[rows], x_in[rows] + ref * gate, rtol=1e-2, atol=2e-2 * math.sqrt(K / 1536))
@@ -601,6 +593,33 @@ def test_gemm_bf16_gelu_split_equals_the_two_linears(M, d, kernel_variant):
     torch.testing.assert_close(am[:, d:].float(), F.gelu(ref[:, ns:].bfloat16().float(), approximate="tanh"), rtol=2e-2, atol=2e-2)
     if M == 1536 and kernel_variant in (0, 4):
         assert lib.mc_op_gemm_bf16_kernel(M, N, K, 10) == 4         # the one-launch form did run
+
+
+def test_gemm_forms_gemm_v2_lacks_fall_back_instead_of_failing():
+    """a two-destination split whose first GELU column is off the 256-column grid, on a shape the by-shape
+    dispatch gives to gemm_bf16_v2, must run as the two launches it replaces (the header's promise), not return MC_EINVAL;
+    a per-token-gate call without the second gate vector is refused on the host instead of faulting on the device."""
+    lib = _lib.load()
+    M, K, N, ns = 1536, 3072, 7 * 3072, 3 * 3072 + 64
+    assert lib.mc_op_gemm_bf16_kernel(M, N, K, 10) == 4              # the aligned form of this shape is one v2 launch
+    A = rnd(M, K, seed=51, dtype=torch.bfloat16)
+    Wt = rnd(N, K, seed=52, scale=0.03, dtype=torch.bfloat16)
+    bias = rnd(N, seed=53)
+    lo = torch.zeros(M, ns, dtype=torch.bfloat16, device=DEV)
+    hi = torch.zeros(M, N - ns, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.mc_op_gemm_bf16_gelu_split(H.P(A), K, H.P(Wt), K, H.P(bias), M, N, K, ns, H.P(lo), ns, H.P(hi), N - ns, H.S()))
+    lo2, hi2 = torch.zeros_like(lo), torch.zeros_like(hi)
+    H.gemm(A, Wt[:ns], bias[:ns], 0, Cb=lo2)
+    H.gemm(A, Wt[ns:], bias[ns:], 1, Cb=hi2)
+    assert torch.equal(lo.view(torch.int16), lo2.view(torch.int16)) and torch.equal(hi.view(torch.int16), hi2.view(torch.int16))
+    # gate_sel with a null gate2
+    x = rnd(M, 3072, seed=54)
+    sel = torch.zeros(M, dtype=torch.uint8, device=DEV)
+    gate = rnd(3072, seed=55)
+    st = lib.mc_op_gemm_bf16_resid_sel(H.P(A), K, H.P(Wt), K, H.P(bias), M, 3072, K, 0, H.P(x), 3072, H.P(gate), None, H.P(sel),
+                                       None, 0, None, 0, H.S())
+    assert st == _lib.MC_EINVAL
+    torch.cuda.synchronize()
 
 
 # ----------------------------------------------------------------------------- attention
