@@ -92,7 +92,7 @@ DEFAULT_CFG = {
     "exp_gap": 3,            # instructions (MFMAs included) between two v_exp_f32 at least
     "exp_lat": 3,            # ... between an exponential and the first instruction that reads it
     "skew": 2,               # pairs between an exponential and the instructions that consume it
-    "abl": "",               # TIMING ABLATIONS (wrong results): comma list of exp add cvt max lds dma bar -- drops those
+    "abl": "",               # TIMING ABLATIONS (wrong results): '+' list of exp add cvt max lds dma bar vt128 -- drops those
     # ---- the per-workgroup fixed cost (round 4: 12.4 us of the 20.7 us a 512-key cross-attention workgroup lives,
     #      profiles/r04/kbench_attn_keys_sweep.log)
     "early_dma": 0,          # (measured: +1 % on 512 keys, nothing on 32 760 -- off) the tiles the loop expects in flight (K(2), V(0), ...) are issued WITH K(0), K(1), in front of the
@@ -524,6 +524,16 @@ def vfrag_read_half(E, f, h, off, addr_base=None):
     ks, db = f // M.NDB, f % M.NDB
     b = M.V_VF + 4 * (f % M.NVF) + 2 * h
     step, second = (4096, 2048) if M.mfma == 32 else (8192, 4096)
+    if E.in_body and "vt128" in str(E.cfg["abl"]).split("+"):
+        # TIMING ABLATION (wrong results), round 6: the upper bound of "V^T images written by the QKV epilogue" -- the same
+        # LDS bytes fetched by ONE plain ds_read_b128 per fragment instead of two transposing ds_read_b64_tr_b16
+        # (the K fragments' lane addresses: the V tile has the K tile's [key][d] image, and that b128 pattern is bank-conflict
+        # free -- reading 16 bytes at the TRANSPOSING reads' lane addresses serialises on the banks: 6.72 ms instead of 4.46,
+        # profiles/r06/attn_vt128_ablation_conflicting.log)
+        if h == 0:
+            kbs = 8192 if M.mfma == 32 else 4096
+            return E.ds(f"ds_read_b128 {v(b, 4)}, {v(M.V_KOFF + f % M.NDS)} offset:{off + (f // M.NDS) * kbs}")
+        return E.lds_issued            # the second half rides on the first read's ticket
     return E.ds(f"ds_read_b64_tr_b16 {v(b, 2)}, {v(addr_base + db)} offset:{off + ks * step + h * second}")
 
 
