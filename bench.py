@@ -293,7 +293,8 @@ def kernels_live(cfg, steps, wall_s, classes, sp=1, fwd_per_step=2):
     for name, (ms, n) in classes.items():
         if n == 0:
             continue
-        total += ms
+        if name != "sp_wait":          # the waits for gather rounds lie INSIDE the attention chain's pair (mc_prof_class)
+            total += ms
         ent = {"ms": ms / n, "pairs": n, "ms_per_forward": ms / fwd}
         t = ms / n * 1e-3
         if name in fl:
@@ -735,14 +736,16 @@ def bench_main():
             # N > 1: rank 0's self-attention launches of the timed no-cache region (cfg2: one full-sequence launch per
             # layer; sequence parallel: local-shard launch + one per gather round per layer), algorithmic FLOPs of its share
             sp = layout.sp_size
-            pairs = attn_live[1] // ((1 + extra.get("sp_rounds", 1)) if sp > 1 else 1)      # layers run
+            pairs = (1 if layout.cfg_size == 2 else 2) * args.steps * cfg["num_layers"]     # layers this rank ran
             fl_attn = 4.0 * (SEQ / sp) * SEQ * cfg["dim"] * pairs
             rate = fl_attn / (attn_live[0] * 1e-3)
             line["roofline"] = {"bound": "mfma", "achieved": rate / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                                 "frac": rate / 2.5e15, "traffic": None, "launches": attn_live[1],
                                 "avg_launch_ms": attn_live[0] / attn_live[1],
-                                "measured": "rank 0, hipEvent pairs around every self-attention launch of the timed "
-                                            "no-cache region; per-GPU rate",
+                                "measured": "rank 0, hipEvent pairs on the launch stream around every layer's self-attention of the "
+                                            "timed no-cache region (sequence parallel: ONE pair around the whole chain -- local "
+                                            "shard + gather rounds on two streams + merge --, stalls for the gather included); "
+                                            "per-GPU rate",
                                 "kernel": "self-attention, attn_fwd_v5_kernel (32x32x16 lazy / pipelined stream) for every form of "
                                           "the call: one key shard, and the sequence-parallel local-shard + per-round "
                                           "launches with the log-sum-exp merge"}

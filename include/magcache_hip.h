@@ -103,6 +103,14 @@ const char* mc_version(void);
  *   "gemm_defer"    no effect in the shipped library.  (A/B libraries whose gemm_bf16_v2 stream was generated with
  *                   tools/gen_gemm_v2.py --defer 1 apply a gated-residual epilogue inside the next output tile's main
  *                   loop -- bit-identical, measured 1.5-4 % slower, DESIGN 3.2 -- and 0 switches that off at run time.)
+ *   "sp_attn_partials"  mc_blocks_sp can run the launches of a layer's self-attention chain (this rank's shard + one per
+ *                   gather round) INDEPENDENTLY, alternating between the launch stream and an engine-owned side stream, each
+ *                   into its own slot of "ao_part" / "lse_part", with one merge kernel joining them by their log-sum-exp in
+ *                   fp32.  A rank's launch has 32 760 / (256 sp_size) x heads workgroups of one CU each -- 384 at sp 4, 192 at
+ *                   sp 8: not whole waves of the chip's 256 CUs --, two launches side by side fill it: +11 % / +9 % on a
+ *                   rank's attention alone (profiles/r06/attn_fill_probe.log), -4 % on the layer loop (sp_timeline.log).
+ *                   1 (default) = where a launch does not fill the chip in whole waves, 2 = always, 0 = never (one stream,
+ *                   every launch merged into the running result in place: what mc_block_attn_local / _round do).
  *   "attn_kernel"   0 = default dispatch = 5: attention_v5.hip (4 waves x 64 query rows, one wave per SIMD, generated
  *                   32x32x16 MFMA stream with the lazy softmax reference and the pipelined finish) for EVERY form of the
  *                   call -- one or several key shards, a shard left out, log-sum-exp out and the merge with an earlier
@@ -206,8 +214,10 @@ typedef enum {
   MC_PROF_EMBED = 10,       /* patch / time / text embeds of a forward */
   MC_PROF_HEAD = 11,        /* head LayerNorm (+ the skip add) + Linear + unpatchify */
   MC_PROF_OTHER = 12,       /* uncached text K|V, I2V image branch, calibration statistics */
-  MC_PROF_SP_WAIT = 13,     /* sequence parallel (mc_blocks_sp): what the launch stream idled waiting for a K|V gather round
-                               = the EXPOSED communication of a forward; 0 launches on one GPU */
+  MC_PROF_SP_WAIT = 13,     /* sequence parallel (mc_blocks_sp): what a stream idled waiting for a K|V gather round = the
+                               EXPOSED communication of a forward; 0 launches on one GPU.  With sp_attn_partials (default)
+                               MC_PROF_ATTN_SELF is ONE pair per layer around the whole attention chain on the launch stream
+                               (its launches overlap on two streams), and these waits lie INSIDE it: not additive */
   MC_PROF_NCLASS = 14
 } mc_prof_class;
 mc_status mc_profile_enable(mc_engine* e, int level);

@@ -794,4 +794,58 @@ hipError_t launch_cfg_euler(const float* cond, const float* uncond, float g, flo
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- merge of partial attention results (sequence parallel)
+// O[row, head] = sum_i w_i O_i[row, head] / sum_i w_i,  w_i = 2^(lse_i[head][row] - max_i lse_i): the log-sum-exp merge of
+// n normalised partial results over disjoint key sets (the launches of a layer's attention chain run INDEPENDENTLY on two
+// streams, each into its own slot, so that under-filled launches -- 384 workgroups at sp 4, 192 at sp 8 -- fill the chip
+// together; this kernel joins them in fp32: one bf16 rounding of the partials + one of the result, instead of one per
+// launch of the in-place chain).  One thread = 8 columns of one row (one 16-byte load per partial); may run beside another
+// stream's MFMA kernel: no packed fp32.
+struct AttnMergeParams {
+  const bf16_t* o[9];
+  const float* lse[9];
+  int n;
+};
+MC_NO_PK_F32 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnMergeParams p, bf16_t* __restrict__ out, long ldo,
+                                                                       int rows, int rows_pad, int d) {
+  const int per_row = d / 8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)rows * per_row) return;
+  const int row = (int)(idx / per_row), c8 = (int)(idx - (long)row * per_row);
+  const int head = (c8 * 8) >> 7;
+  float l[9], m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    if (i < p.n) { l[i] = p.lse[i][(size_t)head * rows_pad + row]; m = fmaxf(m, l[i]); }
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, den = 0.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    if (i < p.n) {
+      const float w = __builtin_amdgcn_exp2f(l[i] - m);
+      den += w;
+      const u32x4 t = *(const u32x4*)(p.o[i] + (size_t)row * ldo + c8 * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += w * __uint_as_float(t[j] << 16);
+        acc[2 * j + 1] += w * __uint_as_float(t[j] & 0xffff0000u);
+      }
+    }
+  const float inv = 1.0f / den;
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = pack_bf16x2(acc[2 * j] * inv, acc[2 * j + 1] * inv);
+  *(u32x4*)(out + (size_t)row * ldo + c8 * 8) = r;
+}
+
+hipError_t launch_attn_merge(const bf16_t* const* o_parts, const float* const* lse_parts, int n, bf16_t* out, long ldo, int rows,
+                             int rows_pad, int d, hipStream_t stream) {
+  if (n < 1 || n > 9 || (d % 128) != 0 || (ldo % 8) != 0 || rows <= 0 || rows > rows_pad) return hipErrorInvalidValue;
+  AttnMergeParams p;
+  for (int i = 0; i < 9; ++i) { p.o[i] = i < n ? o_parts[i] : nullptr; p.lse[i] = i < n ? lse_parts[i] : nullptr; }
+  p.n = n;
+  const long total = (long)rows * (d / 8);
+  hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, out, ldo, rows, rows_pad, d);
+  return hipGetLastError();
+}
+
 }  // namespace mc

@@ -76,6 +76,8 @@ struct Buf {
 
 }  // namespace
 
+constexpr int kSpMaxParts = 9;   // local shard + 8 gather rounds
+
 struct mc_engine {
   mc_config cfg;
   int d, ffn, H, NL, L, Lr, Lp, P, rank, tok0, Kp;  // Kp = in_dim*4 padded to 64
@@ -100,6 +102,10 @@ struct mc_engine {
   int attn_launches = 0;       // launches of that chain so far ("ao" / "attn_lse" hold their merged result)
   bool attn_local_done = false;
   int attn_rounds_done = 0;
+  // mc_blocks_sp with sp_attn_partials (default): the launches of a chain run independently on `stream` and this side
+  // stream, each into its own slot of "ao_part" / "lse_part", and attn_merge joins them
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // text context cache (mc_set_context): per slot the embedded context and every block's normalised cross-attention
   // K|V; a forward called with context_dev == NULL reads slot ctx_active instead of recomputing them
   bool ctx_valid[2] = {false, false};
@@ -251,6 +257,13 @@ mc_status set_error_v(mc_status s, const char* fmt, va_list ap) {
 // mc_set_option("fp8_fused_quant", 0|1): 1 (default) = with fp8_linear the LayerNorm + modulate kernel (and, MX, the GELU
 // epilogue of FFN-1) write the e4m3 operand of the next GEMM directly; 0 = round 3's separate quantise passes (same bits).
 static int g_fp8_fused_quant = 1;
+// mc_set_option("sp_attn_partials", 0|1|2): mc_blocks_sp runs the launches of a layer's self-attention chain independently on
+// two streams into partial buffers + one merge kernel -- 1 (default) when a rank's launch does not fill the chip in whole waves
+// (query blocks x heads not a multiple of the CU count: 384 workgroups at sp 4, 192 at sp 8; at sp 2's 768 the merge would
+// only cost: measured -4 % / -4 % / +2 % of the layer loop at sp 4 / 8 / 2, profiles/r06/sp_timeline.log), 2 always, 0 never
+// (one stream, merged in place launch by launch)
+static int g_sp_attn_partials = 1;
+static int g_n_cu = 0;
 extern int g_mmdit_two_streams;   // mmdit_engine.cpp: mc_set_option("mmdit_two_streams", v)
 
 extern "C" {
@@ -524,6 +537,9 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_buf(e, cur, "ao2", Lp * d * 2);
   }
   if (e->sp) add_buf(e, cur, "attn_lse", (size_t)e->H * Lp * 4);
+  // partial attention results of a layer's chain (local shard + up to 8 gather rounds), merged by attn_merge
+  add_buf(e, cur, "ao_part", e->P > 1 ? (size_t)kSpMaxParts * Lp * d * 2 : 256);
+  add_buf(e, cur, "lse_part", e->P > 1 ? (size_t)kSpMaxParts * e->H * Lp * 4 : 256);
   add_buf(e, cur, "calib_partial", (2048 * 4 + 2) * 8);   // + the arrival ticket of calib_stats_kernel
   add_buf(e, cur, "calib_sums", 4 * 8);
   add_buf(e, cur, "calib_stats", 2 * 3 * 4);
@@ -536,6 +552,9 @@ void mc_destroy(mc_engine* e) {
   if (!e) return;
   for (void* p : e->owned) (void)hipFree(p);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
 }
 
@@ -999,6 +1018,41 @@ static mc_status sp_attn_launch(mc_engine* e, int layer, int round, hipStream_t 
   return MC_OK;
 }
 
+// One launch of the chain as an INDEPENDENT partial result: slot 0 = this rank's own shard, slot 1 + c = gather round c
+// without this rank's shard; normalised O -> "ao_part"[slot], log2-sum-exp -> "lse_part"[slot]; nothing is merged here.
+static mc_status sp_attn_partial(mc_engine* e, int round, hipStream_t s) {   // (timed by the caller: one pair around the chain)
+  const int d = e->d, Lp = e->Lp;
+  const int slot = round < 0 ? 0 : 1 + round;
+  mc::AttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.O = e->buf<bf16_t>("ao_part") + (size_t)slot * Lp * d; a.ldo = d; a.Lq_pad = Lp; a.n_heads = e->H;
+  a.scale = 1.0f / std::sqrt(128.0f);
+  a.Q = e->buf<bf16_t>("qkv"); a.ldq = d;
+  a.lse_out = e->buf<float>("lse_part") + (size_t)slot * e->H * Lp;
+  if (round < 0) {
+    bf16_t* kvl = e->buf<bf16_t>("kv_local");
+    a.K = kvl; a.ldk = 2 * d; a.V = kvl + d; a.ldv = 2 * d;
+    a.shard_rows = Lp; a.shard_valid = e->Lr; a.n_shards = 1;
+  } else {
+    const int lc = sp_chunk_rows(e);
+    bf16_t* kvg = e->buf<bf16_t>("kv_gather") + (size_t)round * e->P * lc * 2 * d;
+    a.K = kvg; a.ldk = 2 * d; a.k_shard_stride = (long)lc * 2 * d;
+    a.V = kvg + d; a.ldv = 2 * d; a.v_shard_stride = (long)lc * 2 * d;
+    a.shard_rows = lc; a.shard_valid = sp_round_valid(e, round); a.n_shards = e->P;
+    a.skip_shard_p1 = e->rank + 1;
+  }
+  HIP_TRY(mc::launch_attention(a, s));
+  return MC_OK;
+}
+
+static mc_status sp_side_stream(mc_engine* e) {
+  if (e->side) return MC_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+  return MC_OK;
+}
+
 // Self-attention over this rank's own K/V shard ("kv_local"): normalised partial result -> "ao", log2-sum-exp ->
 // "attn_lse".  Needs nothing from the other ranks, so the caller overlaps it with the all-gather.
 mc_status mc_block_attn_local(mc_engine* e, int layer, mc_stream stream_) {
@@ -1335,10 +1389,23 @@ mc_status mc_blocks_sp(mc_engine* e, int layer_begin, int layer_end, int branch,
     const int rc = gather(user, layer, phase, stream);
     return rc == 0 ? MC_OK : fail(MC_ESTATE, "gather callback failed (layer %d, phase %d, code %d)", layer, phase, rc);
   };
-  auto wait_round = [&](int layer, int c) -> mc_status {
-    Prof pr(e, MC_PROF_SP_WAIT, s);
-    return coll(layer, 2 * c + 1);
+  auto wait_round = [&](int layer, int c, hipStream_t on) -> mc_status {
+    Prof pr(e, MC_PROF_SP_WAIT, on);
+    const int rc = gather(user, layer, 2 * c + 1, (mc_stream)on);
+    return rc == 0 ? MC_OK : fail(MC_ESTATE, "gather callback failed (layer %d, phase %d, code %d)", layer, 2 * c + 1, rc);
   };
+  // independent partial launches on two streams + one merge (see g_sp_attn_partials); a world of one has nothing to merge
+  if (!g_n_cu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      g_n_cu = n;
+    else
+      g_n_cu = 256;
+  }
+  const bool underfilled = ((e->Lp / 256) * e->H) % g_n_cu != 0;       // one workgroup = 256 query rows of one head = one CU
+  const bool partials = (g_sp_attn_partials == 2 || (g_sp_attn_partials == 1 && underfilled)) && e->P > 1 && 1 + R <= kSpMaxParts;
+  if (partials)
+    if (mc_status st = sp_side_stream(e); st != MC_OK) return st;
   // one attention chain: starts, [waits], q, local shard, ([wait] round) x R
   auto attend = [&](int l, const Layer& ly, int chain) -> mc_status {
     mc_status st;
@@ -1346,13 +1413,39 @@ mc_status mc_blocks_sp(mc_engine* e, int layer_begin, int layer_end, int branch,
       if ((st = coll(l, 2 * c)) != MC_OK) return st;
     if (!overlap)
       for (int c = 0; c < R; ++c)
-        if ((st = wait_round(l, c)) != MC_OK) return st;
+        if ((st = wait_round(l, c, s)) != MC_OK) return st;
     if ((st = block_pre_q(e, ly, s)) != MC_OK) return st;
-    if ((st = sp_attn_launch(e, chain, -1, s)) != MC_OK) return st;
-    for (int c = 0; c < R; ++c) {
-      if (overlap && (st = wait_round(l, c)) != MC_OK) return st;
-      if ((st = sp_attn_launch(e, chain, c, s)) != MC_OK) return st;
+    if (!partials) {
+      if ((st = sp_attn_launch(e, chain, -1, s)) != MC_OK) return st;
+      for (int c = 0; c < R; ++c) {
+        if (overlap && (st = wait_round(l, c, s)) != MC_OK) return st;
+        if ((st = sp_attn_launch(e, chain, c, s)) != MC_OK) return st;
+      }
+      return MC_OK;
     }
+    // ONE event pair on the launch stream around the whole chain (fork .. join .. merge): its launches overlap on two streams,
+    // pairs around each would count the shared time twice.  Stalls for gather rounds are inside it AND logged as SP_WAIT.
+    Prof chain_pr(e, MC_PROF_ATTN_SELF, s);
+    // q is ready (and the previous layer's merge has read the partial slots) once `s` gets here: the side stream follows
+    HIP_TRY(hipEventRecord(e->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+    if ((st = sp_attn_partial(e, -1, s)) != MC_OK) return st;
+    for (int c = 0; c < R; ++c) {
+      hipStream_t on = (c & 1) ? s : e->side;          // round 0 beside the local shard, then alternating
+      if (overlap && (st = wait_round(l, c, on)) != MC_OK) return st;
+      if ((st = sp_attn_partial(e, c, on)) != MC_OK) return st;
+    }
+    HIP_TRY(hipEventRecord(e->ev_join, e->side));
+    HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
+    const bf16_t* op[kSpMaxParts];
+    const float* lp[kSpMaxParts];
+    for (int i = 0; i <= R; ++i) {
+      op[i] = e->buf<bf16_t>("ao_part") + (size_t)i * e->Lp * e->d;
+      lp[i] = e->buf<float>("lse_part") + (size_t)i * e->H * e->Lp;
+    }
+    HIP_TRY(mc::launch_attn_merge(op, lp, 1 + R, e->buf<bf16_t>("ao"), e->d, e->Lp, e->Lp, e->d, s));
+    // the chain is complete: block_post has nothing left to attend
+    e->attn_layer = chain; e->attn_launches = 1 + R; e->attn_local_done = true; e->attn_rounds_done = R;
     return MC_OK;
   };
   const int d = e->d;
@@ -1814,6 +1907,11 @@ mc_status mc_set_option(const char* key, int value) {
                              "test-only libmagcache_hip_ref.so, magcache_amd.build.build_ref())");
 #endif
     mc::g_gemm_kernel = value;
+  } else if (k == "sp_attn_partials") {
+    if (value < 0 || value > 2)
+      return fail(MC_EINVAL, "sp_attn_partials must be 0 (chain on one stream), 1 (independent launches on two streams + merge where a launch "
+                             "does not fill the chip in whole waves) or 2 (always)");
+    g_sp_attn_partials = value;
   } else if (k == "gemm_splitk") {
     if (value < 0 || value > 16) return fail(MC_EINVAL, "gemm_splitk must be 0 (never), 1 (by shape) or 2..16 (that many K slices wherever valid)");
     mc::g_gemm_splitk = value;

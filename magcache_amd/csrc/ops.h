@@ -190,6 +190,10 @@ hipError_t launch_add_bcast(const float* a, int na, const float* b, float* out, 
 hipError_t launch_cast_pad_bf16(const float* src, long lds, int rows_valid, int rows, int cols, bf16_t* dst,
                                 long ldd, hipStream_t stream);
 hipError_t launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
+// out[row, head] = log-sum-exp weighted mean of n (1..9) normalised partial attention results over disjoint key sets:
+// o_parts[i] bf16 [rows][ldo], lse_parts[i] fp32 [d / 128][rows_pad] (log2 units) -- sequence parallel, see elementwise.hip
+hipError_t launch_attn_merge(const bf16_t* const* o_parts, const float* const* lse_parts, int n, bf16_t* out, long ldo, int rows,
+                             int rows_pad, int d, hipStream_t stream);
 // a[i] = bf16(float(a[i]) + float(b[i]))   (sum of two attention outputs, Wan I2V cross-attention)
 hipError_t launch_add_bf16(bf16_t* a, const bf16_t* b, size_t n, hipStream_t stream);
 // head: out[m, n] = dot(xn[m,:], W[n,:]) + b[n], fp32, N <= 256 (64 columns per block)

@@ -346,13 +346,15 @@ class Engine:
     def blocks_sp(self, layer_begin, layer_end, branch, mode, overlap, gather):
         """the sequence-parallel layer loop in one C call (mc_blocks_sp): gather(layer, phase) is called back for the
         collective only -- phase 2 c: start round c of the K|V all-gather, phase 2 c + 1: make the launch stream wait for
-        it (one round: 0 / 1).  An exception raised inside the callback aborts the loop and is re-raised here."""
+        it (one round: 0 / 1) -- `stream` (a raw hipStream_t) is the stream that has to wait: the launch stream or the engine's side
+        stream (the launches of a layer's attention chain alternate between the two).  An exception raised inside the callback
+        aborts the loop and is re-raised here."""
         from ._lib import SP_GATHER_FN
         err = []
 
-        def cb(_user, layer, phase, _stream_):
+        def cb(_user, layer, phase, stream_):
             try:
-                gather(layer, phase)
+                gather(layer, phase, stream_)       # stream_: the raw hipStream_t that has to wait (phase 2 c + 1)
                 return 0
             except BaseException as ex:   # noqa: BLE001 -- must not propagate through the C frame
                 err.append(ex)

@@ -223,12 +223,21 @@ class SequenceParallelForward:
                 # phase 2c+1 = the launch stream waits for round c (stream dependency, no host sync)
                 pending = [None] * self.C
 
-                def gather(layer, phase):
+                def gather(layer, phase, stream=None):
                     c = phase >> 1
-                    if phase & 1:
-                        self._wait(pending, (c,))
-                    else:
+                    if not phase & 1:
                         pending[c] = self._start_round(c)
+                    elif pending[c] is not None:
+                        # Work.wait() makes torch's CURRENT stream wait: name the stream the engine asks for (the launch
+                        # stream or its side stream -- the chain's launches alternate between the two)
+                        cur = torch.cuda.current_stream()
+                        if stream and int(stream) != cur.cuda_stream:
+                            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=cur.device)):
+                                self._wait(pending, (c,))
+                        else:
+                            self._wait(pending, (c,))
+                    else:
+                        self._wait(pending, (c,))
                 e.blocks_sp(0, self.NL, branch, mode, SP_OVERLAP, gather)
             else:
                 self._layers_by_phase(branch, mode)

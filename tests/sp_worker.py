@@ -43,13 +43,25 @@ def main():
     sp.forward(lat * 0.9, 600.0, ctx, 1, MC_MODE_CALIB)
     stats = e.calib_stats(1)
     res = e.residual(0).clone()
-    # the layer loop in ONE engine call (mc_blocks_sp, the default) == the same phases issued one by one from Python
+    # the layer loop in ONE engine call (mc_blocks_sp, the default) == the same phases issued one by one from Python -- bit for
+    # bit when the C loop merges the chain in place like the phase calls do (sp_attn_partials = 0); its default (independent
+    # partial launches on two streams + one fp32 merge) differs by the bf16 rounding of the partial results only
+    from magcache_amd import _lib
     from magcache_amd import parallel as PAR
     assert PAR.SP_C_LOOP
+    lib = _lib.load()
+    _lib.check(lib.mc_set_option(b"sp_attn_partials", 0))
+    full_chain = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()
+    _lib.check(lib.mc_set_option(b"sp_attn_partials", 2))      # forced: this tiny geometry would not choose it by itself
+    full = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()
     PAR.SP_C_LOOP = False
     full_by_phase = sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL).clone()
     PAR.SP_C_LOOP = True
-    c_loop_equal = bool(torch.equal(full, full_by_phase))
+    c_loop_equal = bool(torch.equal(full_chain, full_by_phase))
+    partials_rel = float((full - full_chain).norm() / full_chain.norm())
+    # the two-stream form is deterministic: 20 replays, same bits
+    partials_deterministic = all(bool(torch.equal(sp.forward(lat, 700.0, ctx, 0, MC_MODE_FULL), full)) for _ in range(20))
+    _lib.check(lib.mc_set_option(b"sp_attn_partials", 1))
     # an exception inside the gather callback surfaces as that exception, the engine stays usable
     def boom(c):
         raise RuntimeError("gather failed on purpose")
@@ -95,7 +107,8 @@ def main():
         e1.forward(lat * 0.9, 600.0, ctx, 1, MC_MODE_CALIB)
         st1 = e1.calib_stats(1)
         out = dict(rel_full=rel(full, f1), rel_skip=rel(skip, s1), rel_vace=rel_vace,
-                   c_loop_equal=c_loop_equal, cb_error=cb_error, again_equal=again_equal,
+                   c_loop_equal=c_loop_equal, partials_rel=partials_rel, partials_deterministic=partials_deterministic,
+                   cb_error=cb_error, again_equal=again_equal,
                    rel_calib=max(abs(a - b) for a, b in zip(stats, st1)),
                    rel_residual=rel(torch.cat(gathered), e1.residual(0).cpu()), stats=stats, stats1=st1)
         json.dump(out, open(a.out, "w"))

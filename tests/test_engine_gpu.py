@@ -396,6 +396,8 @@ def test_sequence_parallel_two_ranks_one_gpu(tmp_path):
     # one mc_blocks_sp call per forward == the phase-by-phase sequence, bit for bit; a failing collective inside the callback
     # comes back as its own exception and the next forward is right again
     assert res["c_loop_equal"] and res["again_equal"], res
+    # mc_blocks_sp's default: the chain's launches as independent partials on two streams + one fp32 merge
+    assert res["partials_rel"] < 3e-3 and res["partials_deterministic"], res
     assert res["cb_error"] == "gather failed on purpose", res
 
 
@@ -436,7 +438,7 @@ _BENCH_REF = {}      # steps -> the single-process line (one run per session, no
 
 
 @pytest.mark.parametrize("nproc,extra,par,steps", [(2, ["--layout", "cfg2sp"], "cfg2 x sp1", 10),
-                                                   (2, ["--layout", "sp"], "sequence-parallel sp2", 10),
+                                                   (2, ["--layout", "sp"], "sequence-parallel sp2", 6),
                                                    (4, [], None, 6),
                                                    (8, ["--layout", "sp"], "sequence-parallel sp8", 2),
                                                    (8, ["--layout", "cfg2sp"], "cfg2 x sp4", 2)])
@@ -456,7 +458,9 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
     if nproc >= 4:
         base.append("--no_kernels")
     if steps == 2:
-        base += ["--retention_ratio", "0.5"]      # both forwards of step 0 run (the rule may not skip before a residual exists)
+        # both forwards of step 0 run (the rule may not skip before a residual exists); no second (cache off) region: 1.4 GB
+        # per layer cross host memory over gloo at 8 ranks, and the MagCache region's final latent is the check
+        base += ["--retention_ratio", "0.5", "--no_nocache"]
     if steps not in _BENCH_REF:
         one = subprocess.run([sys.executable] + base + ["--gpus", "1"], env=env, capture_output=True, text=True, timeout=900)
         assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
@@ -471,10 +475,11 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
     got = json.loads(lines[0])
     assert got["n_gpus"] == nproc
     assert got["forwards_skipped"] == ref["forwards_skipped"] and got["forwards_total"] == 2 * steps
-    assert abs(got["psnr_vs_nocache_db"] - ref["psnr_vs_nocache_db"]) < 0.5
+    if steps != 2:
+        assert abs(got["psnr_vs_nocache_db"] - ref["psnr_vs_nocache_db"]) < 0.5
     # the final latents themselves: the parallel layouts change nothing but the bf16 rounding of the partial attention
     # results (1 + rounds merges per layer instead of one launch)
-    for which in ("magcache", "nocache"):
+    for which in ("magcache", "nocache") if steps != 2 else ("magcache",):
         a, b = got["final_latent_probe"][which], ref["final_latent_probe"][which]
         assert abs(a["l2"] - b["l2"]) < 2e-3 * b["l2"], (which, a["l2"], b["l2"])
         assert max(abs(x - y) for x, y in zip(a["samples"], b["samples"])) < 3e-2 * b["rms"], (which, a, b)
@@ -495,8 +500,9 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
         k = got["kernels_live_rank0"]
         sp = 2 if got["layout"] == "sp" else 1
         forwards = 3 * (2 if sp == 2 else 1)        # 3 live steps; cfg2: one CFG branch per rank, sp: both on every rank
-        # sp 2: the local-shard launch + one launch per gather round per layer; the q|k|v Linear as k|v + q
-        assert k["classes"]["attn_self"]["pairs"] == forwards * 30 * ((1 + got["sp_rounds"]) if sp == 2 else 1)
+        # sp 2: ONE pair around the layer's whole attention chain (local shard + gather rounds on two streams + merge); the
+        # q|k|v Linear as k|v + q
+        assert k["classes"]["attn_self"]["pairs"] == forwards * 30
         assert k["classes"]["gemm_qkv"]["pairs"] == forwards * 30 * sp
         assert k["classes"]["gemm_ffn1"]["pairs"] == forwards * 30
         assert 0.0 < k["sum_classes_ms_per_forward"] <= k["wall_ms_per_forward"] * 1.02

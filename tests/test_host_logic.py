@@ -117,9 +117,9 @@ def test_set_option_validates_keys_and_values():
     """mc_set_option is host state only (no GPU): every documented key takes its documented values and nothing else."""
     lib = _lib.load()
     ok = {b"gemm_v2_max_grid": (0, 128, 256), b"gemm_splitk": (0, 1, 2, 16), b"gemm_kernel": (0, 1, 4), b"attn_kernel": (0, 3, 5), b"mmdit_two_streams": (-1, 0, 1, 2, 6), b"gemm_defer": (0, 1),
-          b"fp8_fused_quant": (0, 1)}
+          b"fp8_fused_quant": (0, 1), b"sp_attn_partials": (0, 1, 2)}
     bad = {b"gemm_v2_max_grid": (-1, 5000), b"gemm_splitk": (-1, 17), b"gemm_kernel": (-1, 2, 3, 5, 9), b"attn_kernel": (1, 2, 4, 6), b"mmdit_two_streams": (-2, 7), b"gemm_defer": (-1, 2),
-           b"fp8_fused_quant": (-1, 2)}
+           b"fp8_fused_quant": (-1, 2), b"sp_attn_partials": (-1, 3)}
     try:
         for key, vals in ok.items():
             for v in vals:
@@ -138,6 +138,7 @@ def test_set_option_validates_keys_and_values():
         lib.mc_set_option(b"mmdit_two_streams", 0)
         lib.mc_set_option(b"gemm_defer", 1)
         lib.mc_set_option(b"fp8_fused_quant", 1)
+        lib.mc_set_option(b"sp_attn_partials", 1)
 
 
 def test_c_rule_short_eval_schedules_wrap_like_python():

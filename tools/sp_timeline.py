@@ -28,7 +28,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from magcache_amd import _lib  # noqa: E402
 from magcache_amd.engine import MC_MODE_FULL, WAN_T2V_1_3B, Engine, synthetic_weights  # noqa: E402
+
+LIB = _lib.load()
 
 DEV = "cuda:0"
 GRID = (21, 60, 104)
@@ -50,12 +53,24 @@ def measure(P, C):
     R, Lc, _ = e.sp_round_info(0)
     kvg = e.buffer("kv_gather", torch.bfloat16)
     kvg.copy_((torch.randn(kvg.numel(), generator=g, device=DEV) * 0.5).bfloat16())
-    noop = lambda layer, phase: None  # noqa: E731
+    noop = lambda layer, phase, stream=None: None  # noqa: E731
 
     def fwd():
         e.embed(lat, 700.0, ctx)
         e.blocks_sp(0, layers, 0, MC_MODE_FULL, True, noop)
         e.head(0, MC_MODE_FULL)
+    def wall():
+        """ms per layer of the layer loop alone (events on the launch stream around mc_blocks_sp: includes the join)"""
+        e.embed(lat, 700.0, ctx)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            e.blocks_sp(0, layers, 0, MC_MODE_FULL, True, noop)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (reps * layers)
+    # the chain merged in place on one stream: the classes add up to the wall time
+    _lib.check(LIB.mc_set_option(b"sp_attn_partials", 0))
     for _ in range(2):
         fwd()
     torch.cuda.synchronize()
@@ -67,13 +82,21 @@ def measure(P, C):
     n = reps * layers
     per_layer = {k: ms / n for k, (ms, cnt) in cls.items() if cnt and k not in ("embed", "head", "sp_wait")}
     pairs = {k: cnt / n for k, (ms, cnt) in cls.items() if cnt}
+    walls = {"chain": sorted(wall() for _ in range(3))[1]}
+    # the shipped form: independent partial launches on two streams + one merge (their event pairs overlap: wall time only)
+    _lib.check(LIB.mc_set_option(b"sp_attn_partials", 2))
+    fwd()
+    walls["partials"] = sorted(wall() for _ in range(3))[1]
+    _lib.check(LIB.mc_set_option(b"sp_attn_partials", 1))
     del e
     torch.cuda.empty_cache()
-    return per_layer, pairs, R, Lc
+    return per_layer, pairs, R, Lc, walls
 
 
-def timeline(pl, pairs, P, R, Lc, rate_gbs, lat_us=20.0):
+def timeline(pl, pairs, P, R, Lc, rate_gbs, lat_us=20.0, attn_ms=None):
     Lr = SEQ // P
+    if attn_ms is not None:
+        pl = dict(pl, attn_self=attn_ms)
     # split the classes of the pre-attention part: ln_modulate is 3 launches per layer (one in front of the k|v Linear);
     # gemm_qkv = k|v (2/3 of its FLOPs) + q (1/3); rmsnorm_rope = k (in front of the gather), q, cross-q
     ln1 = pl["ln_modulate"] / 3
@@ -106,11 +129,16 @@ def timeline(pl, pairs, P, R, Lc, rate_gbs, lat_us=20.0):
 out = []
 for P in (2, 4, 8):
     for C in (1, 4):
-        pl, pairs, R, Lc = measure(P, C)
+        pl, pairs, R, Lc, walls = measure(P, C)
+        # attention of the two-stream form = the chain's attention minus what the layer loop's wall time lost
+        attn_p = pl["attn_self"] - (walls["chain"] - walls["partials"])
         ent = {"sp_size": P, "rows_per_rank": SEQ // P, "chunks": C, "rounds": R, "chunk_rows": Lc,
-               "classes_ms_per_layer": {k: round(v, 4) for k, v in pl.items()}, "pairs_per_layer": pairs,
-               "compute_ms_per_layer": sum(pl.values()),
-               "timeline": [timeline(pl, pairs, P, R, Lc, r) for r in (48.0, 100.0)]}
+               "classes_ms_per_layer_chain": {k: round(v, 4) for k, v in pl.items()}, "pairs_per_layer": pairs,
+               "wall_ms_per_layer": walls, "attn_ms_per_layer": {"chain": pl["attn_self"], "partials": attn_p},
+               "attn_ideal_ms_per_layer": None,
+               "compute_ms_per_layer": sum(pl.values()) - pl["attn_self"] + attn_p,
+               "timeline_chain": [timeline(pl, pairs, P, R, Lc, r) for r in (48.0, 100.0)],
+               "timeline": [timeline(pl, pairs, P, R, Lc, r, attn_ms=attn_p) for r in (48.0, 100.0)]}
         out.append(ent)
         print(json.dumps(ent), flush=True)
 # single GPU for scale
