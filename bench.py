@@ -588,7 +588,8 @@ def bench_main():
             extra["sp_rounds"] = getattr(sp, "R", None)          # ... of which carry valid keys
             extra["sp_collective"] = ("RCCL communicator inside the library (mc_forward_sp_rccl: one C call per forward): "
                                       + model.engine.rccl_info(sp.rccl)) if getattr(sp, "rccl", None) is not None else \
-                "torch.distributed from the gather callback of mc_blocks_sp (" + str(dist.get_backend()) + ")"
+                "torch.distributed from the gather callback of mc_blocks_sp (" + str(dist.get_backend()) + ")" + \
+                (f"; the library-side communicator was not used: {sp.rccl_error}" if getattr(sp, "rccl_error", None) else "")
 
         model, built, abl = None, None, {}
         for n in names:

@@ -284,6 +284,8 @@ void* mc_workspace_base(const mc_engine* e);
  * (fp32 [seq_len][head_stride], caller-owned) and mc_unpatchify -> out_dev [out_dim, F, H, W] on every rank. */
 #define MC_SP_ID_BYTES 128
 typedef struct mc_sp_comm mc_sp_comm;
+int mc_sp_rccl_available(void); /* 1: librccl found and bound (mc_last_error() says why not) -- ask EVERY rank before the
+                                   collective mc_sp_comm_create, which a rank without the library would never join */
 mc_status mc_sp_comm_id(void* id_out);
 mc_status mc_sp_comm_create(const void* id, int nranks, int rank, mc_sp_comm** out);
 void mc_sp_comm_destroy(mc_sp_comm* c);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mc_workspace_base": (_vp, [_vp]),
     "mc_block_attn_local": (_i, [_vp, _i, _vp]),
     "mc_block_attn_round": (_i, [_vp, _i, _i, _vp]),
+    "mc_sp_rccl_available": (_i, []),
     "mc_sp_comm_id": (_i, [_vp]),
     "mc_sp_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "mc_sp_comm_destroy": (None, [_vp]),

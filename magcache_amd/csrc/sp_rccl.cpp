@@ -146,6 +146,8 @@ int gather_cb(void* user, int /*layer*/, int phase, mc_stream stream_) {
 
 extern "C" {
 
+int mc_sp_rccl_available(void) { return load_rccl() == MC_OK ? 1 : 0; }
+
 mc_status mc_sp_comm_id(void* id_out) {
   if (!id_out) return failf(MC_EINVAL, "null id");
   if (mc_status st = load_rccl(); st != MC_OK) return st;

@@ -315,18 +315,32 @@ class Engine:
         import torch.distributed as dist
         rank, n = dist.get_rank(group), dist.get_world_size(group)
         assert n == self.sp_size and rank == self.sp_rank, (n, rank, self.sp_size, self.sp_rank)
+        # every rank must be able to join ncclCommInitRank, or none starts it
+        have = torch.tensor([float(self.lib.mc_sp_rccl_available())], device=self.device)
+        mine = have.item() > 0.5
+        dist.all_reduce(have, op=dist.ReduceOp.MIN, group=group)
+        if have.item() < 0.5:
+            raise RuntimeError("librccl could not be bound on " + ("this rank: " + self.lib.mc_last_error().decode() if not mine
+                                                                  else "another rank of the group"))
         box = [None]
         if rank == 0:
             buf = C.create_string_buffer(128)
-            check(self.lib.mc_sp_comm_id(buf))
-            box[0] = buf.raw
+            if self.lib.mc_sp_comm_id(buf) == 0:
+                box[0] = buf.raw
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(box, src=src, group=group)
+        if box[0] is None:
+            raise RuntimeError("ncclGetUniqueId failed on the group's first rank")
         comm = C.c_void_p()
         check(self.lib.mc_sp_comm_create(C.c_char_p(box[0]), n, rank, C.byref(comm)))
         self._rccl = getattr(self, "_rccl", [])
         self._rccl.append(comm)
         return comm
+
+    def rccl_detach(self, comm):
+        torch.cuda.synchronize(self.device)
+        self.lib.mc_sp_comm_destroy(comm)
+        self._rccl = [c for c in getattr(self, "_rccl", []) if c is not comm]
 
     def rccl_info(self, comm):
         return self.lib.mc_sp_comm_info(comm).decode()

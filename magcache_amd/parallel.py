@@ -143,9 +143,20 @@ class SequenceParallelForward:
         self.set_chunks(SP_CHUNKS if chunks is None else chunks)
         self.HT = getattr(engine, "head_stride", 64)
         self.tokens_full = torch.empty(self.L, self.HT, dtype=torch.float32, device=self.kv_local.device)
-        self.rccl = None
+        self.rccl, self.rccl_error = None, None
         if self.nccl and SP_RCCL and hasattr(engine, "rccl_attach"):
-            self.rccl = engine.rccl_attach(group)        # collective: every rank of the group
+            # collective: every rank of the group.  A rank whose library-side communicator cannot be created (librccl not
+            # found, ncclCommInitRank failing) must not leave the others in a collective it never joins: the outcome is
+            # all-reduced and the group falls back to the torch.distributed callback path TOGETHER
+            try:
+                self.rccl = engine.rccl_attach(group)
+            except Exception as ex:      # noqa: BLE001
+                self.rccl_error = f"{type(ex).__name__}: {ex}"
+            ok = torch.tensor([0.0 if self.rccl is None else 1.0], device=self.kv_local.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if ok.item() < 0.5 and self.rccl is not None:
+                engine.rccl_detach(self.rccl)
+                self.rccl, self.rccl_error = None, "another rank of the group could not create its communicator"
 
     def set_chunks(self, chunks):
         e = self.e

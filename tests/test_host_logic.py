@@ -703,3 +703,23 @@ def test_bench_multi_gpu_failure_ends_in_a_parseable_line():
     assert len(lines) == 1, r.stdout[-1000:] + r.stderr[-1000:]
     line = json.loads(lines[0])
     assert line["value"] is None and line["n_gpus"] == 2 and "no GPU" in line["error"] and line["stage"]
+
+
+def test_rccl_is_bound_at_run_time_from_the_process_own_copy():
+    """csrc/sp_rccl.cpp binds RCCL with dlopen (no link dependency: `ldd libmagcache_hip.so` shows no librccl) and prefers the
+    copy already mapped into the process -- PyTorch-ROCm's, which sits on the same HIP runtime as the engine.  Needs no GPU:
+    the library loads, its symbols resolve, ncclGetUniqueId hands out 128 bytes."""
+    import subprocess
+    lib = _lib.load()
+    assert lib.mc_sp_rccl_available() == 1, lib.mc_last_error()
+    info = lib.mc_sp_comm_info(None).decode()
+    assert info.startswith("rccl ") and "already mapped" in info, info
+    a, b = C.create_string_buffer(128), C.create_string_buffer(128)
+    assert lib.mc_sp_comm_id(a) == _lib.MC_OK and lib.mc_sp_comm_id(b) == _lib.MC_OK
+    assert a.raw != b.raw and a.raw != bytes(128)                       # two ids, not zeros
+    assert lib.mc_sp_comm_id(None) == _lib.MC_EINVAL
+    out = C.c_void_p()
+    assert lib.mc_sp_comm_create(a, 0, 0, C.byref(out)) == _lib.MC_EINVAL      # nranks < 1
+    assert lib.mc_sp_comm_create(a, 2, 2, C.byref(out)) == _lib.MC_EINVAL      # rank out of range
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
