@@ -106,6 +106,7 @@ struct mc_engine {
   // stream, each into its own slot of "ao_part" / "lse_part", and attn_merge joins them
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  size_t splitk_bytes = 0;     // "splitk": scratch for FFN-2's split-K where a rank's shard leaves the chip under-filled
   // text context cache (mc_set_context): per slot the embedded context and every block's normalised cross-attention
   // K|V; a forward called with context_dev == NULL reads slot ctx_active instead of recomputing them
   bool ctx_valid[2] = {false, false};
@@ -537,6 +538,10 @@ mc_status mc_create(const mc_config* cfg, mc_engine** out) {
     add_buf(e, cur, "ao2", Lp * d * 2);
   }
   if (e->sp) add_buf(e, cur, "attn_lse", (size_t)e->H * Lp * 4);
+  // split-K scratch of FFN-2 (K = ffn): a rank of a wide sequence-parallel job has too few 256^2 tiles for the chip (sp 8 at
+  // 1.3B: M = 4096 -> 96 tiles), launch_gemm_bf16 then cuts K in slices (policy: gemm_bf16_v2.hip); 0 bytes where it would not
+  e->splitk_bytes = e->sp ? mc::gemm_splitk_ws_need((int)Lp, (int)d, (int)ffn, mc::EPI_RESID_GATE) : 0;
+  add_buf(e, cur, "splitk", e->splitk_bytes ? e->splitk_bytes : 256);
   // partial attention results of a layer's chain (local shard + up to 8 gather rounds), merged by attn_merge
   add_buf(e, cur, "ao_part", e->P > 1 ? (size_t)kSpMaxParts * Lp * d * 2 : 256);
   add_buf(e, cur, "lse_part", e->P > 1 ? (size_t)kSpMaxParts * e->H * Lp * 4 : 256);
@@ -1251,6 +1256,7 @@ static mc_status block_post(mc_engine* e, const Layer& l, const float* em, float
     }
     mc::GemmParams q = gp(h, ffn, l.w2, ffn, l.b2, Lp, d, ffn);
     q.X = x; q.ldx = d; q.gate = em + 5 * d;
+    if (e->splitk_bytes) { q.splitk_ws = e->buf<float>("splitk"); q.splitk_ws_bytes = e->splitk_bytes; }
     if (em2) { q.gate2 = em2 + 5 * d; q.gate_sel = sel; }
     const bool f8 = l.q_w2 != nullptr;
     auto ffn2 = [&](int epi) -> mc_status {

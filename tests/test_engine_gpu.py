@@ -438,8 +438,8 @@ _BENCH_REF = {}      # steps -> the single-process line (one run per session, no
 
 
 @pytest.mark.parametrize("nproc,extra,par,steps", [(2, ["--layout", "cfg2sp"], "cfg2 x sp1", 10),
-                                                   (2, ["--layout", "sp"], "sequence-parallel sp2", 6),
-                                                   (4, [], None, 6),
+                                                   (2, ["--layout", "sp"], "sequence-parallel sp2", 5),
+                                                   (4, [], None, 4),
                                                    (8, ["--layout", "sp"], "sequence-parallel sp8", 2),
                                                    (8, ["--layout", "cfg2sp"], "cfg2 x sp4", 2)])
 def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
@@ -457,9 +457,10 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
     base = [os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "0", "--no_cpu_baseline", "--no_table"]
     if nproc >= 4:
         base.append("--no_kernels")
-    if steps == 2:
-        # both forwards of step 0 run (the rule may not skip before a residual exists); no second (cache off) region: 1.4 GB
-        # per layer cross host memory over gloo at 8 ranks, and the MagCache region's final latent is the check
+    if steps <= 4:
+        # both forwards of step 0 run (the rule may not skip before a residual exists); no second (cache off) region: up to
+        # 1.4 GB per layer cross host memory over gloo (the 4-rank case took 280 s with it), the MagCache region's final latent
+        # is the check
         base += ["--retention_ratio", "0.5", "--no_nocache"]
     if steps not in _BENCH_REF:
         one = subprocess.run([sys.executable] + base + ["--gpus", "1"], env=env, capture_output=True, text=True, timeout=900)
@@ -475,11 +476,11 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
     got = json.loads(lines[0])
     assert got["n_gpus"] == nproc
     assert got["forwards_skipped"] == ref["forwards_skipped"] and got["forwards_total"] == 2 * steps
-    if steps != 2:
+    if steps > 4:
         assert abs(got["psnr_vs_nocache_db"] - ref["psnr_vs_nocache_db"]) < 0.5
     # the final latents themselves: the parallel layouts change nothing but the bf16 rounding of the partial attention
     # results (1 + rounds merges per layer instead of one launch)
-    for which in ("magcache", "nocache") if steps != 2 else ("magcache",):
+    for which in ("magcache", "nocache") if steps > 4 else ("magcache",):
         a, b = got["final_latent_probe"][which], ref["final_latent_probe"][which]
         assert abs(a["l2"] - b["l2"]) < 2e-3 * b["l2"], (which, a["l2"], b["l2"])
         assert max(abs(x - y) for x, y in zip(a["samples"], b["samples"])) < 3e-2 * b["rms"], (which, a, b)
@@ -500,9 +501,10 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
         k = got["kernels_live_rank0"]
         sp = 2 if got["layout"] == "sp" else 1
         forwards = 3 * (2 if sp == 2 else 1)        # 3 live steps; cfg2: one CFG branch per rank, sp: both on every rank
-        # sp 2: ONE pair around the layer's whole attention chain (local shard + gather rounds on two streams + merge); the
-        # q|k|v Linear as k|v + q
-        assert k["classes"]["attn_self"]["pairs"] == forwards * 30
+        # sp 2: a rank's attention launch has 768 workgroups = whole waves of the chip, so the chain runs on one stream, merged in
+        # place: the local-shard launch + one per gather round, a pair each (the two-stream partial form of sp 4 / sp 8 logs ONE
+        # pair around the whole chain); the q|k|v Linear as k|v + q
+        assert k["classes"]["attn_self"]["pairs"] == forwards * 30 * ((1 + got["sp_rounds"]) if sp == 2 else 1)
         assert k["classes"]["gemm_qkv"]["pairs"] == forwards * 30 * sp
         assert k["classes"]["gemm_ffn1"]["pairs"] == forwards * 30
         assert 0.0 < k["sum_classes_ms_per_forward"] <= k["wall_ms_per_forward"] * 1.02

@@ -723,3 +723,21 @@ def test_rccl_is_bound_at_run_time_from_the_process_own_copy():
     assert lib.mc_sp_comm_create(a, 2, 2, C.byref(out)) == _lib.MC_EINVAL      # rank out of range
     needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "rccl" not in needed.lower()
+
+
+def test_reference_library_is_current():
+    """tests/_ref/libmagcache_hip_ref.so (the shipped objects + the 8-wave GEMM, magcache_amd.build.build_ref(); built by
+    __graft_entry__.build()) must export every symbol the ctypes binding names and must not be older than the shipped library:
+    the GPU parity tests bind it with the same signatures."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hip_ops as H
+    assert os.path.exists(H.REF_PATH), "python -m magcache_amd.build  (builds both libraries)"
+    assert os.path.getmtime(H.REF_PATH) >= os.path.getmtime(_lib.LIB_PATH) - 1.0, "the reference build is older than the shipped library"
+    lib = C.CDLL(H.REF_PATH)
+    missing = [n for n in _lib.SIGNATURES if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.mc_set_option.restype, lib.mc_set_option.argtypes = C.c_int, [C.c_char_p, C.c_int]
+    assert lib.mc_set_option(b"gemm_kernel", 2) == _lib.MC_OK          # the reference build has the 8-wave kernel ...
+    lib.mc_set_option(b"gemm_kernel", 0)
+    assert _lib.load().mc_set_option(b"gemm_kernel", 2) == _lib.MC_EINVAL   # ... the shipped one refuses it
