@@ -109,7 +109,7 @@ const char* mc_version(void);
  *                   fp32.  A rank's launch has 32 760 / (256 sp_size) x heads workgroups of one CU each -- 384 at sp 4, 192 at
  *                   sp 8: not whole waves of the chip's 256 CUs --, two launches side by side fill it: +11 % / +9 % on a
  *                   rank's attention alone (profiles/r06/attn_fill_probe.log), -4 % on the layer loop (sp_timeline.log).
- *                   1 (default) = where a launch does not fill the chip in whole waves, 2 = always, 0 = never (one stream,
+ *                   1 (default) = where a launch fills less than 90 % of the CU slots of its waves, 2 = always, 0 = never (one stream,
  *                   every launch merged into the running result in place: what mc_block_attn_local / _round do).
  *   "attn_kernel"   0 = default dispatch = 5: attention_v5.hip (4 waves x 64 query rows, one wave per SIMD, generated
  *                   32x32x16 MFMA stream with the lazy softmax reference and the pipelined finish) for EVERY form of the

@@ -259,9 +259,10 @@ mc_status set_error_v(mc_status s, const char* fmt, va_list ap) {
 // epilogue of FFN-1) write the e4m3 operand of the next GEMM directly; 0 = round 3's separate quantise passes (same bits).
 static int g_fp8_fused_quant = 1;
 // mc_set_option("sp_attn_partials", 0|1|2): mc_blocks_sp runs the launches of a layer's self-attention chain independently on
-// two streams into partial buffers + one merge kernel -- 1 (default) when a rank's launch does not fill the chip in whole waves
-// (query blocks x heads not a multiple of the CU count: 384 workgroups at sp 4, 192 at sp 8; at sp 2's 768 the merge would
-// only cost: measured -4 % / -4 % / +2 % of the layer loop at sp 4 / 8 / 2, profiles/r06/sp_timeline.log), 2 always, 0 never
+// two streams into partial buffers + one merge kernel -- 1 (default) when a rank's launch fills less than 90 % of the CU slots
+// of the waves it runs in (query blocks x heads against the CU count: 384 workgroups at sp 4 and 192 at sp 8 are 75 %; sp 2's
+// 768 are 100 % and 14B's 1480 at sp 8 96 %: there the merge only costs -- measured -4 % / -4 % / +2 % / +3 % of the layer loop
+// at 1.3B sp 4 / 8 / 2 and 14B sp 8, profiles/r06/sp_timeline*.log), 2 always, 0 never
 // (one stream, merged in place launch by launch)
 static int g_sp_attn_partials = 1;
 static int g_n_cu = 0;
@@ -823,15 +824,17 @@ mc_status mc_embed(mc_engine* e, const float* latent_dev, const float* t_dev, do
 // multiplied inside the matrix core (gemm_mxfp8.hip).
 // A == nullptr: the producer already left the quantised rows (and their scales) in "aq" / "a_mx" / "a_scale"
 // (ln_for_gemm below) or in aq_pre / amx_pre (the GELU epilogue of the MX FFN-1 GEMM, which writes into "h").
+// mx_rows_w: rows of the block-major MX scale image `wm` points into (0 = p.N: the whole weight; a row RANGE of a fused
+// weight -- the k|v rows of w_qkv -- passes the fused weight's row count and a pointer advanced by the first row)
 static mc_status gemm_fp8_rows(mc_engine* e, const bf16_t* A, long lda, int M, int K, const uint8_t* Wq, const float* ws,
                                const uint8_t* wm, mc::GemmParams p, int epi, hipStream_t s, uint8_t* aq_pre = nullptr,
-                               uint8_t* amx_pre = nullptr) {
+                               uint8_t* amx_pre = nullptr, long mx_rows_w = 0) {
   uint8_t* aq = aq_pre ? aq_pre : e->buf<uint8_t>("aq");
   p.A = (const bf16_t*)aq; p.lda = K; p.W = (const bf16_t*)Wq; p.ldw = K; p.K = K;
   if (wm) {
     uint8_t* am = amx_pre ? amx_pre : e->buf<uint8_t>("a_mx");
     if (A) HIP_TRY(mc::launch_quantize_rows_mx(A, nullptr, lda, M, K, aq, K, am, (long)e->Lp, s));
-    p.a_mx = am; p.mx_rows_a = (long)e->Lp; p.w_mx = wm; p.mx_rows_w = p.N;
+    p.a_mx = am; p.mx_rows_a = (long)e->Lp; p.w_mx = wm; p.mx_rows_w = mx_rows_w ? mx_rows_w : p.N;
     HIP_TRY(mc::launch_gemm_mxfp8(p, epi, s));
     return MC_OK;
   }
@@ -891,7 +894,7 @@ static mc_status block_pre_kv(mc_engine* e, const Layer& l, const float* em, flo
   bool fused = false;
   {
     Prof pr(e, MC_PROF_LN_MODULATE, s);
-    mc_status st = ln_for_gemm(e, !e->sp && l.q_wqkv, l.m_wqkv != nullptr, x, em + d, em, 0, em2 ? em2 + d : nullptr, em2,
+    mc_status st = ln_for_gemm(e, l.q_wqkv != nullptr, l.m_wqkv != nullptr, x, em + d, em, 0, em2 ? em2 + d : nullptr, em2,
                                sel, s, &fused);
     if (st != MC_OK) return st;
   }
@@ -917,7 +920,15 @@ static mc_status block_pre_kv(mc_engine* e, const Layer& l, const float* em, flo
       Prof pr(e, MC_PROF_GEMM_QKV, s);
       mc::GemmParams q = gp(xn, d, l.wqkv + (size_t)d * d, d, l.bqkv + d, Lp, 2 * d, d);
       q.Cb = kvl; q.ldc = 2 * d;
-      HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+      if (l.q_wqkv) {
+        // fp8 Linear modes: rows [d, 3d) of the fused e4m3 weight (+ their per-row / MX scales); the activation rows are
+        // quantised once ("aq": by the fused LayerNorm, or here) and block_pre_q reuses them
+        mc_status st = gemm_fp8_rows(e, fused ? nullptr : xn, d, Lp, d, l.q_wqkv + (size_t)d * d, l.s_wqkv ? l.s_wqkv + d : nullptr,
+                                     l.m_wqkv ? l.m_wqkv + d : nullptr, q, mc::EPI_BF16, s, nullptr, nullptr, 3 * d);
+        if (st != MC_OK) return st;
+      } else {
+        HIP_TRY(mc::launch_gemm_bf16(q, mc::EPI_BF16, s));
+      }
     }
     Prof pr(e, MC_PROF_RMSNORM_ROPE, s);
     HIP_TRY(mc::launch_rmsnorm_rope(kvl, 2 * d, l.nk, e->cfg.eps, e->cs_table, 0, Lp, d, s));
@@ -937,7 +948,12 @@ static mc_status block_pre_q(mc_engine* e, const Layer& l, hipStream_t s) {
     Prof pr(e, MC_PROF_GEMM_QKV, s);
     mc::GemmParams p = gp(xn, d, l.wqkv, d, l.bqkv, Lp, d, d);
     p.Cb = qkv; p.ldc = d;
-    HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    if (l.q_wqkv) {    // rows [0, d) of the fused weight on the activation rows block_pre_kv left quantised in "aq"
+      mc_status st = gemm_fp8_rows(e, nullptr, d, Lp, d, l.q_wqkv, l.s_wqkv, l.m_wqkv, p, mc::EPI_BF16, s, nullptr, nullptr, 3 * d);
+      if (st != MC_OK) return st;
+    } else {
+      HIP_TRY(mc::launch_gemm_bf16(p, mc::EPI_BF16, s));
+    }
   }
   Prof pr(e, MC_PROF_RMSNORM_ROPE, s);
   HIP_TRY(mc::launch_rmsnorm_rope(qkv, d, l.nq, e->cfg.eps, e->cs_table, 0, Lp, d, s));
@@ -1408,7 +1424,10 @@ mc_status mc_blocks_sp(mc_engine* e, int layer_begin, int layer_end, int branch,
     else
       g_n_cu = 256;
   }
-  const bool underfilled = ((e->Lp / 256) * e->H) % g_n_cu != 0;       // one workgroup = 256 query rows of one head = one CU
+  // one workgroup = 256 query rows of one head = one CU: the launch runs in ceil(wg / CUs) waves of which the last is partial
+  const long wg = (long)(e->Lp / 256) * e->H, waves = (wg + g_n_cu - 1) / g_n_cu;
+  const bool underfilled = wg * 10 < waves * g_n_cu * 9;               // < 90 % of the CU slots it occupies (sp 4 / 8 at 1.3B: 75 %;
+                                                                       // 14B at sp 8: 1480 workgroups = 96 %: the merge would only cost)
   const bool partials = (g_sp_attn_partials == 2 || (g_sp_attn_partials == 1 && underfilled)) && e->P > 1 && 1 + R <= kSpMaxParts;
   if (partials)
     if (mc_status st = sp_side_stream(e); st != MC_OK) return st;

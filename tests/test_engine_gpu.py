@@ -689,6 +689,68 @@ def test_sequence_parallel_overlap_is_deterministic_in_process():
     assert rel_l2(ref, one) < 3e-3
 
 
+@pytest.mark.parametrize("fp8", [1, 2])
+def test_sequence_parallel_fp8_linears_in_process(fp8):
+    """BASELINE.json config 5's combination -- the fp8 MFMA weight path on a sequence-parallel engine: the sharded engine runs
+    its q|k|v Linear as k|v + q launches on ROW RANGES of the fused e4m3 weight (per-row scales, mode 1; MX block scales, mode 2:
+    a pointer into the block-major scale image + the fused weight's row count) over activation rows quantised once.  Both
+    ranks' engines of a 2-way job in one process (copies play the gather), against the 1-rank fp8 engine: the quantisation is
+    per row / per 32-element block of a row, so sharding the rows changes nothing but the attention merge's bf16 rounding."""
+    cfg = dict(W.WAN_T2V_1_3B, num_layers=2, fp8_linear=fp8)
+    grid = (2, 32, 64)                      # 1024 tokens -> 512 per rank
+    L = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+    from magcache_amd.engine import synthetic_weights
+    sd = dict(synthetic_weights(cfg, seed=5, device=DEV))
+    d = cfg["dim"]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    lat = torch.randn(16, *grid, generator=g, device=DEV)
+    ctx = torch.randn(77, cfg["text_dim"], generator=g, device=DEV)
+    t = torch.tensor([611.0], device=DEV)
+    eng = []
+    for r in range(2):
+        e = Engine(cfg, grid, device=DEV, sp_rank=r, sp_size=2, n_branches=1, calibration=False)
+        e.load_weights(sd)
+        e.sp_set_chunks(2)
+        eng.append(e)
+    R, Lc, _ = eng[0].sp_round_info(0)
+    kvl = [e.buffer("kv_local", torch.bfloat16).view(-1, 2 * d) for e in eng]
+    kvg = [e.buffer("kv_gather", torch.bfloat16).view(2, 2, Lc, 2 * d) for e in eng]
+    for e in eng:
+        e.embed(lat, t, ctx)
+    for layer in range(2):
+        for e in eng:
+            e.block_pre_attn(layer)
+        for c in range(R):
+            for dst in range(2):
+                for src in range(2):
+                    kvg[dst][c, src].copy_(kvl[src][c * Lc:(c + 1) * Lc])
+        for e in eng:
+            e.block_attn_local(layer)
+            e.block_post_attn(layer, 0, MC_MODE_FULL)      # attends the rounds the caller has not
+    outs = []
+    for e in eng:
+        e.head(0, MC_MODE_FULL)
+        outs.append(e.buffer("head_tokens", torch.float32).view(-1, 64)[:L // 2].clone())
+    got = torch.cat(outs)
+    def one_rank(c):
+        e1 = Engine(c, grid, device=DEV, n_branches=1, calibration=False)
+        e1.load_weights(sd)
+        e1.embed(lat, t, ctx)
+        for layer in range(2):
+            e1.block_pre_attn(layer)
+            e1.block_post_attn(layer, 0, MC_MODE_FULL)
+        e1.head(0, MC_MODE_FULL)
+        out = e1.buffer("head_tokens", torch.float32).view(-1, 64)[:L].clone()
+        torch.cuda.synchronize()
+        return out
+    one8, one16 = one_rank(cfg), one_rank(dict(cfg, fp8_linear=0))
+    # the bar: sharding (k|v + q launches on row ranges of the fused fp8 weight, the attention chain's bf16 merges) perturbs the
+    # result by less than half of what the fp8 mode itself costs against bf16 (a wrong scale offset would be O(1))
+    d_shard, e_mode = rel_l2(got, one8), rel_l2(one8, one16)
+    _probe(f"sp_fp8_linear_{fp8}", dict(sharded_vs_one_rank=d_shard, fp8_vs_bf16=e_mode))
+    assert bool(torch.isfinite(got).all()) and d_shard < 0.5 * e_mode and d_shard < 2e-2, (d_shard, e_mode)
+
+
 def test_wan22_ti2v_per_token_timesteps_vs_reference_golden(golden_dir):
     """Wan2.2 TI2V-5B path: t [1, seq_len] with t = 0 on the conditioning frame's tokens.  The golden is the
     reference's own Wan2.2 magcache_forward run around the per-token oracle (oracle/gen_golden_wan22.py, fp32); the

@@ -19,7 +19,10 @@ chunk crosses its own xGMI link (fully connected, 7 links per GPU), so a round o
 bytes / per-link rate; rates: 48 GB/s (a pessimistic RCCL all-gather figure per link) and 100 GB/s (two thirds of the 153
 GB/s link peak), latency 20 us per round.
 
-    python tools/sp_timeline.py [layers=4] [reps=3]
+    python tools/sp_timeline.py [layers=4] [reps=3] [model=1.3b|14b]
+
+model 14b = BASELINE.json configs[3]: Wan2.1-T2V-14B 720p 81 frames (75 600 tokens, d = 5120, 40 heads), sp 8 only (2 layers fit
+comfortably; the per-layer times do not depend on the depth).
 """
 import json
 import os
@@ -29,7 +32,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from magcache_amd import _lib  # noqa: E402
-from magcache_amd.engine import MC_MODE_FULL, WAN_T2V_1_3B, Engine, synthetic_weights  # noqa: E402
+from magcache_amd.engine import MC_MODE_FULL, WAN_T2V_1_3B, WAN_T2V_14B, Engine, synthetic_weights  # noqa: E402
 
 LIB = _lib.load()
 
@@ -37,7 +40,10 @@ DEV = "cuda:0"
 GRID = (21, 60, 104)
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-cfg = dict(WAN_T2V_1_3B, num_layers=layers)
+MODEL = sys.argv[3] if len(sys.argv) > 3 else "1.3b"
+if MODEL == "14b":
+    GRID = (21, 90, 160)
+cfg = dict(WAN_T2V_14B if MODEL == "14b" else WAN_T2V_1_3B, num_layers=layers)
 g = torch.Generator(device=DEV).manual_seed(0)
 lat = torch.randn(16, *GRID, generator=g, device=DEV)
 ctx = torch.randn(512, cfg["text_dim"], generator=g, device=DEV)
@@ -127,7 +133,7 @@ def timeline(pl, pairs, P, R, Lc, rate_gbs, lat_us=20.0, attn_ms=None):
 
 
 out = []
-for P in (2, 4, 8):
+for P in ((8,) if MODEL == "14b" else (2, 4, 8)):
     for C in (1, 4):
         pl, pairs, R, Lc, walls = measure(P, C)
         # attention of the two-stream form = the chain's attention minus what the layer loop's wall time lost
