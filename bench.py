@@ -510,12 +510,17 @@ def bench_main():
     # MC_BENCH_FORCE_DIST=1 (tests/test_rccl_gpu.py): create the communicator at world size 1 too, so that the N > 1
     # code around the timed regions (init on the device, all-reduce, barrier, teardown) runs on RCCL on a one-GPU box
     force_dist = world == 1 and os.environ.get("MC_BENCH_FORCE_DIST") == "1"
+    # MC_BENCH_FORCE_SP=1 (with FORCE_DIST): the WHOLE N > 1 flow on one GPU -- layout, a sharded engine (mc_config.sp_phases:
+    # the sequence-parallel phase path with a world of one), the start-up self-check, the library-side RCCL communicator and
+    # one mc_forward_sp_rccl per forward, the N > 1 report -- so that none of it meets a GPU for the first time on 8 of them
+    force_sp = force_dist and os.environ.get("MC_BENCH_FORCE_SP") == "1"
+    multi = world > 1 or force_sp
     barrier = (lambda: dist.barrier()) if (world > 1 or force_dist) else (lambda: None)
 
     def make_model(layout, tag):
         cls = type("WanModelHIP_" + tag, (M.WanModelHIP,), {})     # MagCache state lives on the class: one per layout
         m = cls(cfg, GRID, device=device, calibration=False, sp_rank=layout.sp_rank if layout else 0,
-                sp_size=layout.sp_size if layout else 1, sp_group=layout.sp_group if layout else None)
+                sp_size=layout.sp_size if layout else 1, sp_group=layout.sp_group if layout else None, sp_phases=force_sp)
         m.engine.load_weights(synthetic_weights(cfg, seed=0, device=device))
         return m
 
@@ -551,6 +556,7 @@ def bench_main():
         dist.all_reduce(ones)
         extra["rccl_world"] = int(ones[0])
         extra["comm_backend"] = dist.get_backend()
+    if multi:
         names = ["sp"] + (["cfg2sp"] if world % 2 == 0 else [])
         if args.layout != "auto":
             assert args.layout in names, f"--layout {args.layout} needs an even number of ranks"
@@ -598,7 +604,7 @@ def bench_main():
                 torch.cuda.empty_cache()
             stage(f"build engine ({n})")
             model, built = make_model(layouts[n], n), n
-            if layouts[n].sp_size > 1 and "sp_selfcheck_rel" not in extra:
+            if (layouts[n].sp_size > 1 or force_sp) and "sp_selfcheck_rel" not in extra:
                 selfcheck(model, n)
             if len(names) > 1:
                 # ---- layout ablation: 2 no-cache steps of every candidate after 1 untimed step; the faster one is benchmarked
@@ -683,11 +689,11 @@ def bench_main():
     if rank == 0:
         # the shim caches the text context per prompt (mc_set_context): its K / V projections are not in the forwards
         fl = flops_forward(cfg, SEQ, ctx_cached=True)
-        line = contract_line(args, world, "single GPU" if world == 1 else layout.describe(), t_mc, t_nc, skipped, fl, psnr,
+        line = contract_line(args, world, layout.describe() if multi else "single GPU", t_mc, t_nc, skipped, fl, psnr,
                              {"magcache": latent_probe(lat_mc), "nocache": latent_probe(lat_nc) if t_nc else None},
                              skipped_steps)
         line.update(extra)
-        if world == 1 and not args.no_kernels:
+        if not multi and not args.no_kernels:
             if args.no_table:        # (A/B runs: tools/live_ab.sh) only the live figures
                 tr, tr_src = pmc_traffic("attn_fwd_v5_kernel")
                 k = {"attention_back_to_back": dict(bound="mfma", achieved=None, peak=2500.0, unit="TFLOP/s", frac=None, traffic=tr,
@@ -718,7 +724,7 @@ def bench_main():
                 line["kernels"] = k
             if live:
                 line["kernels_live"] = kernels_live(cfg, *live)
-        if world > 1 and live:
+        if multi and live:
             # rank 0's launch classes.  The K|V all-gather runs on RCCL's own stream and is in no class; what the launch stream
             # IDLED waiting for a gather round is class "sp_wait" (hipEvent pairs around every wait): the exposed
             # communication, the first thing to read in an N-GPU profile
@@ -733,7 +739,7 @@ def bench_main():
                                           "measured": "rank 0, hipEvent pairs on the launch stream around every wait for a "
                                                       "K|V gather round (MC_PROF_SP_WAIT): time the stream idled for the "
                                                       "collective = exposed communication"}
-        if world > 1 and attn_live and attn_live[1] > 0:
+        if multi and attn_live and attn_live[1] > 0:
             # N > 1: rank 0's self-attention launches of the timed no-cache region (cfg2: one full-sequence launch per
             # layer; sequence parallel: local-shard launch + one per gather round per layer), algorithmic FLOPs of its share
             sp = layout.sp_size
@@ -750,7 +756,7 @@ def bench_main():
                                 "kernel": "self-attention, attn_fwd_v5_kernel (32x32x16 lazy / pipelined stream) for every form of "
                                           "the call: one key shard, and the sequence-parallel local-shard + per-round "
                                           "launches with the log-sum-exp merge"}
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, os.cpu_count() or 1)
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:

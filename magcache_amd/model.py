@@ -112,7 +112,7 @@ class WanModelHIP:
     patch_size = (1, 2, 2)
 
     def __init__(self, cfg, latent_grid, device="cuda:0", calibration=True, engine=None, sp_rank=0, sp_size=1,
-                 sp_group=None):
+                 sp_group=None, sp_phases=False):
         self.cfg = dict(cfg)
         for k in ("dim", "ffn_dim", "freq_dim", "text_len", "text_dim", "in_dim", "out_dim", "num_heads",
                   "num_layers"):
@@ -125,7 +125,7 @@ class WanModelHIP:
         self._ctx_keys = [None, None]     # text-context cache: identity of the tensor held by engine slot 0 / 1
         self._ctx_lru = 0
         self.engine = engine or Engine(cfg, latent_grid, device=device, n_branches=2, calibration=calibration,
-                                       sp_rank=sp_rank, sp_size=sp_size)
+                                       sp_rank=sp_rank, sp_size=sp_size, sp_phases=sp_phases)
         self.device = self.engine.device
         self.sp_group = sp_group      # torch.distributed group of the ranks that share this token sequence
 

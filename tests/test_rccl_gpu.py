@@ -45,3 +45,36 @@ def test_bench_line_through_rccl_at_world_one():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["rccl_world"] == 1 and line["comm_backend"] == "nccl" and line["n_gpus"] == 1
     assert line["value"] > 0 and line["forwards_total"] == 20
+
+
+def test_bench_whole_multi_gpu_flow_on_one_gpu_through_the_library_side_rccl():
+    """bench.py with MC_BENCH_FORCE_DIST=1 MC_BENCH_FORCE_SP=1: everything the driver's --gpus 8 launch runs -- layout, a sharded
+    engine (the sequence-parallel phase path with a world of one), the start-up self-check of overlapped vs serialised
+    forwards, the library-side RCCL communicator with ONE mc_forward_sp_rccl per forward, the N > 1 report (sp_collective,
+    sp_gather_wait, rank 0's launch classes, per-GPU roofline) -- on the one GPU there is, with the real collective library.
+    The final latents equal the plain single-GPU run's."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "0", "--no_cpu_baseline",
+            "--no_table"]
+    r = subprocess.run(base, env=dict(_env(29585), MC_BENCH_FORCE_DIST="1", MC_BENCH_FORCE_SP="1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    one = subprocess.run(base, env=_env(29587), capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-3000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert got["rccl_world"] == 1 and got["comm_backend"] == "nccl" and got["layout"] == "sp"
+    assert "RCCL communicator inside the library" in got["sp_collective"] and "rccl" in got["sp_collective"], got["sp_collective"]
+    assert got["sp_chunks"] == 4 and got["sp_rounds"] == 4 and got["sp_overlap"] is True and got["sp_selfcheck_rel"] <= 3e-3
+    assert got["forwards_skipped"] == ref["forwards_skipped"] > 0 and got["skipped_steps"] == ref["skipped_steps"]
+    for which in ("magcache", "nocache"):
+        a, b = got["final_latent_probe"][which], ref["final_latent_probe"][which]
+        assert abs(a["l2"] - b["l2"]) < 2e-3 * b["l2"] and max(abs(x - y) for x, y in zip(a["samples"], b["samples"])) < 3e-2 * b["rms"]
+    k = got["kernels_live_rank0"]["classes"]
+    # 3 live steps x 2 forwards x 30 layers: four gather rounds each (of the rank's own rows), ONE attention launch (a world of
+    # one: the local shard is every key, the rounds have nothing left to attend)
+    assert k["sp_wait"]["pairs"] == 6 * 30 * 4 and k["attn_self"]["pairs"] == 6 * 30
+    w = got["sp_gather_wait"]
+    assert w["waits_per_layer"] == 4 and 0.0 <= w["frac_of_forward_wall"] < 0.2
+    assert got["roofline"]["bound"] == "mfma" and 0.3 < got["roofline"]["frac"] < 1.0 and "kernels_live" not in got
+    # the sharded path costs a world of one little: the same kernels + the chain's merges and an all-gather of its own rows
+    assert got["nocache_steps_per_s"] > 0.85 * ref["nocache_steps_per_s"]
