@@ -597,9 +597,10 @@ def bench_main():
                 "torch.distributed from the gather callback of mc_blocks_sp (" + str(dist.get_backend()) + ")" + \
                 (f"; the library-side communicator was not used: {sp.rccl_error}" if getattr(sp, "rccl_error", None) else "")
 
-        model, built, abl = None, None, {}
+        model, built, abl, m = None, None, {}, None
         for n in names:
             if model is not None:
+                m = None                 # (the ablation's alias of the same object)
                 del model
                 torch.cuda.empty_cache()
             stage(f"build engine ({n})")
@@ -623,6 +624,7 @@ def bench_main():
             chosen = names[0]
         layout = layouts[chosen]
         if built != chosen:
+            m = None
             del model
             torch.cuda.empty_cache()
             stage(f"build engine ({chosen}, chosen)")
