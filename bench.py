@@ -418,10 +418,38 @@ def engine_bytes_estimate(cfg, sp_size=1):
 
 
 STAGE = ["start"]        # where a failure happened (reported in the error line of a multi-GPU run)
+STAGE_T = [0.0]          # when it was entered (the watchdog of a multi-GPU run)
 
 
 def stage(name):
+    import time
     STAGE[0] = name
+    STAGE_T[0] = time.time()
+
+
+def start_watchdog(world, rank):
+    """N > 1: a collective that never completes (a rank that died, a communicator that deadlocks) blocks the main thread in a
+    device synchronisation for ever -- torch.distributed's own timeout covers its process group, not the library-side RCCL
+    communicator.  A daemon thread ends the run with the ONE parseable JSON line (rank 0) when a stage has not advanced for
+    MC_BENCH_STAGE_TIMEOUT_S seconds (default 900), so that the driver gets a reason instead of its own kill."""
+    import threading
+    import time
+    limit = float(os.environ.get("MC_BENCH_STAGE_TIMEOUT_S", "900"))
+    stage(STAGE[0])
+
+    def watch():
+        while True:
+            time.sleep(5.0)
+            if time.time() - STAGE_T[0] > limit:
+                if rank == 0:
+                    print(json.dumps({"metric": "denoising steps/sec (MagCache on), Wan2.1-T2V-1.3B 480p 81f", "value": None,
+                                      "unit": "steps/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong",
+                                      "error": f"stage '{STAGE[0]}' did not finish within {limit:.0f} s (watchdog: a collective "
+                                               "that never completed?)", "stage": STAGE[0]}), flush=True)
+                else:
+                    sys.stderr.write(f"[rank {rank}] watchdog: stage '{STAGE[0]}' exceeded {limit:.0f} s\n")
+                os._exit(3)
+    threading.Thread(target=watch, daemon=True).start()
 
 
 def main():
@@ -432,6 +460,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     if world == 1:
         return bench_main()
+    start_watchdog(world, rank)
     try:
         return bench_main()
     except BaseException as e:   # noqa: BLE001  (SystemExit from argparse included: the line is the contract)

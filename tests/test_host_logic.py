@@ -705,6 +705,25 @@ def test_bench_multi_gpu_failure_ends_in_a_parseable_line():
     assert line["value"] is None and line["n_gpus"] == 2 and "no GPU" in line["error"] and line["stage"]
 
 
+def test_bench_watchdog_ends_a_hung_multi_gpu_stage_with_the_line():
+    """bench.start_watchdog (N > 1): a stage that does not advance -- a collective of the library-side communicator that never
+    completes blocks the main thread for ever -- ends the run with rank 0's ONE JSON line and exit code 3."""
+    import subprocess
+    import sys
+    code = ("import importlib.util, time, sys\n"
+            "spec = importlib.util.spec_from_file_location('b', sys.argv[1]); b = importlib.util.module_from_spec(spec)\n"
+            "spec.loader.exec_module(b)\n"
+            "b.stage('sequence-parallel self-check (sp)'); b.start_watchdog(8, 0)\n"
+            "time.sleep(60)\n")
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "bench.py")], env=dict(os.environ, MC_BENCH_STAGE_TIMEOUT_S="2",
+                       PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == 8 and line["stage"] == "sequence-parallel self-check (sp)" and "watchdog" in line["error"]
+
+
 def test_rccl_is_bound_at_run_time_from_the_process_own_copy():
     """csrc/sp_rccl.cpp binds RCCL with dlopen (no link dependency: `ldd libmagcache_hip.so` shows no librccl) and prefers the
     copy already mapped into the process -- PyTorch-ROCm's, which sits on the same HIP runtime as the engine.  Needs no GPU:
