@@ -760,3 +760,33 @@ def test_reference_library_is_current():
     assert lib.mc_set_option(b"gemm_kernel", 2) == _lib.MC_OK          # the reference build has the 8-wave kernel ...
     lib.mc_set_option(b"gemm_kernel", 0)
     assert _lib.load().mc_set_option(b"gemm_kernel", 2) == _lib.MC_EINVAL   # ... the shipped one refuses it
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h are the drop-in boundary: they must compile as C99 (gcc -pedantic), with nothing but <stddef.h> / <stdint.h>
+    behind them, and the C host of INTEGRATION.md section 4 must at least parse against them."""
+    import subprocess
+    src = tmp_path / "host.c"
+    src.write_text('''
+#include "magcache_hip.h"
+#include "magcache_mmdit.h"
+int run(mc_engine* e, mc_sp_comm* comm, mc_rule* rule, const float* latent, const void* ctx, float* tokens_full, float* out, mc_stream s) {
+  mc_config cfg = { .dim = 1536, .sp_rank = 0, .sp_size = 8, .n_branches = 2 };
+  char id[MC_SP_ID_BYTES];
+  int branch, rc = 0;
+  (void)cfg;
+  if (!mc_sp_rccl_available()) return 1;
+  rc |= mc_sp_comm_id(id);
+  rc |= mc_sp_comm_create(id, 8, 0, &comm);
+  rc |= mc_sp_set_chunks(e, 4);
+  {
+    int skip = mc_rule_step(rule, &branch);
+    rc |= mc_forward_sp_rccl(e, comm, latent, 0, 500.0, ctx, MC_F32, 512, branch, skip ? MC_MODE_SKIP : MC_MODE_FULL, 1, tokens_full, out, s);
+  }
+  mc_sp_comm_destroy(comm);
+  return rc;
+}
+''')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only",
+                        str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
