@@ -640,9 +640,10 @@ def bench_main():
                 # ---- layout ablation: 2 no-cache steps of every candidate after 1 untimed step; the faster one is benchmarked
                 stage(f"layout ablation ({n})")
                 m = M.disable_magcache(model)
+                k_abl = max(1, int(os.environ.get("MC_BENCH_ABLATION_STEPS", "2")))     # (the one-GPU multi-rank tests: 1)
                 run(m, layouts[n], 1)
-                dt, _ = timed(lambda: run(m, layouts[n], 2), sync, barrier)
-                abl[n] = 2.0 / max_over_ranks(dt)
+                dt, _ = timed(lambda: run(m, layouts[n], k_abl), sync, barrier)
+                abl[n] = k_abl / max_over_ranks(dt)
         if len(names) > 1:
             extra["layout_ablation_nocache_steps_per_s"] = abl
             chosen = max(abl, key=abl.get)

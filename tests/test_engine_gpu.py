@@ -453,7 +453,7 @@ def test_bench_two_ranks_one_gpu(nproc, extra, par, steps):
     4096 rows per rank (a 63-key tail in the last 64-key tile of every shard's last gather round), 7 remote shards merged by
     log-sum-exp over 4 rounds; cfg2 x sp4 = 8190 of 8192 rows.  Two steps keep the gloo traffic (1.4 GB per layer through host
     memory) inside a test; whatever the rule skips in step 1, the check is the FINAL LATENT itself against the single-process run."""
-    env = dict(os.environ, PYTHONPATH=ROOT, MC_BENCH_BACKEND="gloo")
+    env = dict(os.environ, PYTHONPATH=ROOT, MC_BENCH_BACKEND="gloo", MC_BENCH_ABLATION_STEPS="1")
     base = [os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "0", "--no_cpu_baseline", "--no_table"]
     if nproc >= 4:
         base.append("--no_kernels")
