@@ -255,9 +255,10 @@ mc_status mc_block_post_attn(mc_engine* e, int layer, int branch, mc_mode mode, 
 /* The same layer loop in ONE call (sp_size > 1).  For every layer in [layer_begin, layer_end) the engine runs pre_kv, calls
  * gather(user, layer, 2 c, stream) for every round c -- the caller STARTS round c of the all-gather on its own communicator,
  * ordered behind the work `stream` already holds --, runs pre_q and the local-shard attention beside them, then per round
- * gather(user, layer, 2 c + 1, stream) -- the caller makes `stream` wait for round c, no host sync -- and the attention over
- * that round; with overlap == 0 every wait comes right after the starts, so that nothing runs beside the collective; then
- * post_attn.  A VACE control block follows its main layer in the same phases with its own gather.  With C = 1 the phase
+ * gather(user, layer, 2 c + 1, s) -- the caller makes the stream `s` it is HANDED wait for round c, no host sync: the launch
+ * stream, or the engine's side stream when the chain's launches alternate between the two (sp_attn_partials) -- and the
+ * attention over that round; with overlap == 0 every wait comes right after the starts, on the launch stream, so that
+ * nothing runs beside the collective; then post_attn.  A VACE control block follows its main layer in the same phases with its own gather.  With C = 1 the phase
  * argument is 0 (start) / 1 (wait).  The callback returns 0 on success; anything else aborts the loop with MC_ESTATE.  The
  * waits are logged as MC_PROF_SP_WAIT.  A C / C++ host calls ncclAllGather + hipStreamWaitEvent in the callback
  * (mc_blocks_sp_rccl below does exactly that), the Python shim torch.distributed (magcache_amd/parallel.py: the gloo / test
