@@ -19,6 +19,21 @@ inputs.  What is executed from the reference, verbatim:
   * videosys/models/modules/attentions.py:21-100    OpenSoraAttention.forward (imported, stub `diffusers` and
         videosys.core) with qk_norm=True and a rope callable: qk-norm -> RoPE -> SDPA -> proj, against the same chain
         assembled from the oracle's WanRMSNorm / rope_apply / attention_ref_fp32
+  * videosys/models/modules/embeddings.py:54-105    OpenSoraPatchEmbed3D (imported): Conv3d(k = s = patch) -> flatten(2).transpose(1, 2)
+        -> the oracle's patch_embedding + flatten of WanModel.embed: the TOKEN ORDER (frame-major, then rows, then columns)
+  * videosys/models/transformers/open_sora_transformer_3d.py:46-47,50-86  t2i_modulate + T2IFinalLayer (class source exec'd):
+        LayerNorm(no affine, eps 1e-6) -> x * (1 + scale) + shift with (shift, scale) = (table + t).chunk(2) -> Linear
+        -> oracle Head (modulation + e.unsqueeze(1)).chunk(2): same order of the two rows, same formula
+  * videosys/models/transformers/open_sora_transformer_3d.py:633-644  unpatchify's rearrange (method lines exec'd):
+        "(N_t N_h N_w) (T_p H_p W_p C_out) -> C_out (N_t T_p) (N_h H_p) (N_w W_p)" -> oracle WanModel.unpatchify
+        (view(*grid, *patch, c) + einsum 'fhwpqrc->cfphqwr'): the layout of the head's output columns
+  * videosys/models/transformers/open_sora_transformer_3d.py:98-273  STDiT3Block (class source exec'd; its attention / cross-
+        attention are the imported reference modules, approx_gelu the imported lambda; timm's Mlp / DropPath are absent and
+        stubbed as fc1 -> act -> fc2 / identity): the AdaLN-Zero block SKELETON -- (table + t).chunk(6) in the order shift, scale,
+        gate (attention) then shift, scale, gate (MLP); x += gate * attn(modulate(norm1 x)); x += cross_attn(x, y); x += gate *
+        mlp(modulate(norm2 x)); LayerNorm without affine, eps 1e-6 -> oracle WanAttentionBlock.forward with its sub-modules
+        replaced by restatements of those three modules (upstream's block differs inside them -- full-width RMSNorm, RoPE,
+        norm3 -- and those pieces have their own pins above)
   * videosys/schedulers/scheduling_rflow_open_sora.py:245-251 (CFG combine + Euler update, source lines exec'd)
         -> oracle flow_solvers_ref.solve(..., "euler") / the CFG line of the sampler (Open-Sora's velocity points from
         noise to data, Wan's from data to noise: the same update with v -> -v, stated in the test)
@@ -145,6 +160,65 @@ def main():
         exec(src, ns)
         out[f"euler_v_pred"] = ns["v_pred"].numpy()
         out[f"euler_z_next_i{i}"] = ns["z"].numpy()
+    # ---- patch embedding: token order of Conv3d(k = s = (1, 2, 2)) + flatten(2).transpose(1, 2)
+    pe = emb.OpenSoraPatchEmbed3D(patch_size=(1, 2, 2), in_chans=16, embed_dim=48)
+    with torch.no_grad():
+        for p_ in pe.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+        lat = torch.randn(1, 16, 3, 6, 10, generator=g)
+        out["pe_w"], out["pe_b"], out["pe_x"] = pe.proj.weight.numpy(), pe.proj.bias.numpy(), lat.numpy()
+        out["pe_tokens"] = pe(lat).numpy()                                   # [1, 3 * 3 * 5, 48]
+
+    # ---- final layer: t2i_modulate + T2IFinalLayer, the reference's own source
+    import torch.nn as nn
+    from einops import rearrange
+    ns = {"torch": torch, "nn": nn, "rearrange": rearrange}
+    exec(ref_lines("videosys/models/transformers/open_sora_transformer_3d.py", 46, 86), ns)
+    fl = ns["T2IFinalLayer"](48, 4, 16)                                      # hidden 48, 1*2*2 patch, 16 channels
+    with torch.no_grad():
+        for p_ in fl.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.2)
+        xf = torch.randn(2, 45, 48, generator=g) * 2.0
+        tf = torch.randn(2, 48, generator=g)
+        out["fl_x"], out["fl_t"] = xf.numpy(), tf.numpy()
+        out["fl_table"], out["fl_w"], out["fl_b"] = fl.scale_shift_table.numpy(), fl.linear.weight.numpy(), fl.linear.bias.numpy()
+        out["fl_out"] = fl(xf, tf).numpy()
+        out["mod_out"] = ns["t2i_modulate"](xf, tf[:, None, :] * 0.5, tf[:, None, :]).numpy()
+
+    # ---- unpatchify: the rearrange of the reference's method (lines 633-644), on the final layer's output
+    src = ref_lines("videosys/models/transformers/open_sora_transformer_3d.py", 633, 644)
+    ns = {"rearrange": rearrange, "x": torch.from_numpy(out["fl_out"]), "N_t": 3, "N_h": 3, "N_w": 5,
+          "self": types.SimpleNamespace(patch_size=(1, 2, 2), out_channels=16)}
+    exec(src, ns)
+    out["unpatch_out"] = ns["x"].numpy()                                     # [2, 16, 3, 6, 10]
+    # ---- the block skeleton: STDiT3Block (spatial variant, one frame), the reference's own class source
+    act = _load("videosys/models/modules/activations.py", "ref_activations")
+
+    class Mlp(nn.Module):                      # timm.models.vision_transformer.Mlp is absent: fc1 -> act -> fc2 (drop = 0)
+        def __init__(self, in_features, hidden_features, act_layer, drop=0):
+            super().__init__()
+            self.fc1, self.act, self.fc2 = nn.Linear(in_features, hidden_features), act_layer(), nn.Linear(hidden_features, in_features)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+    ns = {"torch": torch, "nn": nn, "rearrange": rearrange, "OpenSoraAttention": att.OpenSoraAttention,
+          "OpenSoraMultiHeadCrossAttention": att.OpenSoraMultiHeadCrossAttention, "Mlp": Mlp, "approx_gelu": act.approx_gelu,
+          "DropPath": nn.Identity, "ParallelManager": object, "enable_pab": lambda: False}
+    exec(ref_lines("videosys/models/transformers/open_sora_transformer_3d.py", 46, 47), ns)          # t2i_modulate
+    exec(ref_lines("videosys/models/transformers/open_sora_transformer_3d.py", 98, 273), ns)         # class STDiT3Block
+    C_, nh_, B_, S_, Lc_ = 64, 2, 2, 11, 5
+    blk = ns["STDiT3Block"](C_, nh_, mlp_ratio=2.0, qk_norm=False, temporal=False)
+    blk.parallel_manager = types.SimpleNamespace(sp_size=1)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.15 if p_.dim() > 1 else 0.1))
+        xb = torch.randn(B_, S_, C_, generator=g) * 1.5
+        yb = torch.randn(1, B_ * Lc_, C_, generator=g)                                # the conditions of both samples, concatenated
+        tb = torch.randn(B_, 6 * C_, generator=g) * 0.5
+        out["blk_x"], out["blk_y"], out["blk_t"] = xb.numpy(), yb.numpy(), tb.numpy()
+        out["blk_out"] = blk(xb, yb, tb, mask=[Lc_] * B_, T=1, S=S_).numpy()
+        for k, v in blk.state_dict().items():
+            out["blk_w_" + k] = v.numpy()
     np.savez_compressed(os.path.join(GOLD, "building_blocks_golden.npz"), **out)
     print("wrote building_blocks_golden.npz:", {k: getattr(v, "shape", ()) for k, v in out.items()})
 
