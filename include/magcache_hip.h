@@ -422,6 +422,11 @@ mc_status mc_op_attention_partial(const void* Q_dev, long ldq, const void* K_dev
                                   int Lq_pad, int n_heads, int shard_rows, int shard_valid, int n_shards,
                                   float scale, int skip_shard, float* lse_out_dev, const float* lse_in_dev,
                                   mc_stream stream);
+/* the join of the two-stream attention chain (sequence parallel, sp_attn_partials): out[row, head] = sum_i w_i O_i / sum_i w_i
+ * with w_i = 2^(lse_i[head][row] - max_i lse_i) over n (1..9) normalised partial results on disjoint key sets; o_parts / lse_parts
+ * are HOST arrays of n device pointers (bf16 [rows][ldo] each / fp32 [d / 128][rows_pad] each, log2 units) */
+mc_status mc_op_attn_merge(const void* const* o_parts, const float* const* lse_parts, int n, void* out_bf16_dev, long ldo,
+                           int rows, int rows_pad, int d, mc_stream stream);
 mc_status mc_op_ln_modulate(const float* x_dev, long ldx, const void* x0_dev, long ldx0, const float* sc_dev,
                             const float* sh_dev, int mode, float eps, void* out_bf16_dev, long ldo,
                             float* out_f32_dev, long ldof, int M, int D, mc_stream stream);

@@ -111,6 +111,7 @@ SIGNATURES = {
     "mc_op_quantize_rows_mx": (_i, [_vp, _i, _l, _i, _i, _vp, _l, _vp, _l, _vp]),
     "mc_op_gemm_mxfp8": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
     "mc_op_attention_partial": (_i, [_vp, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "mc_op_attn_merge": (_i, [_vp, _vp, _i, _vp, _l, _i, _i, _i, _vp]),
     "mc_op_ln_modulate": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _f, _vp, _l, _vp, _l, _i, _i, _vp]),
     "mc_op_rmsnorm_rope": (_i, [_vp, _l, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mc_op_skip_add": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp]),

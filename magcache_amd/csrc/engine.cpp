@@ -1859,6 +1859,16 @@ mc_status mc_op_attention_partial(const void* Q, long ldq, const void* K, long l
   return MC_OK;
 }
 
+mc_status mc_op_attn_merge(const void* const* o_parts, const float* const* lse_parts, int n, void* out, long ldo, int rows,
+                           int rows_pad, int d, mc_stream s) {
+  if (!o_parts || !lse_parts || !out) return fail(MC_EINVAL, "attn_merge: null argument");
+  hipError_t err = mc::launch_attn_merge((const bf16_t* const*)o_parts, lse_parts, n, (bf16_t*)out, ldo, rows, rows_pad, d,
+                                         (hipStream_t)s);
+  if (err == hipErrorInvalidValue) return fail(MC_EINVAL, "attn_merge: 1..9 parts, d a multiple of 128, 16-byte rows");
+  HIP_TRY(err);
+  return MC_OK;
+}
+
 mc_status mc_op_ln_modulate(const float* x, long ldx, const void* x0, long ldx0, const float* sc, const float* sh,
                             int mode, float eps, void* out, long ldo, float* out_f32, long ldof, int M, int D,
                             mc_stream s) {

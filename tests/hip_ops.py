@@ -145,6 +145,15 @@ def attention_partial(Q, K, V, O, n_heads, shard_rows, shard_valid, n_shards, sc
                                       n_shards, scale, skip_shard, P(lse_out), P(lse_in), S()))
 
 
+def attn_merge(o_parts, lse_parts, out):
+    """out = log-sum-exp weighted mean of the partial attention results (bf16 [rows, d] each, lse fp32 [heads, rows_pad] each)"""
+    lib = L()
+    n = len(o_parts)
+    op = (C.c_void_p * n)(*[t.data_ptr() for t in o_parts])
+    lp = (C.c_void_p * n)(*[t.data_ptr() for t in lse_parts])
+    check(lib.mc_op_attn_merge(op, lp, n, P(out), out.stride(0), out.shape[0], lse_parts[0].shape[1], out.shape[1], S()))
+
+
 def ln_modulate(x, sc, sh, mode, eps, out_bf16=None, out_f32=None, x0=None):
     lib = L()
     M, D = x.shape

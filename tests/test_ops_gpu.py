@@ -694,6 +694,59 @@ def test_attention_two_phase_local_then_remote(Lq, heads, shard_rows, valid, n_s
     torch.testing.assert_close(lse2, torch.logsumexp(s_all, -1) / math.log(2), rtol=1e-2, atol=5e-2)
 
 
+@pytest.mark.parametrize("Lq,heads,rounds,chunk,valid_last", [(256, 2, 4, 64, 63), (512, 1, 3, 128, 100), (256, 3, 2, 192, 192)])
+def test_attention_chain_over_gather_rounds_in_place_and_as_partials(Lq, heads, rounds, chunk, valid_last, attn_variant):
+    """The two forms of a sequence-parallel layer's attention (round 6).  Keys = a local shard + `rounds` gather rounds of P = 3
+    shards x `chunk` rows (the last round with a ragged tail), this rank's shard left out of every round.
+    chain: every launch merges into O / lse IN PLACE (lse_in == lse_out: the same buffer) -- mc_block_attn_local / _round;
+    partials: every launch into its own slot, joined once by attn_merge in fp32 -- mc_blocks_sp's two-stream form.
+    Both == one pass over all valid keys == the fp32 reference; the partial form is the closer one (fewer bf16 roundings)."""
+    P_, rank, d = 3, 1, heads * 128
+    sc = 1 / math.sqrt(128)
+    q = rnd(Lq, d, seed=1, dtype=torch.bfloat16)
+    local = rnd(chunk * rounds, 2 * d, seed=2, dtype=torch.bfloat16)                      # this rank's k|v rows
+    gathered = rnd(rounds, P_, chunk, 2 * d, seed=3, dtype=torch.bfloat16)                # [C][P][Lc][2d]
+    n_local = chunk * (rounds - 1) + valid_last
+    for c in range(rounds):
+        gathered[c, rank] = local[c * chunk:(c + 1) * chunk]                               # the gather delivers the own rows too
+    valids = [chunk] * (rounds - 1) + [valid_last]
+    # reference over every valid key: the local shard + the other ranks' chunks
+    ks = [local[:n_local]] + [gathered[c, r, :valids[c]] for c in range(rounds) for r in range(P_) if r != rank]
+    allk = torch.cat(ks)
+    want = attn_ref(q, allk[:, :d].contiguous(), allk[:, d:].contiguous(), heads, torch.arange(allk.shape[0], device=DEV))
+    # ---- chain, in place
+    o = torch.zeros(Lq, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((heads, Lq), float("nan"), device=DEV)
+    H.attention_partial(q, local[:, :d], local[:, d:], o, heads, chunk * rounds, n_local, 1, sc, 0, lse_out=lse)
+    for c in range(rounds):
+        g = gathered[c].reshape(P_ * chunk, 2 * d)
+        last = c == rounds - 1
+        H.attention_partial(q, g[:, :d], g[:, d:], o, heads, chunk, valids[c], P_, sc, chunk * 2 * d, skip_shard=rank,
+                            lse_out=None if last else lse, lse_in=lse)
+    torch.testing.assert_close(o.float(), want, rtol=2e-2, atol=2e-2)
+    e_chain = rel_l2(o, want)
+    # ---- partials + merge
+    parts = [torch.zeros(Lq, d, dtype=torch.bfloat16, device=DEV) for _ in range(1 + rounds)]
+    lses = [torch.full((heads, Lq), float("nan"), device=DEV) for _ in range(1 + rounds)]
+    H.attention_partial(q, local[:, :d], local[:, d:], parts[0], heads, chunk * rounds, n_local, 1, sc, 0, lse_out=lses[0])
+    for c in range(rounds):
+        g = gathered[c].reshape(P_ * chunk, 2 * d)
+        H.attention_partial(q, g[:, :d], g[:, d:], parts[1 + c], heads, chunk, valids[c], P_, sc, chunk * 2 * d, skip_shard=rank,
+                            lse_out=lses[1 + c])
+    merged = torch.zeros(Lq, d, dtype=torch.bfloat16, device=DEV)
+    H.attn_merge(parts, lses, merged)
+    torch.testing.assert_close(merged.float(), want, rtol=2e-2, atol=2e-2)
+    e_part = rel_l2(merged, want)
+    assert e_chain < 1e-2 and e_part < 1e-2 and e_part <= e_chain * 1.05 + 1e-4, (e_chain, e_part)
+    # the merge kernel against its own definition in fp32 on the stored partials: only the final bf16 rounding apart
+    w = torch.stack(lses)                                                                  # [n, heads, Lq], log2 units
+    wt = torch.exp2(w - w.max(0).values)
+    wt = (wt / wt.sum(0)).permute(0, 2, 1)[..., None]                                      # [n, Lq, heads, 1]
+    ref = (torch.stack([p.float().view(Lq, heads, 128) for p in parts]) * wt).sum(0).reshape(Lq, d)
+    torch.testing.assert_close(merged.float(), ref, rtol=1e-2, atol=1e-3)
+    assert rel_l2(merged, ref) < 3e-3
+
+
 def test_attention_two_phase_rejects_bad_selection():
     q = rnd(256, 128, dtype=torch.bfloat16)
     o = torch.zeros_like(q)
